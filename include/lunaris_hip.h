@@ -1,0 +1,117 @@
+/* lunaris_hip.h — C ABI of liblunaris_hip.so: the MI355X (gfx950) kernels behind the Lunaris-Orion VAE training step.
+ *
+ * The reference (MeryylleA/Lunaris-Orion) has no FFI / operator-plugin interface: its hot path
+ * (TrainingManager._process_batch, /root/reference/train_hybrid.py:838-954) calls PyTorch ATen ops directly.  This
+ * header therefore DEFINES the boundary; every entry point cites the reference lines whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding the Python host uses (lunaris_orion_amd/_lib.py).
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer (tensor.data_ptr()); the caller owns all memory, including workspaces;
+ *     the library never allocates or frees device memory and never synchronises the device;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value: 0 = ok, <0 = error class (-1 bad argument/unsupported shape, -2 HIP error, -3 bad state); the
+ *     message is available from lo_last_error() (thread-local);
+ *   - activations inside the library are fp16 NHWC; tensors crossing the boundary are fp32 in PyTorch's layouts
+ *     (images / reconstructions NCHW, parameters in their nn.Module layouts);
+ *   - gradients flowing between kernels are multiplied by `loss_scale` (fp16 range); every parameter gradient that
+ *     leaves the library is un-scaled (true gradient, fp32).
+ */
+#ifndef LUNARIS_HIP_H
+#define LUNARIS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* lo_last_error(void);
+int lo_version(void);
+
+/* ---- op kinds for the generic implicit-GEMM entry points ---------------------------------------------------- */
+enum {
+  LO_KIND_CONV3_S1 = 0,        /* nn.Conv2d(k3,s1,p1)           lunar_generate.py:36,41          */
+  LO_KIND_CONV3_S2 = 1,        /* nn.Conv2d(k3,s2,p1)           lunar_generate.py:102,109,116    */
+  LO_KIND_CONVT4_S2 = 2,       /* nn.ConvTranspose2d(k4,s2,p1)  lunar_generate.py:169,175,181,187 */
+  LO_KIND_CONV3_S1_DGRAD = 3,  /* aten::convolution_backward (input grad) of the above           */
+  LO_KIND_CONV3_S2_DGRAD = 4,
+  LO_KIND_CONVT4_S2_DGRAD = 5,
+  LO_KIND_LINEAR = 6           /* nn.Linear                      lunar_generate.py:124,125,165    */
+};
+
+/* ---- single-op entry points (used by the parity tests; the step executor below calls the same launchers) ----- */
+
+/* Packed fp16 weight size (elements) for an op of `kind` reading [B,H,W,Cin] and writing Cout channels. */
+size_t lo_packed_weight_elems_for(int kind, int B, int H, int W, int Cin, int Cout);
+/* canonical fp32 weight (nn.Module layout) -> packed fp16 operand of the implicit GEMM */
+int lo_pack_weight_for(int kind, int B, int H, int W, int Cin, int Cout, const float* w, void* wp, void* stream);
+/* out = conv(in) + bias (+ add_src); optional GroupNorm partial sums [B][MT][8][2]; returns MT through *mt_out.
+ * in/out/add_src: fp16 NHWC.  Replaces aten::convolution / aten::addmm. */
+int lo_conv_forward(int kind, int B, int H, int W, int Cin, int Cout, const void* in, const void* wp, const float* bias,
+                    const void* add_src, void* out, float* gn_partial, int* mt_out, void* stream);
+/* Linear with split-K: y[M,N] (fp32 and/or fp16) = x[M,K] Wp[N,K]^T + bias.  slab: nsplit*M*N floats. */
+int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab, int nsplit,
+                     float* out32, void* out16, void* stream);
+/* weight gradient of a FORWARD op `kind` (0,1,2,6): grad (canonical fp32 layout) = scale * sum_pixels dy (x) x. */
+size_t lo_wgrad_slab_bytes_for(int kind, int B, int H, int W, int Cin, int Cout);
+int lo_conv_wgrad(int kind, int B, int H, int W, int Cin, int Cout, const void* x, const void* dy, float* slab,
+                  float* grad, float scale, void* stream);
+
+/* GroupNorm(8,C)+Mish forward on the raw conv output v (fp16 NHWC): mode 0 y=mish(u); 1 y=mish(u)+other;
+ * 2 y=mish(mish(u)+other) (ResBlock tail, lunar_generate.py:49-53).  stats[B][8][2] = (mean, rstd) is written. */
+int lo_gn_mish_forward(const void* v, const float* gn_partial, int MT, const float* gamma, const float* beta,
+                       const void* other, void* y, float* stats, int B, int HW, int C, int mode, void* stream);
+/* backward of the above: dv (fp16), ds (mode 2: gradient of the identity branch), dgamma/dbeta/dbias (fp32 * scale).
+ * P1: B*nchunk*C*2 floats, P2: B*nchunk*C floats of scratch (nchunk = lo_gn_nchunk(HW,C) <= 64). */
+int lo_gn_nchunk_for(int HW, int C);
+int lo_gn_mish_backward(const void* dy, const void* v, const void* other, const float* stats, const float* gamma,
+                        const float* beta, void* ds, void* dv, float* P1, float* P2, float* dgamma, float* dbeta,
+                        float* dbias, int B, int HW, int C, int mode, float scale, void* stream);
+
+/* first conv Conv2d(3,64,k3,s2,p1) on fp32 NCHW images (lunar_generate.py:95) and its weight gradient */
+int lo_first_conv_forward(const float* x, const float* w, const float* bias, void* v, float* gn_partial, int B, void* stream);
+int lo_first_conv_wgrad_op(const float* x, const void* dv, float* partial /*B*8*1728*/, float* dw, int B, float scale, void* stream);
+/* final conv Conv2d(32,3,k3,p1)+tanh (+MSE partial sums, B*64 floats) (lunar_generate.py:192,227-228; train_hybrid.py:859) */
+int lo_final_conv_forward(const void* a4, const float* w, const float* bias, const float* target, float* recon,
+                          float* mse_partial, int B, void* stream);
+int lo_final_conv_backward(const void* a4, const float* w, const float* recon, const float* target, const float* drecon,
+                           const float* coef_dev, float gscale, void* da4, float* partial /*B*64*867*/, float* dw,
+                           float* db, int B, float scale, void* stream);
+
+/* clip_grad_norm_ + AdamW over one flat fp32 buffer (train_hybrid.py:913,921; :504-509).  scratch: 1024+4 floats;
+ * scratch[1024..1026] = (grad norm, clip coef, finite flag) afterwards. */
+int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float max_norm, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, float* scratch, void* stream);
+
+/* ---- the VAE step executor (LunarisCoreVAE.forward / backward, lunar_generate.py:263-276) -------------------- */
+typedef struct LoVae LoVae;
+int lo_vae_create(int batch, int latent_dim, LoVae** out);
+void lo_vae_destroy(LoVae* h);
+/* parameters live in ONE flat fp32 buffer; tensor i (state_dict order, 72 tensors) starts at this element offset */
+int lo_vae_num_params(const LoVae* h);
+size_t lo_vae_param_offset(const LoVae* h, int index);
+size_t lo_vae_param_numel(const LoVae* h, int index);
+size_t lo_vae_flat_elems(const LoVae* h);
+size_t lo_vae_workspace_bytes(const LoVae* h);
+/* refresh the packed fp16 operand copies from the fp32 master parameters (call after every parameter update) */
+int lo_vae_pack(LoVae* h, const float* flat_params, void* ws, void* stream);
+/* forward.  eps: explicit N(0,1) noise [B,L] or NULL (on-device counter RNG with `seed`).  target: images for the fused
+ * MSE partial sums or NULL.  Outputs recon [B,3,128,128], mu, logvar [B,L] (fp32). */
+int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* flat_params, void* ws,
+                   float* recon, float* mu, float* logvar, const float* target, void* stream);
+/* reduce the loss partial sums of the last forward; losses_dev[4] = recon_loss, kl_loss, vae_loss, pg_loss.
+ * vae_loss = (recon_weight*recon + kl_weight*kl - mean_advantage*recon)/accum  (train_hybrid.py:886-889,895).
+ * adv_dev (device scalar) overrides mean_advantage when not NULL.  Also prepares the gradient seeds for
+ * lo_vae_backward(fused=1). */
+int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weight, float mean_advantage, const float* adv_dev,
+                float accum, float loss_scale, float* losses_dev, void* stream);
+/* backward into flat_grads (same layout as the parameters; every element is written).  fused=1: gradients of the
+ * vae_loss prepared by lo_vae_loss (needs `target`).  fused=0: explicit upstream gradients drecon/gmu/glv (fp32, may
+ * be NULL = zero). */
+int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws, const float* recon, const float* target,
+                    int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
+                    float* flat_grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

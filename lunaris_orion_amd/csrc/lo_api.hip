@@ -1,0 +1,484 @@
+// C ABI (include/lunaris_hip.h) + the native VAE step executor: one C call enqueues every kernel of
+// LunarisCoreVAE.forward (lunar_generate.py:263-276) or of its backward on the given HIP stream.
+#include "lo_internal.h"
+#include "../../include/lunaris_hip.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+#define LO_TRY(call)            \
+  do {                          \
+    int _r = (call);            \
+    if (_r != LO_OK) return _r; \
+  } while (0)
+
+extern "C" const char* lo_last_error(void) { return lo_get_error(); }
+extern "C" int lo_version(void) { return 1; }
+
+// =============================================================================================
+// single-op entry points
+// =============================================================================================
+extern "C" size_t lo_packed_weight_elems_for(int kind, int B, int H, int W, int Cin, int Cout) {
+  LoGeom g;
+  if (lo_make_geom(&g, kind, B, H, W, Cin, Cout) != LO_OK) return 0;
+  return lo_packed_weight_elems(g);
+}
+extern "C" int lo_pack_weight_for(int kind, int B, int H, int W, int Cin, int Cout, const float* w, void* wp, void* stream) {
+  LoGeom g;
+  LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
+  return lo_pack_weight(w, (f16*)wp, g, S(stream));
+}
+extern "C" int lo_conv_forward(int kind, int B, int H, int W, int Cin, int Cout, const void* in, const void* wp,
+                               const float* bias, const void* add_src, void* out, float* gn_partial, int* mt_out,
+                               void* stream) {
+  LoGeom g;
+  LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
+  if (mt_out) *mt_out = (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
+  return lo_conv_run(g, (const f16*)in, (const f16*)wp, bias, (const f16*)add_src, (f16*)out, gn_partial, nullptr, 1, S(stream));
+}
+extern "C" int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab,
+                                int nsplit, float* out32, void* out16, void* stream) {
+  LoGeom g;
+  LO_TRY(lo_make_geom(&g, LO_LINEAR, M, 1, 1, K, N));
+  LO_TRY(lo_conv_run(g, (const f16*)x, (const f16*)wp, nullptr, nullptr, nullptr, nullptr, slab, nsplit, S(stream)));
+  return lo_splitk_reduce(slab, bias, out32, (f16*)out16, M, N, nsplit, S(stream));
+}
+extern "C" size_t lo_wgrad_slab_bytes_for(int kind, int B, int H, int W, int Cin, int Cout) {
+  LoGeom g;
+  if (lo_make_geom(&g, kind, B, H, W, Cin, Cout) != LO_OK) return 0;
+  return lo_wgrad_slab_bytes(g);
+}
+extern "C" int lo_conv_wgrad(int kind, int B, int H, int W, int Cin, int Cout, const void* x, const void* dy, float* slab,
+                             float* grad, float scale, void* stream) {
+  LoGeom g;
+  LO_REQUIRE(kind == LO_CONV3_S1 || kind == LO_CONV3_S2 || kind == LO_CONVT4_S2 || kind == LO_LINEAR,
+             "lo_conv_wgrad: kind %d is not a forward op", kind);
+  LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
+  return lo_wgrad_run(g, (const f16*)x, (const f16*)dy, slab, grad, scale, S(stream));
+}
+extern "C" int lo_gn_mish_forward(const void* v, const float* gn_partial, int MT, const float* gamma, const float* beta,
+                                  const void* other, void* y, float* stats, int B, int HW, int C, int mode, void* stream) {
+  return lo_gn_fwd((const f16*)v, gn_partial, MT, gamma, beta, (const f16*)other, (f16*)y, stats, B, HW, C, mode, S(stream));
+}
+extern "C" int lo_gn_nchunk_for(int HW, int C) { return lo_gn_nchunk(HW, C); }
+extern "C" int lo_gn_mish_backward(const void* dy, const void* v, const void* other, const float* stats, const float* gamma,
+                                   const float* beta, void* ds, void* dv, float* P1, float* P2, float* dgamma, float* dbeta,
+                                   float* dbias, int B, int HW, int C, int mode, float scale, void* stream) {
+  return lo_gn_bwd((const f16*)dy, (const f16*)v, (const f16*)other, stats, gamma, beta, (f16*)ds, (f16*)dv, P1, P2, dgamma,
+                   dbeta, dbias, B, HW, C, mode, scale, S(stream));
+}
+extern "C" int lo_first_conv_forward(const float* x, const float* w, const float* bias, void* v, float* gn_partial, int B,
+                                     void* stream) {
+  return lo_first_conv_fwd(x, w, bias, (f16*)v, gn_partial, B, S(stream));
+}
+extern "C" int lo_first_conv_wgrad_op(const float* x, const void* dv, float* partial, float* dw, int B, float scale, void* stream) {
+  return lo_first_conv_wgrad(x, (const f16*)dv, partial, dw, B, scale, S(stream));
+}
+extern "C" int lo_final_conv_forward(const void* a4, const float* w, const float* bias, const float* target, float* recon,
+                                     float* mse_partial, int B, void* stream) {
+  return lo_final_conv_fwd((const f16*)a4, w, bias, target, recon, mse_partial, B, S(stream));
+}
+extern "C" int lo_final_conv_backward(const void* a4, const float* w, const float* recon, const float* target,
+                                      const float* drecon, const float* coef_dev, float gscale, void* da4, float* partial,
+                                      float* dw, float* db, int B, float scale, void* stream) {
+  return lo_final_conv_bwd((const f16*)a4, w, recon, target, drecon, coef_dev, gscale, (f16*)da4, partial, dw, db, B, scale,
+                           S(stream));
+}
+extern "C" int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float max_norm, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int step, float* scratch,
+                                  void* stream) {
+  LO_TRY(lo_gradnorm(g, n, max_norm, scratch, scratch + 1024, S(stream)));
+  return lo_adamw(p, g, m, v, n, scratch + 1024, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
+// =============================================================================================
+// VAE executor
+// =============================================================================================
+namespace {
+
+struct ConvLayer {           // conv + GroupNorm + Mish
+  int kind;                  // forward kind
+  int H, W, Cin, Cout;       // input spatial dims / channels
+  int Ho, Wo;                // output spatial dims
+  LoGeom gf, gd;             // forward / data-gradient geometry
+  int p_w, p_b, p_gw, p_gb;  // parameter indices (state_dict order)
+  size_t o_wp_f, o_wp_d;     // workspace offsets: packed fp16 weights (fwd, dgrad)
+  size_t o_v, o_a;           // raw conv output, activation after GN+Mish(+...)
+  size_t o_part, o_stats;    // GN partial sums, saved stats
+  int MT;
+};
+
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+}  // namespace
+
+struct LoVae {
+  int B, L;
+  // parameters
+  int nparam;
+  std::vector<size_t> p_off, p_numel;
+  size_t flat_elems;
+  // layers: encoder stage s: enc[s][0] = strided conv, enc[s][1] = res.conv1, enc[s][2] = res.conv2
+  ConvLayer enc[4][3];
+  ConvLayer dec[4];
+  size_t o_eout[4];          // ResBlock outputs (stage outputs)
+  // latent
+  LoGeom g_head, g_head_d, g_dfc, g_dfc_d;
+  int head_split, dfcd_split;
+  size_t o_wp_head, o_wp_head_t, o_wp_dfc, o_wp_dfc_t;
+  size_t o_xflat, o_slab_head, o_eps, o_z, o_klp, o_mu, o_lv, o_yfc, o_h0;
+  size_t o_msep, o_losses, o_coefs;
+  // backward scratch
+  size_t o_G[4], o_skipg[3], o_P1, o_P2, o_wslab, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
+  size_t ws_bytes;
+  int idx_fc_mu_w, idx_fc_mu_b, idx_fc_lv_w, idx_fc_lv_b, idx_dfc_w, idx_dfc_b, idx_final_w, idx_final_b;
+  bool forward_done, loss_done;
+};
+
+static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin, int Cout, int p_w, Arena& ar, bool first) {
+  c.kind = kind; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout;
+  c.p_w = p_w; c.p_b = p_w + 1; c.p_gw = p_w + 2; c.p_gb = p_w + 3;
+  if (!first) {
+    LO_TRY(lo_make_geom(&c.gf, kind, B, H, W, Cin, Cout));
+    int dk = kind == LO_CONV3_S1 ? LO_CONV3_S1_DGRAD : (kind == LO_CONV3_S2 ? LO_CONV3_S2_DGRAD : LO_CONVT4_S2_DGRAD);
+    c.Ho = c.gf.Hout; c.Wo = c.gf.Wout;
+    // the data-gradient op READS the forward output tensor [B,Ho,Wo,Cout] and WRITES Cin channels
+    LO_TRY(lo_make_geom(&c.gd, dk, B, c.Ho, c.Wo, Cout, Cin));
+    c.o_wp_f = ar.take(lo_packed_weight_elems(c.gf) * 2);
+    c.o_wp_d = ar.take(lo_packed_weight_elems(c.gd) * 2);
+    c.MT = (c.gf.GH * c.gf.GW / lo_conv_tile_m(c.gf)) * c.gf.n_phase;
+  } else {
+    c.Ho = H / 2; c.Wo = W / 2;
+    c.o_wp_f = c.o_wp_d = 0;
+    c.MT = 64;
+  }
+  size_t act = (size_t)B * c.Ho * c.Wo * Cout * 2;
+  c.o_v = ar.take(act);
+  c.o_a = ar.take(act);
+  c.o_part = ar.take((size_t)B * c.MT * 16 * 4);
+  c.o_stats = ar.take((size_t)B * 16 * 4);
+  return LO_OK;
+}
+
+extern "C" int lo_vae_create(int B, int L, LoVae** out) {
+  LO_REQUIRE(out, "lo_vae_create: null out");
+  LO_REQUIRE(B >= 1 && B <= 4096, "lo_vae_create: batch %d out of range", B);
+  LO_REQUIRE(L >= 64 && L % 64 == 0 && L <= 4096, "lo_vae_create: latent_dim %d must be a multiple of 64", L);
+  LoVae* h = new LoVae();
+  h->B = B; h->L = L;
+  h->forward_done = h->loss_done = false;
+  // ---- parameter table in state_dict order (lunar_generate.py:91-125, 162-192)
+  std::vector<size_t> numel;
+  const int ench[5] = {3, 64, 128, 256, 512};
+  for (int s = 0; s < 4; ++s) {
+    size_t ci = ench[s], co = ench[s + 1];
+    numel.push_back(co * ci * 9); numel.push_back(co); numel.push_back(co); numel.push_back(co);
+    for (int k = 0; k < 2; ++k) { numel.push_back(co * co * 9); numel.push_back(co); numel.push_back(co); numel.push_back(co); }
+  }
+  h->idx_fc_mu_w = (int)numel.size(); numel.push_back((size_t)L * 32768);
+  h->idx_fc_mu_b = (int)numel.size(); numel.push_back(L);
+  h->idx_fc_lv_w = (int)numel.size(); numel.push_back((size_t)L * 32768);
+  h->idx_fc_lv_b = (int)numel.size(); numel.push_back(L);
+  h->idx_dfc_w = (int)numel.size(); numel.push_back((size_t)32768 * L);
+  h->idx_dfc_b = (int)numel.size(); numel.push_back(32768);
+  const int dech[5] = {512, 256, 128, 64, 32};
+  int dec_first = (int)numel.size();
+  for (int s = 0; s < 4; ++s) {
+    size_t ci = dech[s], co = dech[s + 1];
+    numel.push_back(ci * co * 16); numel.push_back(co); numel.push_back(co); numel.push_back(co);
+  }
+  h->idx_final_w = (int)numel.size(); numel.push_back(3 * 32 * 9);
+  h->idx_final_b = (int)numel.size(); numel.push_back(3);
+  h->nparam = (int)numel.size();
+  h->p_numel = numel;
+  h->p_off.assign(h->nparam, 0);
+  // flat layout: state_dict order, except that fc_logvar.weight directly follows fc_mu.weight and the two head
+  // biases are adjacent, so the encoder head is ONE [2L, 32768] matrix; every tensor starts on a 64-element boundary.
+  {
+    size_t off = 0;
+    auto place = [&](int i) { h->p_off[i] = off; off += (numel[i] + 63) & ~(size_t)63; };
+    for (int i = 0; i < h->nparam; ++i) {
+      if (i == h->idx_fc_mu_b || i == h->idx_fc_lv_w || i == h->idx_fc_lv_b) continue;
+      place(i);
+      if (i == h->idx_fc_mu_w) { place(h->idx_fc_lv_w); place(h->idx_fc_mu_b); place(h->idx_fc_lv_b); }
+    }
+    h->flat_elems = off;
+  }
+  // ---- workspace plan
+  Arena ar;
+  int Hs = 128;
+  int pidx = 0;
+  for (int s = 0; s < 4; ++s) {
+    int ci = ench[s], co = ench[s + 1];
+    LO_TRY(setup_conv_layer(h->enc[s][0], LO_CONV3_S2, B, Hs, Hs, ci, co, pidx, ar, s == 0));
+    pidx += 4;
+    Hs /= 2;
+    LO_TRY(setup_conv_layer(h->enc[s][1], LO_CONV3_S1, B, Hs, Hs, co, co, pidx, ar, false));
+    pidx += 4;
+    LO_TRY(setup_conv_layer(h->enc[s][2], LO_CONV3_S1, B, Hs, Hs, co, co, pidx, ar, false));
+    pidx += 4;
+    h->o_eout[s] = ar.take((size_t)B * Hs * Hs * co * 2);
+  }
+  Hs = 8;
+  for (int s = 0; s < 4; ++s) {
+    LO_TRY(setup_conv_layer(h->dec[s], LO_CONVT4_S2, B, Hs, Hs, dech[s], dech[s + 1], dec_first + 4 * s, ar, false));
+    Hs *= 2;
+  }
+  // latent
+  LO_TRY(lo_make_geom(&h->g_head, LO_LINEAR, B, 1, 1, 32768, 2 * L));     // [mu|logvar] = xflat W^T
+  LO_TRY(lo_make_geom(&h->g_head_d, LO_LINEAR, B, 1, 1, 2 * L, 32768));   // dxflat = dml Wt^T  (Wt = W^T packed)
+  LO_TRY(lo_make_geom(&h->g_dfc, LO_LINEAR, B, 1, 1, L, 32768));          // y = z Wd^T
+  LO_TRY(lo_make_geom(&h->g_dfc_d, LO_LINEAR, B, 1, 1, 32768, L));        // dz = dy Wdt^T
+  h->head_split = 32;
+  h->dfcd_split = 32;
+  h->o_wp_head = ar.take((size_t)2 * L * 32768 * 2);
+  h->o_wp_head_t = ar.take((size_t)2 * L * 32768 * 2);
+  h->o_wp_dfc = ar.take((size_t)L * 32768 * 2);
+  h->o_wp_dfc_t = ar.take((size_t)L * 32768 * 2);
+  h->o_xflat = ar.take((size_t)B * 32768 * 2);
+  h->o_slab_head = ar.take((size_t)h->head_split * B * 2 * L * 4);
+  h->o_eps = ar.take((size_t)B * L * 4);
+  h->o_mu = ar.take((size_t)B * L * 4);
+  h->o_lv = ar.take((size_t)B * L * 4);
+  h->o_z = ar.take((size_t)B * L * 2);
+  h->o_klp = ar.take((size_t)((B * L + 255) / 256) * 4);
+  h->o_yfc = ar.take((size_t)B * 32768 * 2);
+  h->o_h0 = ar.take((size_t)B * 32768 * 2);
+  h->o_msep = ar.take((size_t)B * 64 * 4);
+  h->o_losses = ar.take(16 * 4);
+  h->o_coefs = ar.take(16 * 4);
+  // backward scratch
+  size_t max_act = (size_t)B * 128 * 128 * 32 * 2;
+  for (int i = 0; i < 4; ++i) h->o_G[i] = ar.take(max_act);
+  h->o_skipg[0] = ar.take((size_t)B * 64 * 64 * 64 * 2);    // grad wrt (up3.act + enc1.out)
+  h->o_skipg[1] = ar.take((size_t)B * 32 * 32 * 128 * 2);   // grad wrt (up2.act + enc2.out)
+  h->o_skipg[2] = ar.take((size_t)B * 16 * 16 * 256 * 2);   // grad wrt (up1.act + enc3.out)
+  h->o_P1 = ar.take((size_t)B * 64 * 512 * 2 * 4);
+  h->o_P2 = ar.take((size_t)B * 64 * 512 * 4);
+  size_t wslab = 0;
+  for (int s = 0; s < 4; ++s) {
+    for (int k = 0; k < 3; ++k) {
+      if (s == 0 && k == 0) continue;
+      size_t b = lo_wgrad_slab_bytes(h->enc[s][k].gf);
+      wslab = b > wslab ? b : wslab;
+    }
+    size_t b = lo_wgrad_slab_bytes(h->dec[s].gf);
+    wslab = b > wslab ? b : wslab;
+  }
+  {
+    size_t b = lo_wgrad_slab_bytes(h->g_head); wslab = b > wslab ? b : wslab;
+    b = lo_wgrad_slab_bytes(h->g_dfc); wslab = b > wslab ? b : wslab;
+  }
+  h->o_wslab = ar.take(wslab);
+  h->o_fcw_part = ar.take((size_t)B * 8 * 1728 * 4);
+  h->o_lc_part = ar.take((size_t)B * 64 * 867 * 4);
+  h->o_dz = ar.take((size_t)B * L * 2);
+  h->o_dml = ar.take((size_t)B * 2 * L * 2);
+  h->o_slab_dz = ar.take((size_t)h->dfcd_split * B * L * 4);
+  h->ws_bytes = ar.off;
+  *out = h;
+  return LO_OK;
+}
+
+extern "C" void lo_vae_destroy(LoVae* h) { delete h; }
+extern "C" int lo_vae_num_params(const LoVae* h) { return h->nparam; }
+extern "C" size_t lo_vae_param_offset(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_off[i] : (size_t)-1; }
+extern "C" size_t lo_vae_param_numel(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_numel[i] : 0; }
+extern "C" size_t lo_vae_flat_elems(const LoVae* h) { return h->flat_elems; }
+extern "C" size_t lo_vae_workspace_bytes(const LoVae* h) { return h->ws_bytes; }
+
+#define WSP(T, off) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (off))
+#define PRM(i) (P + h->p_off[(i)])
+#define GRD(i) (G + h->p_off[(i)])
+
+extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
+  LO_REQUIRE(h && P && ws, "lo_vae_pack: null argument");
+  hipStream_t st = S(stream);
+  for (int s = 0; s < 4; ++s)
+    for (int k = 0; k < 3; ++k) {
+      if (s == 0 && k == 0) continue;
+      ConvLayer& c = h->enc[s][k];
+      LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_f), c.gf, st));
+      LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_d), c.gd, st));
+    }
+  for (int s = 0; s < 4; ++s) {
+    ConvLayer& c = h->dec[s];
+    LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_f), c.gf, st));
+    LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_d), c.gd, st));
+  }
+  const int L = h->L;
+  // encoder head: [fc_mu.weight ; fc_logvar.weight] is one contiguous [2L][32768] fp32 matrix in the flat buffer
+  LO_REQUIRE(h->p_off[h->idx_fc_lv_w] == h->p_off[h->idx_fc_mu_w] + (size_t)L * 32768, "flat layout: head weights not adjacent");
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, st));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, st));
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, st));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, st));
+  return LO_OK;
+}
+
+static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16* y, int mode, const float* P, void* ws,
+                   hipStream_t st) {
+  LO_TRY(lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st));
+  return lo_gn_fwd(WSP(f16, c.o_v), WSP(float, c.o_part), c.MT, PRM(c.p_gw), PRM(c.p_gb), other, y, WSP(float, c.o_stats), h->B,
+                   c.Ho * c.Wo, c.Cout, mode, st);
+}
+
+extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* P, void* ws,
+                              float* recon, float* mu, float* logvar, const float* target, void* stream) {
+  LO_REQUIRE(h && x && P && ws && recon && mu && logvar, "lo_vae_forward: null argument");
+  hipStream_t st = S(stream);
+  const int B = h->B, L = h->L;
+  // ---- encoder (lunar_generate.py:127-153)
+  const f16* cur = nullptr;
+  for (int s = 0; s < 4; ++s) {
+    ConvLayer& c0 = h->enc[s][0];
+    ConvLayer& c1 = h->enc[s][1];
+    ConvLayer& c2 = h->enc[s][2];
+    if (s == 0) {
+      LO_TRY(lo_first_conv_fwd(x, PRM(c0.p_w), PRM(c0.p_b), WSP(f16, c0.o_v), WSP(float, c0.o_part), B, st));
+      LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
+                       WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st));
+    } else {
+      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st));
+    }
+    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st));
+    // ResBlock tail: out = mish(mish(GN(conv2)) + identity); c2.o_a is unused, the result is the stage output
+    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st));
+    cur = WSP(f16, h->o_eout[s]);
+  }
+  // ---- heads + reparameterisation (lunar_generate.py:150-152, 259-261)
+  LO_TRY(lo_nhwc_to_nchw_f16(cur, WSP(f16, h->o_xflat), B, 64, 512, st));
+  LO_TRY(lo_conv_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_wp_head), nullptr, nullptr, nullptr, nullptr,
+                     WSP(float, h->o_slab_head), h->head_split, st));
+  LO_REQUIRE(h->p_off[h->idx_fc_lv_b] == h->p_off[h->idx_fc_mu_b] + (size_t)L, "flat layout: head biases not adjacent");
+  LO_TRY(lo_head_reduce(WSP(float, h->o_slab_head), PRM(h->idx_fc_mu_b), eps, seed, WSP(float, h->o_mu), WSP(float, h->o_lv),
+                        WSP(f16, h->o_z), WSP(float, h->o_eps), WSP(float, h->o_klp), B, L, h->head_split, st));
+  LO_HIP(hipMemcpyAsync(mu, WSP(float, h->o_mu), (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
+  LO_HIP(hipMemcpyAsync(logvar, WSP(float, h->o_lv), (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
+  // ---- decoder (lunar_generate.py:194-229)
+  LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
+                     nullptr, 1, st));
+  LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st));
+  cur = WSP(f16, h->o_h0);
+  for (int s = 0; s < 4; ++s) {
+    ConvLayer& c = h->dec[s];
+    const f16* skip = s < 3 ? WSP(f16, h->o_eout[2 - s]) : nullptr;
+    LO_TRY(conv_gn(h, c, cur, skip, WSP(f16, c.o_a), s < 3 ? 1 : 0, P, ws, st));
+    cur = WSP(f16, c.o_a);
+  }
+  LO_TRY(lo_final_conv_fwd(cur, PRM(h->idx_final_w), PRM(h->idx_final_b), target, recon, target ? WSP(float, h->o_msep) : nullptr,
+                           B, st));
+  h->forward_done = true;
+  h->loss_done = false;
+  return LO_OK;
+}
+
+extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weight, float mean_advantage, const float* adv_dev,
+                           float accum, float loss_scale, float* losses_dev, void* stream) {
+  LO_REQUIRE(h && ws && losses_dev, "lo_vae_loss: null argument");
+  if (!h->forward_done) { lo_set_error("lo_vae_loss: no forward with a target has run"); return LO_ERR_STATE; }
+  hipStream_t st = S(stream);
+  const int B = h->B, L = h->L;
+  LO_TRY(lo_loss_finalize(WSP(float, h->o_msep), B * 64, WSP(float, h->o_klp), (B * L + 255) / 256, recon_weight, kl_weight,
+                          mean_advantage, adv_dev, accum, loss_scale, WSP(float, h->o_losses), WSP(float, h->o_coefs),
+                          (float)B * 3.f * 128.f * 128.f, (float)B * (float)L, st));
+  LO_HIP(hipMemcpyAsync(losses_dev, WSP(float, h->o_losses), 16, hipMemcpyDeviceToDevice, st));
+  h->loss_done = true;
+  return LO_OK;
+}
+
+// backward of one conv+GN+Mish layer.  dy: gradient wrt the layer's activation output (after mish, before any skip add).
+// Produces the parameter gradients and, when din != null, the gradient wrt the layer input (+ add_src).
+static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, int mode, const f16* layer_in, f16* ds,
+                       f16* dv, f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale,
+                       hipStream_t st) {
+  LO_TRY(lo_gn_bwd(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv, WSP(float, h->o_P1),
+                   WSP(float, h->o_P2), GRD(c.p_gw), GRD(c.p_gb), GRD(c.p_b), h->B, c.Ho * c.Wo, c.Cout, mode, inv_scale, st));
+  LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st));
+  if (din) LO_TRY(lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st));
+  return LO_OK;
+}
+
+extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* ws, const float* recon, const float* target,
+                               int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
+                               float* G, void* stream) {
+  LO_REQUIRE(h && x && P && ws && recon && G, "lo_vae_backward: null argument");
+  if (!h->forward_done) { lo_set_error("lo_vae_backward: forward has not run"); return LO_ERR_STATE; }
+  if (fused && (!h->loss_done || !target)) { lo_set_error("lo_vae_backward: fused mode needs lo_vae_loss and a target"); return LO_ERR_STATE; }
+  LO_REQUIRE(loss_scale > 0.f, "lo_vae_backward: loss_scale must be positive");
+  hipStream_t st = S(stream);
+  const int B = h->B, L = h->L;
+  const float inv = 1.0f / loss_scale;
+  f16* Ga = WSP(f16, h->o_G[0]);
+  f16* Gb = WSP(f16, h->o_G[1]);
+  f16* Gc = WSP(f16, h->o_G[2]);
+  f16* Gd = WSP(f16, h->o_G[3]);
+  // padding elements of the flat gradient buffer stay zero
+  LO_HIP(hipMemsetAsync(G, 0, h->flat_elems * sizeof(float), st));
+  // ---- final conv (+tanh, + fused MSE gradient)
+  {
+    ConvLayer& u4 = h->dec[3];
+    if (fused || drecon) {
+      LO_TRY(lo_final_conv_bwd(WSP(f16, u4.o_a), PRM(h->idx_final_w), recon, fused ? target : nullptr, fused ? nullptr : drecon,
+                               fused ? WSP(float, h->o_coefs) : nullptr, loss_scale, Ga, WSP(float, h->o_lc_part),
+                               GRD(h->idx_final_w), GRD(h->idx_final_b), B, inv, st));
+    } else {
+      LO_HIP(hipMemsetAsync(Ga, 0, (size_t)B * 128 * 128 * 32 * 2, st));
+    }
+  }
+  // ---- decoder: up4..up1.  Ga holds the gradient wrt the stage's (activation [+ skip]) output.
+  const f16* gout = Ga;
+  for (int s = 3; s >= 0; --s) {
+    ConvLayer& c = h->dec[s];
+    const f16* layer_in = s > 0 ? WSP(f16, h->dec[s - 1].o_a) : WSP(f16, h->o_h0);
+    f16* din = s > 0 ? WSP(f16, h->o_skipg[3 - s]) : Ga;   // up4->skipg[0] (wrt up3 out), up3->skipg[1], up2->skipg[2], up1->Ga
+    // mode 1 (skip add) has the same du as mode 0; the skip branch receives gout unchanged (kept in skipg)
+    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, Gb, din, nullptr, P, G, ws, inv, st));
+    gout = din;
+  }
+  // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
+  // ---- decoder.fc
+  LO_TRY(lo_nhwc_to_nchw_f16(Ga, Gb, B, 64, 512, st));                       // Gb = dy of decoder.fc, [B][32768] c-major
+  LO_TRY(lo_colsum_f16(Gb, GRD(h->idx_dfc_b), B, 32768, inv, st));
+  LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gb, WSP(float, h->o_wslab), GRD(h->idx_dfc_w), inv, st));
+  LO_TRY(lo_conv_run(h->g_dfc_d, Gb, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
+                     h->dfcd_split, st));
+  LO_TRY(lo_splitk_reduce(WSP(float, h->o_slab_dz), nullptr, nullptr, WSP(f16, h->o_dz), B, L, h->dfcd_split, st));
+  // ---- latent: KL + reparameterisation backward (train_hybrid.py:862; lunar_generate.py:259-261)
+  LO_TRY(lo_latent_bwd(WSP(f16, h->o_dz), WSP(float, h->o_mu), WSP(float, h->o_lv), WSP(float, h->o_eps),
+                       fused ? WSP(float, h->o_coefs) : nullptr, fused ? nullptr : gmu, fused ? nullptr : glv, loss_scale,
+                       WSP(f16, h->o_dml), B, L, st));
+  // ---- encoder heads
+  LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, st));
+  LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab), GRD(h->idx_fc_mu_w), inv, st));
+  LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
+  LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
+  // ---- encoder stages 4..1
+  for (int s = 3; s >= 0; --s) {
+    ConvLayer& c0 = h->enc[s][0];
+    ConvLayer& c1 = h->enc[s][1];
+    ConvLayer& c2 = h->enc[s][2];
+    // ResBlock tail + conv2:  dy = Ga -> ds = Gb (identity branch), dv2 = Gc ; dgrad -> Gd (grad wrt conv1 activation)
+    LO_TRY(conv_gn_bwd(h, c2, Ga, WSP(f16, c0.o_a), 2, WSP(f16, c1.o_a), Gb, Gc, Gd, nullptr, P, G, ws, inv, st));
+    // conv1: dy = Gd -> dv1 = Gc ; dgrad (+ ds) -> Gd (grad wrt the block input = c0 activation)
+    LO_TRY(conv_gn_bwd(h, c1, Gd, nullptr, 0, WSP(f16, c0.o_a), nullptr, Gc, Gd, Gb, P, G, ws, inv, st));
+    if (s > 0) {
+      // strided conv: dy = Gd -> dv0 = Gc ; dgrad (+ decoder skip gradient) -> Ga (grad wrt the previous stage output)
+      LO_TRY(conv_gn_bwd(h, c0, Gd, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Gc, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
+                         ws, inv, st));
+    } else {
+      LO_TRY(lo_gn_bwd(Gd, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gc,
+                       WSP(float, h->o_P1), WSP(float, h->o_P2), GRD(c0.p_gw), GRD(c0.p_gb), GRD(c0.p_b), B, 64 * 64, 64, 0, inv, st));
+      LO_TRY(lo_first_conv_wgrad(x, Gc, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
+    }
+  }
+  return LO_OK;
+}

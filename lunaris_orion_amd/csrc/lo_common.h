@@ -1,0 +1,102 @@
+// Common definitions for the lunaris-orion MI355X (gfx950 / CDNA4) kernels.
+// Internal header: the public C ABI is include/lunaris_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));  // type of the tr16 builtin
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LO_WAVE 64
+
+// error classes returned across the C ABI
+#define LO_OK 0
+#define LO_ERR_ARG (-1)      // bad argument / unsupported shape
+#define LO_ERR_HIP (-2)      // a HIP runtime call failed
+#define LO_ERR_STATE (-3)    // object used in the wrong state
+
+void lo_set_error(const char* fmt, ...);
+int lo_check_hip(hipError_t e, const char* what);
+
+#define LO_HIP(call)                                   \
+  do {                                                 \
+    int _e = lo_check_hip((call), #call);              \
+    if (_e != LO_OK) return _e;                        \
+  } while (0)
+#define LO_LAUNCH_CHECK(name) LO_HIP(hipGetLastError())
+#define LO_REQUIRE(cond, ...)                          \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      lo_set_error(__VA_ARGS__);                       \
+      return LO_ERR_ARG;                               \
+    }                                                  \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of one implicit-GEMM convolution-like op (forward conv, transposed conv as sub-pixel
+// phases, and every data-gradient of those).  All tensors are NHWC fp16.
+//
+//   for phase p, output-grid point (n, gy, gx), output channel co:
+//     out[n, gy*out_stride + out_oy[p], gx*out_stride + out_ox[p], co] =
+//        bias[co] + sum_{t < T[p]} sum_{ci} in[n, gy*in_stride + dy[p][t], gx*in_stride + dx[p][t], ci]
+//                                         * Wp[p][co][t*Cin + ci]
+//   (input positions outside [0,Hin)x[0,Win) read as zero).
+// ---------------------------------------------------------------------------------------------
+#define LO_MAX_TAPS 16
+#define LO_MAX_PHASE 4
+struct LoGeom {
+  int B, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int GH, GW;          // output grid per phase
+  int in_stride, out_stride;
+  int n_phase;
+  int T[LO_MAX_PHASE];
+  int out_oy[LO_MAX_PHASE], out_ox[LO_MAX_PHASE];
+  int wofs[LO_MAX_PHASE];                 // element offset of phase p inside the packed weight
+  int8_t dy[LO_MAX_PHASE][LO_MAX_TAPS];
+  int8_t dx[LO_MAX_PHASE][LO_MAX_TAPS];
+  int8_t rs[LO_MAX_PHASE][LO_MAX_TAPS];   // r*S+s of the canonical weight this tap reads
+  // canonical weight addressing: W[n*sn + c*sc + rs]  (n = this op's output channel, c = reduced channel)
+  int sn, sc;
+};
+
+enum LoConvKind {
+  LO_CONV3_S1 = 0,        // Conv2d k3 s1 p1 forward
+  LO_CONV3_S2 = 1,        // Conv2d k3 s2 p1 forward
+  LO_CONVT4_S2 = 2,       // ConvTranspose2d k4 s2 p1 forward (4 sub-pixel phases)
+  LO_CONV3_S1_DGRAD = 3,  // data gradient of k3 s1 p1
+  LO_CONV3_S2_DGRAD = 4,  // data gradient of k3 s2 p1 (4 phases: 1,2,2,4 taps)
+  LO_CONVT4_S2_DGRAD = 5, // data gradient of ConvTranspose k4 s2 p1 (= conv k4 s2 p1)
+  LO_LINEAR = 6           // 1x1 "conv" on a [M,1,1,K] tensor: y = x W^T
+};
+
+// Build the geometry.  (H, W, Cin) describe the tensor this op READS, Cout the channels it WRITES.
+int lo_make_geom(LoGeom* g, int kind, int B, int H, int W, int Cin, int Cout);
+
+__device__ __forceinline__ float lo_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// mish(u) = u * tanh(softplus(u)) = u * t/(t+2), t = w(w+2), w = e^u   (lunar_generate.py:24-26; nn.Mish)
+__device__ __forceinline__ float lo_mish(float u) {
+  float w = __expf(fminf(u, 20.0f));
+  float t = w * (w + 2.0f);
+  return u * (t / (t + 2.0f));
+}
+// d mish / du = tau + u * (1 - tau^2) * sigmoid(u),  tau = tanh(softplus(u))
+__device__ __forceinline__ float lo_mish_grad(float u) {
+  float w = __expf(fminf(u, 20.0f));
+  float t = w * (w + 2.0f);
+  float tau = t / (t + 2.0f);
+  float sig = w / (1.0f + w);
+  return tau + u * (1.0f - tau * tau) * sig;
+}

@@ -1,0 +1,51 @@
+// Internal launcher prototypes shared by the kernel translation units and the C-ABI layer.
+#pragma once
+#include "lo_common.h"
+
+const char* lo_get_error();
+
+// lo_conv.hip
+int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
+int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
+                float* gn_partial, float* slab, int nsplit, hipStream_t st);
+int lo_conv_tile_m(const LoGeom& g);
+int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);
+int lo_wgrad_nsplit(const LoGeom& g);
+int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st);
+size_t lo_wgrad_slab_bytes(const LoGeom& g);
+size_t lo_packed_weight_elems(const LoGeom& g);
+
+// lo_norm.hip
+int lo_gn_nchunk(int HW, int C);
+int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, const float* beta, const f16* other, f16* y,
+              float* stats, int B, int HW, int C, int mode, hipStream_t st);
+int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
+              f16* ds, f16* dv, float* P1, float* P2, float* dgamma, float* dbeta, float* dbias, int B, int HW, int C,
+              int mode, float scale, hipStream_t st);
+int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
+int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
+
+// lo_edge.hip
+int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v, float* gn_partial, int B, hipStream_t st);
+int lo_first_conv_wgrad(const float* x, const f16* dv, float* partial, float* dw, int B, float scale, hipStream_t st);
+int lo_colsum(const float* partial, float* out, int nrow, int ncol, int stride, float scale, hipStream_t st);
+int lo_final_conv_fwd(const f16* a4, const float* w, const float* bias, const float* target, float* recon,
+                      float* mse_partial, int B, hipStream_t st);
+int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const float* target, const float* drecon,
+                      const float* coef, float gscale, f16* da4, float* partial, float* dw, float* db, int B, float scale,
+                      hipStream_t st);
+
+// lo_train.hip
+int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, uint64_t seed, float* mu, float* logvar,
+                   f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st);
+int lo_loss_finalize(const float* mse_partial, int n_mse, const float* kl_partial, int n_kl, float rw, float kw, float adv,
+                     const float* adv_dev, float accum, float ls, float* losses, float* coefs, float n_rec, float n_lat,
+                     hipStream_t st);
+int lo_latent_bwd(const f16* dz, const float* mu, const float* logvar, const float* eps, const float* coefs,
+                  const float* gmu, const float* glv, float gscale, f16* dml, int B, int L, hipStream_t st);
+int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream_t st);
+int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st);
+int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st);
+int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st);
+int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
+             float eps, float wd, int step, hipStream_t st);

@@ -1,0 +1,338 @@
+// GroupNorm(8) + Mish kernels (forward apply, backward reduce / apply, parameter-gradient finalize) on NHWC fp16
+// activations with fp32 statistics.  HBM-bound streaming kernels: 16-byte vector loads/stores, one thread owns a
+// fixed 8-channel chunk and strides over pixel rows; all cross-thread reductions are in a fixed order
+// (bitwise run-to-run reproducible, no float atomics).
+//
+// Reference ops replaced: nn.GroupNorm(8, C) + nn.Mish (lunar_generate.py:37-38,42-43,96-97,103-104,110-111,
+// 117-118,170-171,176-177,182-183,188-189), the ResBlock tail mish(out + identity) (:49-53) and the decoder
+// skip additions (:212-222).
+#include "lo_common.h"
+
+#define GN_EPS 1e-5f
+
+enum { GN_MODE_PLAIN = 0, GN_MODE_SKIP = 1, GN_MODE_RES = 2 };
+
+int lo_gn_nchunk(int HW, int C) {
+  long e = (long)HW * C / 16384;
+  if (e < 1) e = 1;
+  if (e > 64) e = 64;
+  while (HW % e) --e;
+  return (int)e;
+}
+
+struct GnFwdArgs {
+  const f16* v;          // conv output (raw), [B][HW][C]
+  const float* partial;  // [B][MT][8][2] (sum, sumsq) from the conv epilogue
+  const float* gamma;
+  const float* beta;
+  const f16* other;      // skip (mode 1) or identity (mode 2)
+  f16* y;
+  float* stats;          // [B][8][2] mean, rstd (saved for backward)
+  int HW, C, MT, nchunk, mode;
+};
+
+__device__ __forceinline__ void gn_group_stats(const float* partial, int MT, int n, float inv_m, float* s_stat, int tid) {
+  // 64 threads: group = tid>>3, part = tid&7 ; double accumulation, fixed order
+  if (tid < 64) {
+    int grp = tid >> 3, part = tid & 7;
+    double s = 0.0, q = 0.0;
+    for (int mt = part; mt < MT; mt += 8) {
+      const float* p = partial + (((size_t)n * MT + mt) * 8 + grp) * 2;
+      s += (double)p[0];
+      q += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (part == 0) {
+      double mean = s * inv_m;
+      double var = q * inv_m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stat[grp * 2 + 0] = (float)mean;
+      s_stat[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)GN_EPS));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
+  __shared__ float s_stat[16];
+  const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
+  const int C = a.C, G = C >> 3, CC = C >> 3;   // CC = 16-byte chunks per pixel row (8 channels each)
+  if (a.partial) {
+    gn_group_stats(a.partial, a.MT, n, 1.0f / ((float)a.HW * (float)G), s_stat, tid);
+    __syncthreads();
+    if (chunk == 0 && tid < 16 && a.stats) a.stats[n * 16 + tid] = s_stat[tid];
+  } else {
+    if (tid < 16) s_stat[tid] = a.stats[n * 16 + tid];
+    __syncthreads();
+  }
+  const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
+  const int c0 = cc * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int grp = (c0 + j) / G;
+    float mean = s_stat[grp * 2], rstd = s_stat[grp * 2 + 1];
+    float gm = a.gamma[c0 + j];
+    sc[j] = gm * rstd;
+    sh[j] = a.beta[c0 + j] - mean * sc[j];
+  }
+  const int rows = a.HW / a.nchunk;
+  const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
+  for (int r = slot; r < rows; r += nslot) {
+    size_t off = base + (size_t)r * C;
+    f16x8 h = *reinterpret_cast<const f16x8*>(a.v + off);
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.mode != GN_MODE_PLAIN) o = *reinterpret_cast<const f16x8*>(a.other + off);
+    f16x8 y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float u = (float)h[j] * sc[j] + sh[j];
+      float m = lo_mish(u);
+      if (a.mode == GN_MODE_SKIP) m += (float)o[j];
+      else if (a.mode == GN_MODE_RES) m = lo_mish(m + (float)o[j]);
+      y[j] = (f16)m;
+    }
+    *reinterpret_cast<f16x8*>(a.y + off) = y;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+//   y = f(u), u = xhat*gamma + beta, xhat = (v - mean)*rstd
+//   mode PLAIN/SKIP : du = dy * mish'(u)            (the skip branch receives dy unchanged)
+//   mode RES        : s = mish(u) + id ; ds = dy * mish'(s) (written out: gradient of the identity path);
+//                     du = ds * mish'(u)
+//   P1[n][chunk][c] = (sum du, sum du*xhat)
+// ---------------------------------------------------------------------------------------------
+struct GnBwdArgs {
+  const f16* dy;
+  const f16* v;
+  const f16* other;     // identity (mode RES)
+  const float* stats;   // [B][8][2]
+  const float* gamma;
+  const float* beta;
+  f16* ds;              // mode RES: gradient wrt (mish(u) + id), fp16
+  f16* dv;              // apply: gradient wrt conv output
+  float* P1;            // [B][nchunk][C][2]
+  float* P2;            // [B][nchunk][C]   (sum dv, for the conv bias gradient)
+  int HW, C, nchunk, mode;
+};
+
+__device__ __forceinline__ void gn_du(const GnBwdArgs& a, float hv, float dyv, float ov, float sc, float sh,
+                                      float mean, float rstd, float& du, float& xhat, float& dsv) {
+  xhat = (hv - mean) * rstd;
+  float u = hv * sc + sh;
+  if (a.mode == GN_MODE_RES) {
+    float s = lo_mish(u) + ov;
+    dsv = dyv * lo_mish_grad(s);
+    du = dsv * lo_mish_grad(u);
+  } else {
+    dsv = dyv;
+    du = dyv * lo_mish_grad(u);
+  }
+}
+
+__global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
+  __shared__ float s_red[256 * 16];
+  const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
+  const int C = a.C, G = C >> 3, CC = C >> 3;
+  const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
+  const int c0 = cc * 8;
+  float sc[8], sh[8], mean[8], rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int grp = (c0 + j) / G;
+    mean[j] = a.stats[n * 16 + grp * 2];
+    rstd[j] = a.stats[n * 16 + grp * 2 + 1];
+    sc[j] = a.gamma[c0 + j] * rstd[j];
+    sh[j] = a.beta[c0 + j] - mean[j] * sc[j];
+  }
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  const int rows = a.HW / a.nchunk;
+  const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
+  for (int r = slot; r < rows; r += nslot) {
+    size_t off = base + (size_t)r * C;
+    f16x8 h = *reinterpret_cast<const f16x8*>(a.v + off);
+    f16x8 d = *reinterpret_cast<const f16x8*>(a.dy + off);
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.mode == GN_MODE_RES) o = *reinterpret_cast<const f16x8*>(a.other + off);
+    f16x8 dso;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float du, xh, dsv;
+      gn_du(a, (float)h[j], (float)d[j], (float)o[j], sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
+      a1[j] += du;
+      a2[j] += du * xh;
+      dso[j] = (f16)dsv;
+    }
+    if (a.mode == GN_MODE_RES) *reinterpret_cast<f16x8*>(a.ds + off) = dso;
+  }
+  // reduce over the row slots in a fixed order
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s_red[tid * 16 + j * 2] = a1[j]; s_red[tid * 16 + j * 2 + 1] = a2[j]; }
+  __syncthreads();
+  // C*2 outputs; thread t handles output (c = t>>1 ... ) looping
+  for (int o = tid; o < C * 2; o += 256) {
+    int c = o >> 1, w = o & 1;
+    int ccx = c >> 3, j = c & 7;
+    float tot = 0.f;
+    for (int s = 0; s < nslot; ++s) tot += s_red[(s * CC + ccx) * 16 + j * 2 + w];
+    a.P1[(((size_t)n * a.nchunk + chunk) * C + c) * 2 + w] = tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
+  __shared__ float s_red[256 * 8];
+  __shared__ float s_c[16];       // per group: c1, c2
+  __shared__ float s_g[512 * 2];  // per channel gamma-weighted sums (scratch)
+  const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
+  const int C = a.C, G = C >> 3, CC = C >> 3;
+  // per-channel totals over chunks, then gamma-weighted group sums
+  for (int c = tid; c < C; c += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < a.nchunk; ++k) {
+      const float* p = a.P1 + (((size_t)n * a.nchunk + k) * C + c) * 2;
+      t1 += p[0];
+      t2 += p[1];
+    }
+    float gm = a.gamma[c];
+    s_g[c * 2] = gm * t1;
+    s_g[c * 2 + 1] = gm * t2;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    int grp = tid >> 1, w = tid & 1;
+    float tot = 0.f;
+    for (int c = grp * G; c < (grp + 1) * G; ++c) tot += s_g[c * 2 + w];
+    s_c[tid] = tot / ((float)a.HW * (float)G);
+  }
+  __syncthreads();
+  const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
+  const int c0 = cc * 8;
+  float sc[8], sh[8], mean[8], rstd[8], gm[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int grp = (c0 + j) / G;
+    mean[j] = a.stats[n * 16 + grp * 2];
+    rstd[j] = a.stats[n * 16 + grp * 2 + 1];
+    gm[j] = a.gamma[c0 + j];
+    sc[j] = gm[j] * rstd[j];
+    sh[j] = a.beta[c0 + j] - mean[j] * sc[j];
+    k1[j] = s_c[grp * 2];
+    k2[j] = s_c[grp * 2 + 1];
+  }
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int rows = a.HW / a.nchunk;
+  const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
+  for (int r = slot; r < rows; r += nslot) {
+    size_t off = base + (size_t)r * C;
+    f16x8 h = *reinterpret_cast<const f16x8*>(a.v + off);
+    f16x8 d = *reinterpret_cast<const f16x8*>(a.dy + off);
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.mode == GN_MODE_RES) o = *reinterpret_cast<const f16x8*>(a.other + off);
+    f16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float du, xh, dsv;
+      gn_du(a, (float)h[j], (float)d[j], (float)o[j], sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
+      float dv = rstd[j] * (gm[j] * du - k1[j] - xh * k2[j]);
+      f16 dvh = (f16)dv;
+      out[j] = dvh;
+      acc[j] += (float)dvh;   // bias gradient = sum of the values the weight-gradient GEMM will also see
+    }
+    *reinterpret_cast<f16x8*>(a.dv + off) = out;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    int ccx = c >> 3, j = c & 7;
+    float tot = 0.f;
+    for (int s = 0; s < nslot; ++s) tot += s_red[(s * CC + ccx) * 8 + j];
+    a.P2[((size_t)n * a.nchunk + chunk) * C + c] = tot;
+  }
+}
+
+// dgamma, dbeta, dbias from the partials (fixed summation order)
+__global__ void lo_gn_param_finalize_kernel(const float* __restrict__ P1, const float* __restrict__ P2, float* dgamma,
+                                            float* dbeta, float* dbias, int nblk, int C, float scale) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float g1 = 0.f, g2 = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    g1 += P1[((size_t)k * C + c) * 2];
+    g2 += P1[((size_t)k * C + c) * 2 + 1];
+    b += P2[(size_t)k * C + c];
+  }
+  dbeta[c] = g1 * scale;
+  dgamma[c] = g2 * scale;
+  dbias[c] = b * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small layout helpers
+// ---------------------------------------------------------------------------------------------
+// [B][HW][C] (NHWC) <-> [B][C][HW] (the order nn.Flatten sees, lunar_generate.py:150 / .view at :208)
+__global__ void lo_nhwc_to_nchw_f16_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int HW, int C, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int hw = i % HW;
+  int c = (i / HW) % C;
+  int n = i / (HW * C);
+  dst[i] = src[((size_t)n * HW + hw) * C + c];
+}
+__global__ void lo_nchw_to_nhwc_f16_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int HW, int C, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  int hw = (i / C) % HW;
+  int n = i / (HW * C);
+  dst[i] = src[((size_t)n * C + c) * HW + hw];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, const float* beta, const f16* other,
+              f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st) {
+  LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_fwd: C=%d unsupported", C);
+  GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode};
+  hipLaunchKernelGGL(lo_gn_fwd_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("gn_fwd");
+  return LO_OK;
+}
+
+int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
+              f16* ds, f16* dv, float* P1, float* P2, float* dgamma, float* dbeta, float* dbias, int B, int HW, int C,
+              int mode, float scale, hipStream_t st) {
+  LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_bwd: C=%d unsupported", C);
+  GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, lo_gn_nchunk(HW, C), mode};
+  hipLaunchKernelGGL(lo_gn_bwd_reduce_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("gn_bwd_reduce");
+  hipLaunchKernelGGL(lo_gn_bwd_apply_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("gn_bwd_apply");
+  hipLaunchKernelGGL(lo_gn_param_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, P1, P2, dgamma, dbeta, dbias,
+                     B * a.nchunk, C, scale);
+  LO_LAUNCH_CHECK("gn_param_finalize");
+  return LO_OK;
+}
+
+int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
+  int total = B * HW * C;
+  hipLaunchKernelGGL(lo_nhwc_to_nchw_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, HW, C, total);
+  LO_LAUNCH_CHECK("nhwc_to_nchw");
+  return LO_OK;
+}
+int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
+  int total = B * HW * C;
+  hipLaunchKernelGGL(lo_nchw_to_nhwc_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, HW, C, total);
+  LO_LAUNCH_CHECK("nchw_to_nhwc");
+  return LO_OK;
+}

@@ -1,0 +1,302 @@
+// Latent / loss / optimizer kernels of the VAE training step (all HBM-bound, fp32 math, deterministic reductions):
+//   encoder-head split-K reduction fused with the reparameterisation and the KL partial sums
+//        (lunar_generate.py:124-125,150-152,259-261; train_hybrid.py:862)
+//   loss finalisation + gradient seeds (train_hybrid.py:859,862,886-889,895)
+//   KL / reparameterisation backward
+//   global gradient norm + clip coefficient (train_hybrid.py:913) and fused clip + AdamW (train_hybrid.py:504-509,921)
+//   weight cast / transpose-cast helpers for the Linear layers
+#include "lo_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// counter-based N(0,1) generator for throughput runs (parity runs pass eps explicitly)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t lo_mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float lo_randn(uint64_t seed, uint64_t idx) {
+  uint64_t h = lo_mix64(seed ^ lo_mix64(idx));
+  float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);          // (0,1)
+  float u2 = ((float)(uint32_t)((h >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f);    // [0,1)
+  return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// head reduce: slab [nsplit][B][2L] -> mu, logvar (fp32 [B][L]), z = mu + eps*exp(0.5 logvar) (fp16 [B][L]),
+// eps_out (fp32, the noise actually used), kl_partial[block] = sum (1 + lv - mu^2 - e^lv)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_head_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                             const float* __restrict__ eps_in, uint64_t seed,
+                                                             float* __restrict__ mu, float* __restrict__ logvar,
+                                                             f16* __restrict__ z, float* __restrict__ eps_out,
+                                                             float* __restrict__ kl_partial, int B, int L, int nsplit) {
+  __shared__ float red[4];
+  int i = blockIdx.x * 256 + threadIdx.x;
+  float term = 0.f;
+  if (i < B * L) {
+    int b = i / L, l = i - b * L;
+    float m = bias[l], lv = bias[L + l];
+    for (int s = 0; s < nsplit; ++s) {
+      const float* p = slab + ((size_t)s * B + b) * (2 * L);
+      m += p[l];
+      lv += p[L + l];
+    }
+    float e = eps_in ? eps_in[i] : lo_randn(seed, (uint64_t)i);
+    float sd = expf(0.5f * lv);
+    mu[i] = m;
+    logvar[i] = lv;
+    eps_out[i] = e;
+    z[i] = (f16)(m + e * sd);
+    term = 1.f + lv - m * m - expf(lv);
+  }
+  float w = lo_wave_sum(term);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) kl_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss finalize (one workgroup).  rw/kw: recon/kl weights, adv: mean advantage, ls: loss scale
+// out: losses[0..3] = recon_loss, kl_loss, vae_loss, pg_loss ;  coefs[0] = d(scaled loss)/d recon multiplier on
+// (recon - x) ; coefs[1] = kl gradient coefficient (loss_scale * kl_weight / accum / (B*L))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_loss_finalize_kernel(const float* __restrict__ mse_partial, int n_mse,
+                                                               const float* __restrict__ kl_partial, int n_kl,
+                                                               float rw, float kw, float adv_host, float accum, float ls,
+                                                               const float* __restrict__ adv_dev, float* __restrict__ losses,
+                                                               float* __restrict__ coefs, float n_rec, float n_lat) {
+  __shared__ double red[2][256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n_mse; i += 256) a += (double)mse_partial[i];
+  for (int i = threadIdx.x; i < n_kl; i += 256) b += (double)kl_partial[i];
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < 256; ++i) { sa += red[0][i]; sb += red[1][i]; }
+    float recon_loss = (float)(sa / (double)n_rec);
+    float kl_loss = (float)(-0.5 * sb / (double)n_lat);
+    float adv = adv_dev ? adv_dev[0] : adv_host;
+    float pg = -adv * recon_loss;
+    losses[0] = recon_loss;
+    losses[1] = kl_loss;
+    losses[2] = (rw * recon_loss + kw * kl_loss + pg) / accum;
+    losses[3] = pg;
+    coefs[0] = ls * (rw - adv) / accum * 2.0f / n_rec;
+    coefs[1] = ls * kw / accum / n_lat;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// latent backward.  dz (fp16, loss-scaled) arrives from decoder.fc's data gradient.
+//   fused path   : dmu = ckl*mu + dz ;  dlv = ckl*0.5*(e^lv - 1) + dz*eps*0.5*e^{lv/2}
+//   explicit path: additional upstream gmu / glv (fp32, unscaled) times gscale are added, ckl = 0
+// output dml fp16 [B][2L] = [dmu | dlv]
+// ---------------------------------------------------------------------------------------------
+__global__ void lo_latent_bwd_kernel(const f16* __restrict__ dz, const float* __restrict__ mu, const float* __restrict__ logvar,
+                                     const float* __restrict__ eps, const float* __restrict__ coefs,
+                                     const float* __restrict__ gmu, const float* __restrict__ glv, float gscale,
+                                     f16* __restrict__ dml, int B, int L) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  int b = i / L, l = i - b * L;
+  float ckl = coefs ? coefs[1] : 0.f;
+  float d = (float)dz[i];
+  float lv = logvar[i];
+  float dm = ckl * mu[i] + d;
+  float dl = ckl * 0.5f * (expf(lv) - 1.f) + d * eps[i] * 0.5f * expf(0.5f * lv);
+  if (gmu) dm += gscale * gmu[i];
+  if (glv) dl += gscale * glv[i];
+  dml[(size_t)b * 2 * L + l] = (f16)dm;
+  dml[(size_t)b * 2 * L + L + l] = (f16)dl;
+}
+
+// column sums of an fp16 matrix [M][N] -> fp32 out[N]*scale  (Linear bias gradients; M = batch, tiny)
+__global__ void lo_colsum_f16_kernel(const f16* __restrict__ x, float* __restrict__ out, int M, int N, float scale) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  float t = 0.f;
+  for (int m = 0; m < M; ++m) t += (float)x[(size_t)m * N + j];
+  out[j] = t * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// casts
+// ---------------------------------------------------------------------------------------------
+__global__ void lo_cast_f32_f16_kernel(const float* __restrict__ src, f16* __restrict__ dst, size_t n4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    reinterpret_cast<f16x4*>(dst)[i] = h;
+  }
+}
+// dst[c][r] = (f16) src[r][c]   (src fp32 [R][C]); 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void lo_transpose_cast_kernel(const float* __restrict__ src, f16* __restrict__ dst, int R, int C) {
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) dst[(size_t)c * R + r] = (f16)t[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient norm + clip coefficient + AdamW over ONE flat fp32 buffer (all 72 tensors are views of it)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * 256;
+  float acc = 0.f;
+  size_t n4 = n / 4;
+  for (size_t k = i; k < n4; k += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(g)[k];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t k = n4 * 4; k < n; ++k) acc += g[k] * g[k];
+  float w = lo_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// norm_out: [0] = total L2 norm, [1] = clip coefficient, [2] = 1 if finite else 0
+__global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* __restrict__ partial, int n, float max_norm,
+                                                                   float* __restrict__ norm_out) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += (double)partial[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 256; ++i) s += red[i];
+    float norm = (float)sqrt(s);
+    float coef = max_norm / (norm + 1e-6f);
+    if (coef > 1.0f) coef = 1.0f;
+    bool finite = isfinite(norm);
+    norm_out[0] = norm;
+    norm_out[1] = finite ? coef : 0.f;
+    norm_out[2] = finite ? 1.f : 0.f;
+  }
+}
+// torch.optim.AdamW (decoupled weight decay, eps outside the bias-corrected sqrt) with the clip coefficient folded in.
+// A non-finite gradient norm skips the update (GradScaler semantics).
+__global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, size_t n, const float* __restrict__ norm,
+                                                       float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                       float bc2_sqrt) {
+  const float coef = norm ? norm[1] : 1.0f;
+  const bool ok = norm ? (norm[2] != 0.f) : true;
+  if (!ok) return;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * 256;
+  const float step_size = lr / bc1;
+  size_t n4 = n / 4;
+  for (size_t k = i; k < n4; k += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[k];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[k];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[k];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gg = gv[j] * coef;
+      float pp = pv[j] * (1.0f - lr * wd);
+      float mm = mv[j] + (gg - mv[j]) * (1.0f - beta1);
+      float v2 = vv[j] * beta2 + (1.0f - beta2) * gg * gg;
+      float denom = sqrtf(v2) / bc2_sqrt + eps;
+      pv[j] = pp - step_size * (mm / denom);
+      mv[j] = mm;
+      vv[j] = v2;
+    }
+    reinterpret_cast<f32x4*>(p)[k] = pv;
+    reinterpret_cast<f32x4*>(m)[k] = mv;
+    reinterpret_cast<f32x4*>(v)[k] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t k = n4 * 4; k < n; ++k) {
+      float gg = g[k] * coef;
+      float pp = p[k] * (1.0f - lr * wd);
+      float mm = m[k] + (gg - m[k]) * (1.0f - beta1);
+      float v2 = v[k] * beta2 + (1.0f - beta2) * gg * gg;
+      p[k] = pp - step_size * (mm / (sqrtf(v2) / bc2_sqrt + eps));
+      m[k] = mm;
+      v[k] = v2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, uint64_t seed, float* mu, float* logvar,
+                   f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st) {
+  int nb = (B * L + 255) / 256;
+  hipLaunchKernelGGL(lo_head_reduce_kernel, dim3(nb), dim3(256), 0, st, slab, bias, eps_in, seed, mu, logvar, z, eps_out,
+                     kl_partial, B, L, nsplit);
+  LO_LAUNCH_CHECK("head_reduce");
+  return LO_OK;
+}
+int lo_loss_finalize(const float* mse_partial, int n_mse, const float* kl_partial, int n_kl, float rw, float kw, float adv,
+                     const float* adv_dev, float accum, float ls, float* losses, float* coefs, float n_rec, float n_lat,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(lo_loss_finalize_kernel, dim3(1), dim3(256), 0, st, mse_partial, n_mse, kl_partial, n_kl, rw, kw, adv,
+                     accum, ls, adv_dev, losses, coefs, n_rec, n_lat);
+  LO_LAUNCH_CHECK("loss_finalize");
+  return LO_OK;
+}
+int lo_latent_bwd(const f16* dz, const float* mu, const float* logvar, const float* eps, const float* coefs,
+                  const float* gmu, const float* glv, float gscale, f16* dml, int B, int L, hipStream_t st) {
+  int n = B * L;
+  hipLaunchKernelGGL(lo_latent_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dz, mu, logvar, eps, coefs, gmu, glv,
+                     gscale, dml, B, L);
+  LO_LAUNCH_CHECK("latent_bwd");
+  return LO_OK;
+}
+int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(lo_colsum_f16_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, out, M, N, scale);
+  LO_LAUNCH_CHECK("colsum_f16");
+  return LO_OK;
+}
+int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st) {
+  LO_REQUIRE(n % 4 == 0, "lo_cast_f32_f16: n must be a multiple of 4");
+  size_t n4 = n / 4;
+  int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(lo_cast_f32_f16_kernel, dim3(nb), dim3(256), 0, st, src, dst, n4);
+  LO_LAUNCH_CHECK("cast");
+  return LO_OK;
+}
+int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st) {
+  hipLaunchKernelGGL(lo_transpose_cast_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, dst, R, C);
+  LO_LAUNCH_CHECK("transpose_cast");
+  return LO_OK;
+}
+#define LO_NORM_BLOCKS 1024
+int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial /*>=1024*/, float* norm_out, hipStream_t st) {
+  hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS), dim3(256), 0, st, g, n, partial);
+  LO_LAUNCH_CHECK("sumsq");
+  hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out);
+  LO_LAUNCH_CHECK("gradnorm_finalize");
+  return LO_OK;
+}
+int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
+             float eps, float wd, int step, hipStream_t st) {
+  float bc1 = 1.0f - powf(beta1, (float)step);
+  float bc2 = 1.0f - powf(beta2, (float)step);
+  double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
+  (void)bc1; (void)bc2;
+  hipLaunchKernelGGL(lo_adamw_kernel, dim3(2048), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
+                     (float)bc1d, (float)sqrt(bc2d));
+  LO_LAUNCH_CHECK("adamw");
+  return LO_OK;
+}

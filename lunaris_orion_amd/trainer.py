@@ -1,0 +1,95 @@
+"""The VAE half of ``TrainingManager._process_batch`` (reference: /root/reference/train_hybrid.py:838-954) as one
+native sequence on the current HIP stream: forward + MSE/KL partial sums -> loss finalize -> backward ->
+global-norm clip + AdamW -> (host) cosine-warm-restart LR.  No host synchronisation inside a step; metrics are
+returned as a device tensor and only converted on request.
+
+What is mirrored, line by line:
+  :841-842  zero_grad            -> every gradient element is overwritten by the backward (no accumulation state)
+  :850      vae(images)          -> lo_vae_forward (eps drawn on device unless injected)
+  :859,862  recon_loss, kl_loss  -> fused partial sums + lo_vae_loss
+  :886-889  vae_loss             -> (recon_weight - mean_advantage)*MSE + kl_weight*KL   (pg_loss = -mean(adv)*MSE)
+  :895      / accumulation steps
+  :907      optimizer steps only when (batch_idx+1) % accum == 0 — with the reference's zero_grad placement the
+            gradients of the other micro-batches are discarded, so their backward is skipped here
+  :913      clip_grad_norm_(max_grad_norm)   :921 AdamW(lr, wd=0.01, betas=(0.9,0.999))   :925 scheduler.step()
+The teacher's contribution is the detached scalar ``mean_advantage``; it is an input here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .vae import LunarisCoreVAE
+
+
+def cosine_warm_restarts_lr(base_lr: float, eta_min: float, t0: int, t_mult: int, epoch: int) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingWarmRestarts after ``epoch`` calls of step() (train_hybrid.py:516-521)."""
+    t_i, t_cur = t0, epoch
+    while t_cur >= t_i:
+        t_cur -= t_i
+        t_i *= t_mult
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t_cur / t_i)) / 2.0
+
+
+class VAEStepper:
+    def __init__(self, vae: LunarisCoreVAE, lr: float = 1e-4, min_lr: float = 1e-6, scheduler_t0: int = 10,
+                 weight_decay: float = 0.01, max_grad_norm: float = 1.0, recon_weight: float = 1.0, kl_weight: float = 0.1,
+                 gradient_accumulation_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8):
+        _lib.require_gpu()
+        self.vae = vae
+        self.base_lr, self.min_lr, self.t0 = lr, min_lr, scheduler_t0
+        self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
+        self.recon_weight, self.kl_weight = recon_weight, kl_weight
+        self.accum = max(1, int(gradient_accumulation_steps))
+        self.betas, self.eps = betas, eps
+        flat = vae.flat_parameters()
+        self.grads = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.scratch = torch.zeros(1028, dtype=torch.float32, device=flat.device)   # [1024:1027] = norm, clip coef, finite
+        self.losses = torch.zeros(4, dtype=torch.float32, device=flat.device)       # recon, kl, vae_loss, pg_loss
+        self.opt_steps = 0
+        self.last = None
+
+    @property
+    def lr(self) -> float:
+        return cosine_warm_restarts_lr(self.base_lr, self.min_lr, self.t0, 2, self.opt_steps)
+
+    def step(self, images: torch.Tensor, batch_idx: int = 0, eps: Optional[torch.Tensor] = None,
+             mean_advantage: float = 0.0, adv_dev: Optional[torch.Tensor] = None):
+        """One micro-batch.  Returns (recon, mu, logvar); losses stay on the device in ``self.losses``."""
+        vae = self.vae
+        images = images.detach().contiguous().float()
+        recon, mu, logvar, eng = vae._native_forward(images, eps, target=images)
+        st = _lib.stream_ptr()
+        _lib.check(_lib.lib.lo_vae_loss(eng.handle, eng.ws.data_ptr(), self.recon_weight, self.kl_weight, float(mean_advantage),
+                                        _lib.ptr(adv_dev), float(self.accum), float(vae.loss_scale), self.losses.data_ptr(), st),
+                   "lo_vae_loss")
+        if (batch_idx + 1) % self.accum == 0:
+            flat = vae._flat
+            _lib.check(_lib.lib.lo_vae_backward(eng.handle, images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
+                                                images.data_ptr(), 1, None, None, None, float(vae.loss_scale),
+                                                self.grads.data_ptr(), st), "lo_vae_backward")
+            lr = self.lr
+            self.opt_steps += 1
+            _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                   self.exp_avg_sq.data_ptr(), flat.numel(), float(self.max_grad_norm), float(lr),
+                                                   float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                   float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st),
+                       "lo_clip_adamw_step")
+            vae.mark_weights_changed()
+        self.last = (recon, mu, logvar)
+        return recon, mu, logvar
+
+    def metrics(self) -> Dict[str, float]:
+        """Host copy of the last step's scalars (this synchronises the stream)."""
+        v = torch.cat([self.losses, self.scratch[1024:1027]]).cpu().tolist()
+        return {"recon_loss": v[0], "kl_loss": v[1], "vae_loss": v[2], "pg_loss": v[3], "grad_norm": v[4],
+                "clip_coef": v[5], "grads_finite": v[6], "lr": self.lr}
+
+    def parameter_grads(self):
+        """Views of the flat gradient buffer, one per parameter (state_dict order)."""
+        return [self.grads[o:o + n].view(shape) for (o, n, shape) in self.vae._layout]

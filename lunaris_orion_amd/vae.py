@@ -1,0 +1,233 @@
+"""LunarisCoreVAE on MI355X: same ``nn.Module`` surface as the reference, arithmetic in liblunaris_hip.so.
+
+Drop-in contract (reference: /root/reference/lunar_generate.py):
+  * ``LunarisCoreVAE(latent_dim=256)``; ``forward(x) -> (reconstruction, mu, logvar)`` (:263-276);
+    ``.encoder`` / ``.decoder`` sub-module trees with the reference's attribute paths, so the 72
+    ``state_dict`` keys and shapes are identical (``encoder.down1.0.weight`` ...
+    ``decoder.final_conv.bias``) and checkpoints interchange; default PyTorch initialisers, created in
+    the reference's order (same weights for the same seed); ``reparameterize`` (:248-261); ``sample(n)``
+    (:278-291).
+  * parameters are fp32 ``nn.Parameter``s.  They are views of ONE flat fp32 buffer (so clip + AdamW is
+    a single fused kernel and a data-parallel gradient exchange is one contiguous buffer); any
+    optimizer that works on ``model.parameters()`` still works.
+
+The sub-modules are parameter containers only: ``forward`` never calls them.  It hands the flat
+parameter buffer to the native step executor (``lo_vae_forward`` / ``lo_vae_backward``), which
+enqueues every kernel of the pass on PyTorch's current HIP stream.  There is no PyTorch/CPU fallback:
+on a machine without the GPU library the import of ``_lib`` fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_ENC = ((3, 64), (64, 128), (128, 256), (256, 512))
+_DEC = ((512, 256), (256, 128), (128, 64), (64, 32))
+
+
+def _conv_gn_mish(cin: int, cout: int, **conv_kw) -> List[nn.Module]:
+    return [nn.Conv2d(cin, cout, **conv_kw), nn.GroupNorm(num_groups=8, num_channels=cout), nn.Mish()]
+
+
+class ResBlock(nn.Module):
+    """Parameter container for the reference ResBlock (lunar_generate.py:28-53)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        if in_channels != out_channels:
+            raise NotImplementedError("the VAE only uses identity-shortcut ResBlocks (lunar_generate.py:98,105,112,119)")
+        self.conv1 = nn.Sequential(*_conv_gn_mish(in_channels, out_channels, kernel_size=3, padding=1))
+        self.conv2 = nn.Sequential(*_conv_gn_mish(out_channels, out_channels, kernel_size=3, padding=1))
+        self.shortcut = nn.Identity()
+
+
+class Encoder(nn.Module):
+    """Parameter container: 4 x (Conv k3 s2 -> GN -> Mish -> ResBlock), fc_mu, fc_logvar (lunar_generate.py:84-125)."""
+
+    def __init__(self, latent_dim: int = 256):
+        super().__init__()
+        for i, (cin, cout) in enumerate(_ENC, start=1):
+            stage = _conv_gn_mish(cin, cout, kernel_size=3, stride=2, padding=1) + [ResBlock(cout, cout)]
+            setattr(self, f"down{i}", nn.Sequential(*stage))
+        self.flatten = nn.Flatten()
+        self.fc_mu = nn.Linear(512 * 8 * 8, latent_dim)
+        self.fc_logvar = nn.Linear(512 * 8 * 8, latent_dim)
+
+
+class Decoder(nn.Module):
+    """Parameter container: fc, 4 x (ConvTranspose k4 s2 -> GN -> Mish), final_conv (lunar_generate.py:155-192)."""
+
+    def __init__(self, latent_dim: int = 256):
+        super().__init__()
+        self.fc = nn.Linear(latent_dim, 512 * 8 * 8)
+        for i, (cin, cout) in enumerate(_DEC, start=1):
+            setattr(self, f"up{i}", nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1),
+                                                  nn.GroupNorm(8, cout), nn.Mish()))
+        self.final_conv = nn.Conv2d(32, 3, kernel_size=3, padding=1)
+
+
+class _Engine:
+    """Native plan + workspace for one (batch, latent_dim, device)."""
+
+    def __init__(self, batch: int, latent_dim: int, device: torch.device):
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib.lo_vae_create(batch, latent_dim, C.byref(self.handle)), "lo_vae_create")
+        self.batch, self.latent_dim, self.device = batch, latent_dim, device
+        self.ws = torch.empty(_lib.lib.lo_vae_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
+        self.packed_version = -1
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib.lo_vae_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _VAEFunction(torch.autograd.Function):
+    """Autograd bridge: forward/backward of the whole VAE are one native call each."""
+
+    @staticmethod
+    def forward(ctx, model, x, eps, *params):
+        recon, mu, logvar, eng = model._native_forward(x, eps, target=None)
+        ctx.model, ctx.eng = model, eng
+        ctx.save_for_backward(x, recon)
+        return recon, mu, logvar
+
+    @staticmethod
+    def backward(ctx, g_recon, g_mu, g_logvar):
+        model, eng = ctx.model, ctx.eng
+        x, recon = ctx.saved_tensors
+        flat_g = torch.empty_like(model._flat)
+        cont = lambda t: None if t is None else t.contiguous().float()
+        g_recon, g_mu, g_logvar = cont(g_recon), cont(g_mu), cont(g_logvar)
+        _lib.check(_lib.lib.lo_vae_backward(eng.handle, x.data_ptr(), model._flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
+                                            None, 0, _lib.ptr(g_recon), _lib.ptr(g_mu), _lib.ptr(g_logvar),
+                                            float(model.loss_scale), flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_backward")
+        grads = tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in model._layout)
+        return (None, None, None) + grads
+
+
+class LunarisCoreVAE(nn.Module):
+    """Variational auto-encoder for 128x128 pixel art; see the module docstring for the drop-in contract."""
+
+    def __init__(self, latent_dim: int = 256):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.encoder = Encoder(latent_dim=latent_dim)
+        self.decoder = Decoder(latent_dim=latent_dim)
+        self.loss_scale = 65536.0      # fp16 gradient range (the reference's GradScaler starts at 2**16 too)
+        self._flat: Optional[torch.Tensor] = None
+        self._layout: List[Tuple[int, int, torch.Size]] = []
+        self._engines: Dict[Tuple[int, str], _Engine] = {}
+        self._weights_version = 0      # bumped whenever the fp32 parameters may have changed
+        self._seed = 0x5EED
+
+    # ---- flat parameter buffer ------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._flat = None              # parameters were re-created (e.g. .to(device)): re-flatten lazily
+        self._engines.clear()
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self.mark_weights_changed()
+        return out
+
+    def mark_weights_changed(self) -> None:
+        """Call after modifying parameters in place (optimizer step, manual edits): the fp16 operand copies are re-packed."""
+        self._weights_version += 1
+
+    def _ensure_flat(self) -> None:
+        params = list(self.parameters())
+        dev = params[0].device
+        if self._flat is not None and self._flat.device == dev:
+            ok = all(p.data_ptr() == self._flat.data_ptr() + 4 * o for p, (o, _n, _s) in zip(params, self._layout))
+            if ok:
+                return
+        _lib.require_gpu()
+        if dev.type != "cuda":
+            raise _lib.LunarisHipError("LunarisCoreVAE parameters must be on the GPU (model.to('cuda')); there is no CPU path")
+        probe = C.c_void_p()
+        _lib.check(_lib.lib.lo_vae_create(1, self.latent_dim, C.byref(probe)), "lo_vae_create")
+        try:
+            assert _lib.lib.lo_vae_num_params(probe) == len(params), "parameter table mismatch"
+            layout = []
+            for i, p in enumerate(params):
+                n = _lib.lib.lo_vae_param_numel(probe, i)
+                assert n == p.numel(), f"parameter {i}: numel {p.numel()} != {n}"
+                layout.append((_lib.lib.lo_vae_param_offset(probe, i), n, p.shape))
+            total = _lib.lib.lo_vae_flat_elems(probe)
+        finally:
+            _lib.lib.lo_vae_destroy(probe)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, (o, n, shape) in zip(params, layout):
+                flat[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[o:o + n].view(shape)
+        self._flat, self._layout = flat, layout
+        self._weights_version += 1
+        self._engines.clear()
+
+    def flat_parameters(self) -> torch.Tensor:
+        """The single fp32 buffer all 72 parameters are views of (padding elements are zero)."""
+        self._ensure_flat()
+        return self._flat
+
+    def _engine(self, batch: int) -> _Engine:
+        self._ensure_flat()
+        key = (batch, str(self._flat.device))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _Engine(batch, self.latent_dim, self._flat.device)
+            self._engines[key] = eng
+        if eng.packed_version != self._weights_version:
+            _lib.check(_lib.lib.lo_vae_pack(eng.handle, self._flat.data_ptr(), eng.ws.data_ptr(), _lib.stream_ptr()), "lo_vae_pack")
+            eng.packed_version = self._weights_version
+        return eng
+
+    # ---- forward --------------------------------------------------------------------------
+    def _native_forward(self, x: torch.Tensor, eps: Optional[torch.Tensor], target: Optional[torch.Tensor]):
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
+            raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B = x.shape[0]
+        eng = self._engine(B)
+        dev = x.device
+        recon = torch.empty(B, 3, 128, 128, dtype=torch.float32, device=dev)
+        mu = torch.empty(B, self.latent_dim, dtype=torch.float32, device=dev)
+        logvar = torch.empty(B, self.latent_dim, dtype=torch.float32, device=dev)
+        if eps is not None:
+            eps = eps.detach().contiguous().float()
+            if tuple(eps.shape) != (B, self.latent_dim):
+                raise ValueError("eps must have shape [B, latent_dim]")
+        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        _lib.check(_lib.lib.lo_vae_forward(eng.handle, x.data_ptr(), _lib.ptr(eps), self._seed, self._flat.data_ptr(),
+                                           eng.ws.data_ptr(), recon.data_ptr(), mu.data_ptr(), logvar.data_ptr(),
+                                           _lib.ptr(target), _lib.stream_ptr()), "lo_vae_forward")
+        return recon, mu, logvar, eng
+
+    def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        """(reconstruction, mu, logvar), lunar_generate.py:263-276.  ``eps`` optionally injects the N(0,1) noise of
+        ``reparameterize`` (parity runs); by default it is drawn on the device."""
+        self._ensure_flat()
+        x = x.detach().contiguous().float()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _VAEFunction.apply(self, x, eps, *self.parameters())
+        recon, mu, logvar, _ = self._native_forward(x, eps, None)
+        return recon, mu, logvar
+
+    def reparameterize(self, mu: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
+        """z = mu + eps * exp(0.5 logvar), lunar_generate.py:248-261 (tiny [B, L] op; PyTorch elementwise)."""
+        std = torch.exp(0.5 * logvar)
+        return mu + torch.randn_like(std) * std
+
+    def sample(self, num_samples: int):
+        """lunar_generate.py:278-291 (decoder without skips).  Not on the training hot path; not built yet."""
+        raise NotImplementedError("decoder-only sampling (SURVEY §8 F4) is not built in this round")

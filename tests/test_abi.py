@@ -1,0 +1,74 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/lunaris_hip.h declares; the
+host-side planner (no kernels launched) lays the 72 parameters out as documented."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "lunaris_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lunaris_orion_amd import _lib
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in include/lunaris_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES.keys()), set(names) ^ set(_lib.SIGNATURES.keys())
+    assert _lib.lib.lo_version() >= 1
+
+
+@pytest.mark.parametrize("L", [256, 512])
+def test_flat_parameter_layout(L):
+    from lunaris_orion_amd import _lib
+    from oracle import vae_ref as R
+    h = C.c_void_p()
+    _lib.check(_lib.lib.lo_vae_create(8, L, C.byref(h)))
+    shapes = list(R.param_shapes(L).items())
+    assert _lib.lib.lo_vae_num_params(h) == len(shapes) == 72
+    spans = []
+    for i, (k, shp) in enumerate(shapes):
+        n = 1
+        for d in shp:
+            n *= d
+        assert _lib.lib.lo_vae_param_numel(h, i) == n, k
+        off = _lib.lib.lo_vae_param_offset(h, i)
+        assert off % 64 == 0
+        spans.append((off, off + n, k))
+    spans.sort()
+    for a, b in zip(spans, spans[1:]):
+        assert a[1] <= b[0], (a, b)                      # no overlap
+    assert spans[-1][1] <= _lib.lib.lo_vae_flat_elems(h)
+    idx = {k: i for i, (k, _) in enumerate(shapes)}
+    mu_w, lv_w = idx["encoder.fc_mu.weight"], idx["encoder.fc_logvar.weight"]
+    assert _lib.lib.lo_vae_param_offset(h, lv_w) == _lib.lib.lo_vae_param_offset(h, mu_w) + L * 32768   # one [2L,32768] head
+    assert _lib.lib.lo_vae_workspace_bytes(h) > 0
+    _lib.lib.lo_vae_destroy(h)
+
+
+def test_bad_arguments_return_error_codes():
+    from lunaris_orion_amd import _lib
+    h = C.c_void_p()
+    assert _lib.lib.lo_vae_create(8, 100, C.byref(h)) == -1          # latent_dim must be a multiple of 64
+    assert b"latent_dim" in _lib.lib.lo_last_error()
+    assert _lib.lib.lo_packed_weight_elems_for(99, 1, 8, 8, 64, 64) == 0
+
+
+def test_module_surface_matches_reference_contract():
+    from lunaris_orion_amd.vae import Decoder, Encoder, LunarisCoreVAE, ResBlock  # noqa: F401
+    m = LunarisCoreVAE(latent_dim=512)
+    assert m.latent_dim == 512
+    sd = m.state_dict()
+    assert tuple(sd["decoder.up1.0.weight"].shape) == (512, 256, 4, 4)
+    assert tuple(sd["encoder.down1.3.conv1.0.weight"].shape) == (64, 64, 3, 3)
+    assert sum(p.numel() for p in m.parameters()) == 60_978_563      # SURVEY §6, latent 512
+    assert all(p.dtype == torch.float32 for p in m.parameters())
+    assert len(list(m.buffers())) == 0

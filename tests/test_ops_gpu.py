@@ -1,0 +1,289 @@
+"""GPU parity tests of the single HIP ops (through the C ABI) against plain PyTorch fp32 on the CPU.
+
+Inputs are rounded through fp16 first (the kernels' operand type), so the only differences left are
+fp32 accumulation order and the fp16 rounding of the outputs; tolerances are stated per test.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.hip_helpers import L, conv_forward, conv_wgrad, from_nhwc, h16, rel_err, sync, to_nhwc_h
+
+pytestmark = pytest.mark.gpu
+
+KIND_S1, KIND_S2, KIND_T4, KIND_S1D, KIND_S2D, KIND_T4D, KIND_LIN = range(7)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return h16(torch.randn(*shape, generator=g) * scale)
+
+
+CONV_CASES = [
+    # kind, B, Cin, Cout, H
+    (KIND_S1, 2, 64, 64, 64),
+    (KIND_S1, 2, 128, 128, 32),
+    (KIND_S1, 3, 512, 512, 8),
+    (KIND_S1, 8, 256, 256, 16),
+    (KIND_S2, 2, 64, 128, 64),
+    (KIND_S2, 2, 256, 512, 16),
+    (KIND_T4, 2, 512, 256, 8),
+    (KIND_T4, 2, 64, 32, 64),
+    (KIND_T4, 4, 128, 64, 32),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H", CONV_CASES)
+def test_conv_forward_and_gn_partials(kind, B, Cin, Cout, H):
+    x = _rand(B, Cin, H, H, seed=1)
+    if kind == KIND_T4:
+        w = _rand(Cin, Cout, 4, 4, seed=2, scale=(Cin * 4) ** -0.5)
+        ref = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    else:
+        w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+        ref = F.conv2d(x, w, None, stride=1 if kind == KIND_S1 else 2, padding=1)
+    bias = _rand(Cout, seed=3, scale=0.1)
+    ref = ref + bias.view(1, -1, 1, 1)
+    out, part, mt = conv_forward(kind, x, w, bias, Cout, want_partial=True)
+    got = from_nhwc(out)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 4e-3 * max(1.0, ref.abs().max().item()), err   # fp16 output rounding (2^-11 relative)
+    # GroupNorm partial sums: (sum, sumsq) per (sample, group) of the fp16-rounded output
+    G = Cout // 8
+    tot = part.double().sum(dim=1).cpu()                            # [B, 8, 2]
+    g5 = got.double().view(B, 8, G, -1)
+    assert torch.allclose(tot[:, :, 0], g5.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, :, 1], (g5 * g5).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+
+
+DGRAD_CASES = [
+    (KIND_S1D, KIND_S1, 2, 64, 64, 64),
+    (KIND_S1D, KIND_S1, 2, 512, 512, 8),
+    (KIND_S2D, KIND_S2, 2, 64, 128, 64),
+    (KIND_S2D, KIND_S2, 2, 256, 512, 16),
+    (KIND_T4D, KIND_T4, 2, 512, 256, 8),
+    (KIND_T4D, KIND_T4, 2, 64, 32, 64),
+]
+
+
+@pytest.mark.parametrize("dkind,fkind,B,Cin,Cout,H", DGRAD_CASES)
+def test_conv_dgrad(dkind, fkind, B, Cin, Cout, H):
+    """data gradient == autograd of the forward op; also exercises the fused residual add."""
+    x = _rand(B, Cin, H, H, seed=1).requires_grad_(True)
+    if fkind == KIND_T4:
+        w = _rand(Cin, Cout, 4, 4, seed=2, scale=(Cin * 4) ** -0.5)
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    else:
+        w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+        y = F.conv2d(x, w, None, stride=1 if fkind == KIND_S1 else 2, padding=1)
+    dy = _rand(*y.shape, seed=4)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    add = _rand(*x.shape, seed=5)
+    # the dgrad op reads dy (channels = Cout of the forward) and writes Cin channels
+    out = conv_forward(dkind, dy, w, None, Cin, add_src=add)
+    got = from_nhwc(out)
+    ref = dx_ref + add
+    err = (got - ref).abs().max().item()
+    assert err <= 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
+WGRAD_CASES = [
+    (KIND_S1, 2, 64, 64, 64),
+    (KIND_S1, 4, 512, 512, 8),
+    (KIND_S1, 2, 128, 128, 32),
+    (KIND_S2, 2, 64, 128, 64),
+    (KIND_S2, 2, 256, 512, 16),
+    (KIND_T4, 2, 512, 256, 8),
+    (KIND_T4, 2, 64, 32, 64),
+    (KIND_T4, 2, 128, 64, 32),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H", WGRAD_CASES)
+def test_conv_wgrad(kind, B, Cin, Cout, H):
+    x = _rand(B, Cin, H, H, seed=1)
+    if kind == KIND_T4:
+        w = _rand(Cin, Cout, 4, 4, seed=2).requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    else:
+        w = _rand(Cout, Cin, 3, 3, seed=2).requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=1 if kind == KIND_S1 else 2, padding=1)
+    dy = _rand(*y.shape, seed=4, scale=0.1)
+    (dw_ref,) = torch.autograd.grad(y, w, dy)
+    got = conv_wgrad(kind, x, dy, Cout, tuple(w.shape), scale=0.5)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, 0.5 * dw_ref) <= 2e-4, rel_err(got, 0.5 * dw_ref)   # fp32 accumulate of exact fp16 products
+
+
+@pytest.mark.parametrize("M,K,N,nsplit", [(2, 32768, 512, 32), (64, 32768, 1024, 32), (8, 512, 128, 4), (37, 1024, 64, 3)])
+def test_linear_splitk(M, K, N, nsplit):
+    lib = L()
+    x = _rand(M, K, seed=1)
+    w = _rand(N, K, seed=2, scale=K ** -0.5)
+    b = _rand(N, seed=3)
+    ref = F.linear(x, w, b)
+    xd = x.to("cuda", torch.float16)
+    wd = w.to("cuda", torch.float16)
+    slab = torch.empty(nsplit * M * N, dtype=torch.float32, device="cuda")
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    bdev = b.cuda()   # keep device copies alive until the kernels have run
+    lib.check(lib.lib.lo_linear_splitk(M, K, N, xd.data_ptr(), wd.data_ptr(), bdev.data_ptr(), slab.data_ptr(), nsplit,
+                                       out.data_ptr(), None, lib.stream_ptr()))
+    sync()
+    assert (out.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kind,M,K,N", [(KIND_LIN, 64, 32768, 512), (KIND_LIN, 2, 256, 32768), (KIND_LIN, 5, 32768, 1024)])
+def test_linear_wgrad(kind, M, K, N):
+    x = _rand(M, K, seed=1)
+    dy = _rand(M, N, seed=2, scale=0.1)
+    ref = dy.t() @ x
+    got = conv_wgrad(kind, x.view(M, K, 1, 1), dy.view(M, N, 1, 1), N, (N, K))
+    assert rel_err(got, ref) <= 2e-4
+
+
+@pytest.mark.parametrize("B,C,HW,mode", [(2, 64, 4096, 0), (2, 64, 4096, 2), (3, 512, 64, 2), (2, 256, 256, 1), (2, 32, 16384, 0), (2, 128, 1024, 1)])
+def test_gn_mish_forward_backward(B, C, HW, mode):
+    lib = L()
+    H = int(HW ** 0.5)
+    v = _rand(B, C, H, H, seed=1, scale=1.5).requires_grad_(True)
+    gamma = (1 + 0.25 * _rand(C, seed=2)).requires_grad_(True)
+    beta = (0.1 * _rand(C, seed=3)).requires_grad_(True)
+    other = _rand(B, C, H, H, seed=4).requires_grad_(True) if mode else None
+    u = F.group_norm(v, 8, gamma, beta, 1e-5)
+    y = F.mish(u)
+    if mode == 1:
+        y = y + other
+    elif mode == 2:
+        y = F.mish(y + other)
+    dy = _rand(B, C, H, H, seed=5)
+    # partial sums as the conv epilogue would deliver them (one tile per sample)
+    g5 = v.detach().double().view(B, 8, C // 8, HW)
+    part = torch.stack([g5.sum(dim=(2, 3)), (g5 * g5).sum(dim=(2, 3))], dim=-1).float().view(B, 1, 8, 2).contiguous().cuda()
+    vd = to_nhwc_h(v.detach())
+    od = to_nhwc_h(other.detach()) if mode else None
+    yd = torch.empty_like(vd)
+    stats = torch.empty(B, 8, 2, dtype=torch.float32, device="cuda")
+    gd, bd = gamma.detach().cuda(), beta.detach().cuda()
+    lib.check(lib.lib.lo_gn_mish_forward(vd.data_ptr(), part.data_ptr(), 1, gd.data_ptr(), bd.data_ptr(), lib.ptr(od),
+                                         yd.data_ptr(), stats.data_ptr(), B, HW, C, mode, lib.stream_ptr()))
+    sync()
+    got = from_nhwc(yd)
+    assert (got - y.detach()).abs().max().item() <= 3e-3 * max(1.0, y.abs().max().item())
+    # backward
+    grads = torch.autograd.grad(y, [v, gamma, beta] + ([other] if mode == 2 else []), dy)
+    nchunk = lib.lib.lo_gn_nchunk_for(HW, C)
+    P1 = torch.empty(B * nchunk * C * 2, dtype=torch.float32, device="cuda")
+    P2 = torch.empty(B * nchunk * C, dtype=torch.float32, device="cuda")
+    dyd = to_nhwc_h(dy)
+    dv = torch.empty_like(vd)
+    ds = torch.empty_like(vd) if mode == 2 else None
+    dg = torch.empty(C, dtype=torch.float32, device="cuda")
+    db = torch.empty(C, dtype=torch.float32, device="cuda")
+    dbias = torch.empty(C, dtype=torch.float32, device="cuda")
+    bmode = 2 if mode == 2 else 0
+    lib.check(lib.lib.lo_gn_mish_backward(dyd.data_ptr(), vd.data_ptr(), lib.ptr(od) if mode == 2 else None, stats.data_ptr(),
+                                          gd.data_ptr(), bd.data_ptr(), lib.ptr(ds), dv.data_ptr(), P1.data_ptr(), P2.data_ptr(),
+                                          dg.data_ptr(), db.data_ptr(), dbias.data_ptr(), B, HW, C, bmode, 1.0, lib.stream_ptr()))
+    sync()
+    assert rel_err(from_nhwc(dv), grads[0]) <= 3e-3
+    assert rel_err(dg.cpu(), grads[1]) <= 2e-3
+    assert rel_err(db.cpu(), grads[2]) <= 2e-3
+    assert rel_err(dbias.cpu(), grads[0].sum(dim=(0, 2, 3))) <= 5e-2 or grads[0].sum(dim=(0, 2, 3)).abs().max() < 1e-2
+    if mode == 2:
+        assert rel_err(from_nhwc(ds), grads[3]) <= 3e-3
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_first_conv(B):
+    lib = L()
+    x = torch.randn(B, 3, 128, 128, generator=torch.Generator().manual_seed(1))
+    w = (torch.randn(64, 3, 3, 3, generator=torch.Generator().manual_seed(2)) / 27 ** 0.5).requires_grad_(True)
+    b = torch.randn(64, generator=torch.Generator().manual_seed(3)) * 0.1
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    v = torch.empty(B, 64, 64, 64, dtype=torch.float16, device="cuda")
+    part = torch.empty(B, 64, 8, 2, dtype=torch.float32, device="cuda")
+    xd, wdev, bdev = x.cuda(), w.detach().cuda(), b.cuda()   # keep device copies alive until the kernels have run
+    lib.check(lib.lib.lo_first_conv_forward(xd.data_ptr(), wdev.data_ptr(), bdev.data_ptr(), v.data_ptr(),
+                                            part.data_ptr(), B, lib.stream_ptr()))
+    sync()
+    got = from_nhwc(v)
+    assert (got - ref.detach()).abs().max().item() <= 3e-3 * max(1.0, ref.abs().max().item())
+    g5 = got.double().view(B, 8, 8, -1)
+    tot = part.double().sum(dim=1).cpu()
+    assert torch.allclose(tot[:, :, 0], g5.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, :, 1], (g5 * g5).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    dy = _rand(B, 64, 64, 64, seed=4, scale=0.1)
+    (dw_ref,) = torch.autograd.grad(ref, w, dy)
+    partial = torch.empty(B * 8 * 1728, dtype=torch.float32, device="cuda")
+    dw = torch.empty(64, 3, 3, 3, dtype=torch.float32, device="cuda")
+    dyd = to_nhwc_h(dy)
+    lib.check(lib.lib.lo_first_conv_wgrad_op(xd.data_ptr(), dyd.data_ptr(), partial.data_ptr(), dw.data_ptr(), B, 1.0,
+                                             lib.stream_ptr()))
+    sync()
+    assert rel_err(dw.cpu(), dw_ref) <= 1e-4
+
+
+@pytest.mark.parametrize("B,explicit", [(1, False), (2, True)])
+def test_final_conv(B, explicit):
+    lib = L()
+    a4 = _rand(B, 32, 128, 128, seed=1).requires_grad_(True)
+    w = (torch.randn(3, 32, 3, 3, generator=torch.Generator().manual_seed(2)) / 288 ** 0.5).requires_grad_(True)
+    b = (torch.randn(3, generator=torch.Generator().manual_seed(3)) * 0.1).requires_grad_(True)
+    target = torch.rand(B, 3, 128, 128, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    recon_ref = torch.tanh(F.conv2d(a4, w, b, padding=1))
+    a4d = to_nhwc_h(a4.detach())
+    wd, bd, td = w.detach().cuda(), b.detach().cuda(), target.cuda()
+    recon = torch.empty(B, 3, 128, 128, dtype=torch.float32, device="cuda")
+    msep = torch.empty(B * 64, dtype=torch.float32, device="cuda")
+    lib.check(lib.lib.lo_final_conv_forward(a4d.data_ptr(), wd.data_ptr(), bd.data_ptr(), td.data_ptr(), recon.data_ptr(),
+                                            msep.data_ptr(), B, lib.stream_ptr()))
+    sync()
+    assert (recon.cpu() - recon_ref.detach()).abs().max().item() <= 2e-5
+    mse_ref = F.mse_loss(recon_ref, target)
+    assert abs(msep.double().sum().item() / target.numel() - mse_ref.item()) <= 1e-6
+    scale = 1024.0
+    if explicit:
+        drecon = torch.randn(B, 3, 128, 128, generator=torch.Generator().manual_seed(5)) * 1e-3
+        grads = torch.autograd.grad(recon_ref, [a4, w, b], drecon)
+        coef = None
+        dr = drecon.cuda()
+    else:
+        c = 0.37 * 2.0 / target.numel()
+        grads = torch.autograd.grad(0.37 * mse_ref, [a4, w, b])
+        coef = torch.tensor([c * scale], dtype=torch.float32, device="cuda")
+        dr = None
+    da4 = torch.empty_like(a4d)
+    partial = torch.empty(B * 64 * 867, dtype=torch.float32, device="cuda")
+    dw = torch.empty(3, 32, 3, 3, dtype=torch.float32, device="cuda")
+    db = torch.empty(3, dtype=torch.float32, device="cuda")
+    lib.check(lib.lib.lo_final_conv_backward(a4d.data_ptr(), wd.data_ptr(), recon.data_ptr(), None if explicit else td.data_ptr(),
+                                             lib.ptr(dr), lib.ptr(coef), scale, da4.data_ptr(), partial.data_ptr(), dw.data_ptr(),
+                                             db.data_ptr(), B, 1.0 / scale, lib.stream_ptr()))
+    sync()
+    assert rel_err(from_nhwc(da4) / scale, grads[0]) <= 2e-3
+    assert rel_err(dw.cpu(), grads[1]) <= 1e-4
+    assert rel_err(db.cpu(), grads[2]) <= 1e-4
+
+
+def test_clip_adamw_matches_torch():
+    lib = L()
+    n = 1_000_003
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g)
+    p_ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999))
+    pd, md, vd = p.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    scratch = torch.zeros(1028, dtype=torch.float32, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 0.01 * step
+        p_ref.grad = grad.clone()
+        norm = torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        gd = grad.cuda()
+        lib.check(lib.lib.lo_clip_adamw_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1.0, 1e-3, 0.9, 0.999,
+                                             1e-8, 0.01, step, scratch.data_ptr(), lib.stream_ptr()))
+        sync()
+        assert abs(scratch[1024].item() - norm.item()) <= 1e-4 * norm.item()
+        assert (pd.cpu() - p_ref.detach()).abs().max().item() <= 2e-6
