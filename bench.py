@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: 128x128 sprites/sec through the full VAE training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = TrainingManager._process_batch semantics for the VAE (reference train_hybrid.py:838-954) with
+--gradient_accumulation_steps 1 and the teacher's scalar at 0 (--reward_scale 0 --quality_weight 0): forward,
+MSE + KL, backward, global-norm clip, AdamW, LR schedule — all through liblunaris_hip.so.  Inputs are synthetic
+sprites already resident in HBM (fp32 NCHW, normalised like train_hybrid.py:181-182).  Per-GPU batch is fixed
+(weak scaling); with N>1 the flat gradient buffer is averaged with one RCCL all-reduce per step.
+
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel (HIP events on the
+launch stream, collected by the library's per-launch profiler in extra steps after the timed region) and a
+`cpu_baseline` object (the CPU oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0           # HBM3E spec (same table)
+
+
+def synth_sprites(n: int, seed: int) -> torch.Tensor:
+    rng = np.random.default_rng(seed)
+    u8 = rng.integers(0, 256, (n, 128, 128, 3), dtype=np.uint8)
+    return (torch.from_numpy(u8).float() / 127.5 - 1.0).permute(0, 3, 1, 2).contiguous()
+
+
+def collect_profile(lib):
+    rows = {}
+    name = C.create_string_buffer(128)
+    ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+    for i in range(lib.lo_prof_count()):
+        lib.lo_prof_get(i, name, 128, C.byref(ms), C.byref(fl), C.byref(by))
+        r = rows.setdefault(name.value.decode(), [0.0, 0, 0.0, 0.0])
+        if ms.value >= 0:
+            r[0] += ms.value
+            r[1] += 1
+            r[2] += fl.value
+            r[3] += by.value
+    return rows
+
+
+def cpu_baseline(batch: int, latent: int, steps: int):
+    """The oracle (CPU restatement, fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle import vae_ref as R
+    # the GPU box gives one GPU's share of the host (16 cores); more threads than that only oversubscribes
+    cores = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    P = {k: torch.randn(shp) * (0.02 if len(shp) > 1 else 0.0) + (1.0 if k.endswith(".1.weight") else 0.0)
+         for k, shp in R.param_shapes(latent).items()}
+    tr = R.OracleTrainer(P)
+    x = synth_sprites(batch, 123)
+    eps = torch.randn(batch, latent)
+    tr.step(x, eps, 0.0)  # warm-up
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tr.step(x, eps, 0.0)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": batch / med, "unit": "sprites/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (oracle/vae_ref.py OracleTrainer, fp32, {cores} threads), batch {batch} latent {latent}, "
+                      f"1 warm-up + {steps} timed full training steps, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--latent", type=int, default=512)
+    ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from lunaris_orion_amd import _lib
+    from lunaris_orion_amd.trainer import VAEStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+
+    torch.manual_seed(42)                      # identical initial weights on every rank (train_hybrid.py:1088,1138)
+    model = LunarisCoreVAE(latent_dim=args.latent).to("cuda")
+    grad_sync = None
+    if world > 1:
+        def grad_sync(flat_grads):
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.AVG)
+    st = VAEStepper(model, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
+                    kl_weight=0.1, gradient_accumulation_steps=1, grad_sync=grad_sync)
+    B = args.batch
+    pool = [synth_sprites(B, 1000 * rank + i).cuda() for i in range(4)]
+
+    def run(n):
+        for i in range(n):
+            st.step(pool[i % len(pool)], batch_idx=i)
+
+    run(args.warmup)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    met = st.metrics()
+    assert met["grads_finite"] == 1.0 and np.isfinite(met["recon_loss"]), met
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: per-launch HIP events on the launch stream, extra steps after the timed region
+        rows = {}
+        if args.prof_steps > 0:
+            _lib.lib.lo_prof_enable(1)
+            run(args.prof_steps)
+            torch.cuda.synchronize()
+            rows = collect_profile(_lib.lib)
+            _lib.lib.lo_prof_enable(0)
+        if not rows:
+            rows = {"(not profiled)": [1.0, 1, 0.0, 0.0]}
+        total_ms = sum(r[0] for r in rows.values())
+        dom_name, dom = max(rows.items(), key=lambda kv: kv[1][0])
+        d_ms, d_n, d_fl, d_by = dom
+        if d_fl > 0:
+            roof = {"bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": d_by / (d_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = dom_name
+        roof["launches_per_step"] = d_n / max(args.prof_steps, 1)
+        roof["avg_launch_ms"] = d_ms / max(d_n, 1)
+        roof["share_of_kernel_time"] = d_ms / total_ms
+        mfma = {k: r for k, r in rows.items() if r[2] > 0 and ("igemm" in k or "wgrad_tn" in k)}
+        mf_ms = sum(r[0] for r in mfma.values())
+        mf_fl = sum(r[2] for r in mfma.values())
+        roof["all_mfma_kernels_tflops"] = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else None
+        if args.breakdown:
+            for k, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+                sys.stderr.write(f"{k:34s} {r[0] / max(args.prof_steps, 1):9.4f} ms/step  n={r[1] // max(args.prof_steps, 1):3d}  "
+                                 f"{(r[2] / (r[0] * 1e-3) / 1e12 if r[0] > 0 else 0):8.1f} TFLOP/s  "
+                                 f"{(r[3] / (r[0] * 1e-3) / 1e9 if r[0] > 0 else 0):8.1f} GB/s\n")
+            sys.stderr.write(f"sum of kernel time {total_ms / max(args.prof_steps, 1):.4f} ms/step\n")
+        out = {
+            "metric": "128x128 sprites/sec, VAE training step (train_hybrid.py _process_batch), latent_dim=512",
+            "value": world * B * args.steps / elapsed,
+            "unit": "sprites/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"VAE-only training step (fwd+MSE/KL+bwd+clip+AdamW), per-GPU batch {B}, latent_dim {args.latent}, "
+                                   "teacher scalar 0 (--reward_scale 0 --quality_weight 0; the teacher forward of BASELINE config 3 is not built yet), "
+                                   "gradient_accumulation_steps 1, fp16 MFMA operands / fp32 accumulate, fp32 master weights",
+                       "global_batch": world * B, "latent_dim": args.latent,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roof,
+            "final_metrics": {k: met[k] for k in ("recon_loss", "kl_loss", "grad_norm")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.latent, args.cpu_steps)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

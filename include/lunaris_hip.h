@@ -27,6 +27,12 @@ extern "C" {
 const char* lo_last_error(void);
 int lo_version(void);
 
+/* Per-launch timing with HIP events recorded on the launch stream (used by bench.py's roofline leg).  Enable, run,
+ * synchronise the stream, then read record i: kernel name, elapsed ms, algorithmic FLOPs and bytes of that launch. */
+void lo_prof_enable(int on);
+int lo_prof_count(void);
+int lo_prof_get(int i, char* name, int name_cap, double* ms, double* flops, double* bytes);
+
 /* ---- op kinds for the generic implicit-GEMM entry points ---------------------------------------------------- */
 enum {
   LO_KIND_CONV3_S1 = 0,        /* nn.Conv2d(k3,s1,p1)           lunar_generate.py:36,41          */

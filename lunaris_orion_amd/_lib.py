@@ -29,6 +29,9 @@ vp, f32p, i32, sz, u64, flt = C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_u
 SIGNATURES = {
     "lo_last_error": (C.c_char_p, []),
     "lo_version": (i32, []),
+    "lo_prof_enable": (None, [i32]),
+    "lo_prof_count": (i32, []),
+    "lo_prof_get": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lo_packed_weight_elems_for": (sz, [i32] * 6),
     "lo_pack_weight_for": (i32, [i32] * 6 + [f32p, vp, vp]),
     "lo_conv_forward": (i32, [i32] * 6 + [vp, vp, f32p, vp, vp, f32p, C.POINTER(C.c_int), vp]),

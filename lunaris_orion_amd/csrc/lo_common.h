@@ -40,6 +40,24 @@ int lo_check_hip(hipError_t e, const char* what);
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// Optional per-launch timing with HIP events ON THE LAUNCH STREAM (bench.py's roofline leg).  Off by default:
+// one predictable branch per launcher.
+// ---------------------------------------------------------------------------------------------
+extern bool g_lo_prof_on;
+void lo_prof_begin(const char* name, double flops, double bytes, hipStream_t st);
+void lo_prof_end(hipStream_t st);
+struct LoProfScope {
+  hipStream_t st;
+  bool on;
+  LoProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s), on(g_lo_prof_on) {
+    if (on) lo_prof_begin(name, flops, bytes, s);
+  }
+  ~LoProfScope() {
+    if (on) lo_prof_end(st);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Geometry of one implicit-GEMM convolution-like op (forward conv, transposed conv as sub-pixel
 // phases, and every data-gradient of those).  All tensors are NHWC fp16.
 //
@@ -54,7 +72,8 @@ int lo_check_hip(hipError_t e, const char* what);
 struct LoGeom {
   int B, Hin, Win, Cin;
   int Hout, Wout, Cout;
-  int GH, GW;          // output grid per phase
+  int GH, GW;          // output grid per phase (powers of two)
+  int lgh, lgw;        // log2(GH), log2(GW)
   int in_stride, out_stride;
   int n_phase;
   int T[LO_MAX_PHASE];
@@ -63,6 +82,7 @@ struct LoGeom {
   int8_t dy[LO_MAX_PHASE][LO_MAX_TAPS];
   int8_t dx[LO_MAX_PHASE][LO_MAX_TAPS];
   int8_t rs[LO_MAX_PHASE][LO_MAX_TAPS];   // r*S+s of the canonical weight this tap reads
+  uint32_t dyc[LO_MAX_PHASE], dxc[LO_MAX_PHASE];  // the same offsets, 2 bits per tap: (d + 1) << (2*t)
   // canonical weight addressing: W[n*sn + c*sc + rs]  (n = this op's output channel, c = reduced channel)
   int sn, sc;
 };

@@ -13,6 +13,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // geometry builder (host)
@@ -87,6 +88,17 @@ int lo_make_geom(LoGeom* g, int kind, int B, int H, int W, int Cin, int Cout) {
   }
   int off = 0;
   for (int p = 0; p < g->n_phase; ++p) { g->wofs[p] = off; off += Cout * g->T[p] * Cin; }
+  if ((g->GH & (g->GH - 1)) || (g->GW & (g->GW - 1)) || g->GH < 1 || g->GW < 1) {
+    lo_set_error("lo_make_geom: output grid %dx%d must be powers of two", g->GH, g->GW);
+    return LO_ERR_ARG;
+  }
+  while ((1 << g->lgh) < g->GH) ++g->lgh;
+  while ((1 << g->lgw) < g->GW) ++g->lgw;
+  for (int p = 0; p < g->n_phase; ++p)
+    for (int t = 0; t < g->T[p]; ++t) {
+      g->dyc[p] |= (uint32_t)(g->dy[p][t] + 1) << (2 * t);
+      g->dxc[p] |= (uint32_t)(g->dx[p][t] + 1) << (2 * t);
+    }
   return LO_OK;
 }
 
@@ -130,27 +142,55 @@ struct IgemmArgs {
   LoGeom g;
 };
 
-template <int BM, int BN, int BK, bool SPLITK>
+// 16 zero bytes x 16: source of every LDS-DMA lane whose row is padding / out of range
+__device__ __attribute__((aligned(256))) unsigned int lo_zero_page[64];
+
+#define LO_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Map the linear block id so that
+// every XCD works on ONE contiguous range of logical tile ids: tiles that re-read the same activations (the taps of a
+// pixel tile, the N tiles of an M tile) then hit in that XCD's L2 instead of the Infinity Cache.  Bijective for any
+// total (speed only, never correctness).
+__device__ __forceinline__ int lo_xcd_remap(int bid, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// Operand tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs and no ds_write pass (the
+// ds_write_b128 path sustains only ~80 B/clk/CU, which made the register-staged version LDS-bound).  One
+// wave-instruction fills 1 KiB of LDS linearly, so tiles are unpadded [rows][BK] and bank conflicts are removed by an
+// XOR swizzle applied on the per-lane SOURCE chunk and again on the fragment read: chunk' = chunk ^ ((row >> 1) & (CPR-1)).
+// NSTAGE LDS stages, NSTAGE-1 K steps in flight behind a counted s_waitcnt vmcnt + one raw s_barrier per K step.
+template <int BM, int BN, int BK, int NSTAGE, bool SPLITK>
 __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   constexpr int CPR = BK / 8;             // 16-byte chunks per tile row
-  constexpr int RPP = 256 / CPR;          // rows loaded per pass
-  constexpr int PA = BM / RPP, PB = BN / RPP;
-  static_assert(PA >= 1 && PB >= 1, "tile too small for 256 threads");
-  constexpr int PITCH = BK * 2 + 32;      // bytes; +32 makes the ds_read_b128 fragment reads conflict-free
-  constexpr int A_BYTES = BM * PITCH, B_BYTES = BN * PITCH;
+  constexpr int RPI = 64 / CPR;           // tile rows filled by one wave-instruction
+  constexpr int ROWB = BK * 2;            // bytes per tile row
+  constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;   // LDS-DMA instructions per wave and K step (A, B)
+  static_assert(IA >= 1 && IB >= 1 && IA * RPI * 4 == BM && IB * RPI * 4 == BN, "tile / wave-instruction mismatch");
+  constexpr int LPT = IA + IB;
+  constexpr int D = NSTAGE - 1;           // K steps in flight
+  static_assert(LPT * D <= 63, "vmcnt range");
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int WM = BM / 2, WN = BN / 2; // wave tile (2 x 2 waves)
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;     // epilogue staging pitch (bytes)
-  constexpr int LDS_BYTES = (2 * STAGE > BM * OPITCH + 4096) ? 2 * STAGE : BM * OPITCH + 4096;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  constexpr int LDS_BYTES = (NSTAGE * STAGE > BM * OPITCH + 4096) ? NSTAGE * STAGE : BM * OPITCH + 4096;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
 
   const LoGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int phase = SPLITK ? 0 : blockIdx.z;
-  const int split = SPLITK ? blockIdx.z : 0;
+  // logical tile id -> (n tile fastest, then m tile, then phase / K split)
+  const int NT = g.Cout / BN, MT = (a.M + BM - 1) / BM;
+  const int tile_id = lo_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt_i = tile_id % NT, mt_i = (tile_id / NT) % MT, z_i = tile_id / (NT * MT);
+  const int m0 = mt_i * BM, n0 = nt_i * BN;
+  const int phase = SPLITK ? 0 : z_i;
+  const int split = SPLITK ? z_i : 0;
   const int T = g.T[phase];
   const int KCB = g.Cin / BK;
   const int ksteps_total = T * KCB;
@@ -159,53 +199,71 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     ks_begin = split * a.ksteps_per_split;
     ks_end = min(ksteps_total, ks_begin + a.ksteps_per_split);
   }
+  const int nk = ks_end - ks_begin;
   const int Ktot = T * g.Cin;
   const f16* wbase = a.w + g.wofs[phase];
+  const f16* zpage = reinterpret_cast<const f16*>(lo_zero_page);
+  const uint32_t dyc = g.dyc[phase], dxc = g.dxc[phase];   // tap offsets in registers: no memory load inside the K loop
 
-  // per-thread load coordinates
-  const int lrow = tid / CPR, lchunk = tid % CPR;
-  int a_pix[PA];       // (n*Hin) row base is folded below
-  int a_iy0[PA], a_ix0[PA];
-  bool a_ok[PA];
+  // per-lane source coordinates of the LDS-DMA instructions this wave issues.  Everything that depends only on the
+  // tap is recomputed when the tap changes; a K step then costs one add + one select per instruction.
+  const int lrow = lane / CPR, lpos = lane % CPR;
+  int a_base[IA], a_iy0[IA], a_ix0[IA];   // element offset of (n, iy0, ix0, chunk); -1 = row out of range
 #pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    int m = m0 + lrow + i * RPP;
-    a_ok[i] = m < a.M;
-    int mm = a_ok[i] ? m : 0;
-    int n_img = mm / (g.GH * g.GW);
-    int rem = mm - n_img * (g.GH * g.GW);
-    int gy = rem / g.GW, gx = rem - gy * g.GW;
-    a_pix[i] = n_img * g.Hin;
-    a_iy0[i] = gy * g.in_stride;
+  for (int i = 0; i < IA; ++i) {
+    int row = (wave * IA + i) * RPI + lrow;
+    int m = m0 + row;
+    bool ok = m < a.M;
+    int mm = ok ? m : 0;
+    int gx = mm & (g.GW - 1), gy = (mm >> g.lgw) & (g.GH - 1), n_img = mm >> (g.lgw + g.lgh);
+    a_iy0[i] = ok ? gy * g.in_stride : -100000;       // makes every tap invalid for an out-of-range row
     a_ix0[i] = gx * g.in_stride;
+    a_base[i] = ((n_img * g.Hin + gy * g.in_stride) * g.Win + gx * g.in_stride) * g.Cin +
+                (lpos ^ ((row >> 1) & (CPR - 1))) * 8;   // logical chunk stored at this lane's LDS slot
   }
-  const f16* b_ptr[PB];
+  int b_base[IB];
 #pragma unroll
-  for (int i = 0; i < PB; ++i) b_ptr[i] = wbase + (size_t)(n0 + lrow + i * RPP) * Ktot + lchunk * 8;
-
-  u32x4 ra[PA], rb[PB];
-  auto gload = [&](int ks) __attribute__((always_inline)) {
-    int t = ks / KCB;
-    int c0 = (ks - t * KCB) * BK;
-    int dy = g.dy[phase][t], dx = g.dx[phase][t];
+  for (int i = 0; i < IB; ++i) {
+    int row = (wave * IB + i) * RPI + lrow;
+    b_base[i] = (n0 + row) * Ktot + (lpos ^ ((row >> 1) & (CPR - 1))) * 8;
+  }
+  // issue-side K position (tap, channel block) and the per-tap source offsets
+  int i_t = ks_begin / KCB, i_cb = ks_begin - i_t * KCB, i_ks = ks_begin;
+  int a_tap[IA];
+  auto set_tap = [&](int t) __attribute__((always_inline)) {
+    int dy = (int)((dyc >> (2 * t)) & 3u) - 1, dx = (int)((dxc >> (2 * t)) & 3u) - 1;
+    int delta = (dy * g.Win + dx) * g.Cin;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-      bool ok = a_ok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)((a_pix[i] + iy) * g.Win + ix) * g.Cin + c0 + lchunk * 8));
-      ra[i] = v;
+    for (int i = 0; i < IA; ++i) {
+      bool ok = (unsigned)(a_iy0[i] + dy) < (unsigned)g.Hin && (unsigned)(a_ix0[i] + dx) < (unsigned)g.Win;
+      a_tap[i] = ok ? a_base[i] + delta : -1;
     }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)ks * BK);
   };
-  auto lstore = [&](int stage) __attribute__((always_inline)) {
+  set_tap(i_t < T ? i_t : 0);
+
+  auto issue = [&](int stage) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE;
     unsigned char* sb = sa + A_BYTES;
+    const bool live = i_ks < ks_end;
+    const int coff = i_cb * BK;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(sa + (lrow + i * RPP) * PITCH + lchunk * 16) = ra[i];
+    for (int i = 0; i < IA; ++i) {
+      const f16* src = (live && a_tap[i] >= 0) ? a.in + (a_tap[i] + coff) : zpage;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * IA + i) * 1024), 16, 0, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(sb + (lrow + i * RPP) * PITCH + lchunk * 16) = rb[i];
+    for (int i = 0; i < IB; ++i) {
+      const f16* src = live ? wbase + (b_base[i] + i_ks * BK) : zpage;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sb + (wave * IB + i) * 1024), 16, 0, 0);
+    }
+    ++i_ks;
+    if (++i_cb == KCB) {
+      i_cb = 0;
+      ++i_t;
+      if (i_t < T) set_tap(i_t);
+    }
   };
 
   f32x4 acc[NI][MI];
@@ -215,36 +273,52 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
-  if (ks_begin < ks_end) {
-    gload(ks_begin);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-      const bool more = ks + 1 < ks_end;
-      if (more) gload(ks + 1);
-      const unsigned char* sa = smem + cur * STAGE;
-      const unsigned char* sb = sa + A_BYTES;
+  // fragment read offsets (bytes inside a stage), swizzled like the DMA sources
+  int xoff[MI][BK / 32], woff[NI][BK / 32];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      int R = wm * WM + mi * 16 + fr;
+      xoff[mi][kk] = R * ROWB + (((kk * 4 + fq) ^ ((R >> 1) & (CPR - 1))) * 16);
+    }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      int R = wn * WN + ni * 16 + fr;
+      woff[ni][kk] = A_BYTES + R * ROWB + (((kk * 4 + fq) ^ ((R >> 1) & (CPR - 1))) * 16);
+    }
+
+  if (nk > 0) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s);
+    int rs = 0;            // stage being read
+    int ws = D % NSTAGE;   // stage being refilled
+    for (int it = 0; it < nk; ++it) {
+      LO_VMCNT(LPT * (D - 1));          // this wave's DMA for K step `it` has landed ...
+      __builtin_amdgcn_s_barrier();     // ... and so has every other wave's; stage `ws` is no longer being read
+      issue(ws);
+      const unsigned char* sbase = smem + rs * STAGE;
 #pragma unroll
       for (int kk = 0; kk < BK / 32; ++kk) {
         f16x8 wf[NI], xf[MI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          wf[ni] = *reinterpret_cast<const f16x8*>(sb + (wn * WN + ni * 16 + fr) * PITCH + (kk * 4 + fq) * 16);
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const f16x8*>(sbase + woff[ni][kk]);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          xf[mi] = *reinterpret_cast<const f16x8*>(sa + (wm * WM + mi * 16 + fr) * PITCH + (kk * 4 + fq) * 16);
+        for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const f16x8*>(sbase + xoff[mi][kk]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
       }
-      if (more) lstore(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
+      rs = (rs + 1 == NSTAGE) ? 0 : rs + 1;
+      ws = (ws + 1 == NSTAGE) ? 0 : ws + 1;
     }
+    LO_VMCNT(0);                        // drain the (dummy) tail DMAs before LDS is reused by the epilogue
   }
+  __syncthreads();
 
   // D^T block (ni, mi): lane holds pixel m = mi*16 + fr, channels n = ni*16 + fq*4 + {0..3}
   if (SPLITK) {
@@ -362,6 +436,7 @@ struct WgradArgs {
   float* grad;      // canonical fp32 gradient, written directly when nsplit == 1 (direct mode)
   float scale;
   int direct;
+  int taps;         // total taps over all phases
   int M;            // pixels per phase = B*GH*GW
   int nsplit;
   int msteps_per_split;  // 32-pixel steps per split
@@ -369,78 +444,92 @@ struct WgradArgs {
   LoGeom g;         // FORWARD geometry
 };
 
-template <int BMW, int BNW>
+// LDS-DMA staged like lo_igemm_nt.  Tiles are [32 pixel rows][BMW or BNW channels] fp16, unpadded; the transposed
+// fragment reads (ds_read_b64_tr_b16) are kept conflict-free by XOR-swizzling 32-byte blocks inside a row:
+//   256-byte rows: block ^= row & 7        128-byte rows: block ^= (row >> 1) & 3
+// Output channels n >= Cout (a 32-channel layer run with the 64-wide tile) read the zero page and are not stored.
+template <int RB>
+__device__ __forceinline__ int lo_tr_swz(int row) {
+  return RB == 256 ? (row & 7) : ((row >> 1) & 3);
+}
+
+template <int BMW, int BNW, int NSTAGE>
 __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
   constexpr int BKP = 32;                        // pixels per K step
-  constexpr int PITCH_A = BMW * 2 + 32, PITCH_B = BNW * 2 + 32;  // bytes; +32: conflict-free tr reads
-  constexpr int A_BYTES = BKP * PITCH_A, B_BYTES = BKP * PITCH_B;
+  constexpr int RBA = BMW * 2, RBB = BNW * 2;    // row bytes
+  static_assert((RBA == 128 || RBA == 256) && (RBB == 128 || RBB == 256), "tile rows must be 128 or 256 bytes");
+  constexpr int A_BYTES = BKP * RBA, B_BYTES = BKP * RBB;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int CPA = BMW / 8, CPB = BNW / 8;    // 16-byte chunks per row
-  constexpr int NA = (BKP * CPA + 255) / 256, NB = (BKP * CPB + 255) / 256;  // loads per thread
+  constexpr int IA = A_BYTES / 1024 / 4, IB = B_BYTES / 1024 / 4;   // LDS-DMA instructions per wave and K step
+  constexpr int CPA = RBA / 16, CPB = RBB / 16;  // 16-byte chunks per row
+  constexpr int RPA = 64 / CPA, RPB = 64 / CPB;  // rows per wave-instruction
+  constexpr int LPT = IA + IB, D = NSTAGE - 1;
   constexpr int WM = BMW / 2, WN = BNW / 2, MI = WM / 16, NI = WN / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
   const LoGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
-  const int ntile_n = g.Cout / BMW;
-  const int tn = blockIdx.x % ntile_n, tc = blockIdx.x / ntile_n;
+  const int ntile_n = (g.Cout + BMW - 1) / BMW, ntile_c = g.Cin / BNW;
+  // logical id -> (tap fastest, then channel tiles, then pixel split): workgroups that read the same pixels are adjacent
+  const int wid = lo_xcd_remap(blockIdx.x, gridDim.x);
+  int t = wid % a.taps;
+  const int tile = (wid / a.taps) % (ntile_n * ntile_c);
+  const int tn = tile % ntile_n, tc = tile / ntile_n;
   const int n0 = tn * BMW, c0 = tc * BNW;
-  // blockIdx.y enumerates (phase, tap)
-  int phase = 0, t = blockIdx.y;
+  int phase = 0;                   // t enumerates (phase, tap)
   while (t >= g.T[phase]) { t -= g.T[phase]; ++phase; }
   const int dyo = g.dy[phase][t], dxo = g.dx[phase][t];
-  const int split = blockIdx.z;
+  const int ooy = g.out_oy[phase], oox = g.out_ox[phase];
+  const int split = wid / (a.taps * ntile_n * ntile_c);
   const int ms_begin = split * a.msteps_per_split;
   const int ms_total = (a.M + BKP - 1) / BKP;
   const int ms_end = min(ms_total, ms_begin + a.msteps_per_split);
+  const int nk = ms_end - ms_begin;
+  const f16* zpage = reinterpret_cast<const f16*>(lo_zero_page);
 
-  u32x4 ra[NA], rb[NB];
-  auto gload = [&](int ms) __attribute__((always_inline)) {
+  // per-lane constants of the DMA instructions
+  int a_row[IA], a_col[IA], b_row[IB], b_col[IB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int idx = tid + i * 256;
-      int row = idx / CPA, ch = idx % CPA;
-      int m = ms * BKP + row;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < a.M && idx < BKP * CPA) {
-        int n_img = m / (g.GH * g.GW);
-        int rem = m - n_img * (g.GH * g.GW);
-        int gy = rem / g.GW, gx = rem - gy * g.GW;
-        int oy = gy * g.out_stride + g.out_oy[phase], ox = gx * g.out_stride + g.out_ox[phase];
-        v = *reinterpret_cast<const u32x4*>(a.dy + ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * g.Cout + n0 + ch * 8);
-      }
-      ra[i] = v;
-    }
+  for (int i = 0; i < IA; ++i) {
+    int row = (wave * IA + i) * RPA + lane / CPA, pos = lane % CPA;
+    int chunk = (((pos >> 1) ^ lo_tr_swz<RBA>(row)) << 1) | (pos & 1);
+    a_row[i] = row;
+    a_col[i] = n0 + chunk * 8;
+  }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int idx = tid + i * 256;
-      int row = idx / CPB, ch = idx % CPB;
-      int m = ms * BKP + row;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < a.M && idx < BKP * CPB) {
-        int n_img = m / (g.GH * g.GW);
-        int rem = m - n_img * (g.GH * g.GW);
-        int gy = rem / g.GW, gx = rem - gy * g.GW;
-        int iy = gy * g.in_stride + dyo, ix = gx * g.in_stride + dxo;
-        if ((unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
-          v = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(n_img * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + ch * 8);
-      }
-      rb[i] = v;
-    }
-  };
-  auto lstore = [&](int stage) __attribute__((always_inline)) {
+  for (int i = 0; i < IB; ++i) {
+    int row = (wave * IB + i) * RPB + lane / CPB, pos = lane % CPB;
+    int chunk = (((pos >> 1) ^ lo_tr_swz<RBB>(row)) << 1) | (pos & 1);
+    b_row[i] = row;
+    b_col[i] = c0 + chunk * 8;
+  }
+  const int pmask_w = g.GW - 1, pmask_h = g.GH - 1;
+
+  auto issue = [&](int stage, int ms) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE;
     unsigned char* sb = sa + A_BYTES;
+    const bool live = ms < ms_end;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int idx = tid + i * 256;
-      if (idx < BKP * CPA) *reinterpret_cast<u32x4*>(sa + (idx / CPA) * PITCH_A + (idx % CPA) * 16) = ra[i];
+    for (int i = 0; i < IA; ++i) {
+      int m = ms * BKP + a_row[i];
+      int gx = m & pmask_w, gy = (m >> g.lgw) & pmask_h, n_img = m >> (g.lgw + g.lgh);
+      int oy = gy * g.out_stride + ooy, ox = gx * g.out_stride + oox;
+      bool ok = live && m < a.M && a_col[i] < g.Cout;
+      const f16* src = ok ? a.dy + ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * g.Cout + a_col[i] : zpage;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * IA + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int idx = tid + i * 256;
-      if (idx < BKP * CPB) *reinterpret_cast<u32x4*>(sb + (idx / CPB) * PITCH_B + (idx % CPB) * 16) = rb[i];
+    for (int i = 0; i < IB; ++i) {
+      int m = ms * BKP + b_row[i];
+      int gx = m & pmask_w, gy = (m >> g.lgw) & pmask_h, n_img = m >> (g.lgw + g.lgh);
+      int iy = gy * g.in_stride + dyo, ix = gx * g.in_stride + dxo;
+      bool ok = live && m < a.M && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+      const f16* src = ok ? a.x + ((size_t)(n_img * g.Hin + iy) * g.Win + ix) * g.Cin + b_col[i] : zpage;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sb + (wave * IB + i) * 1024), 16, 0, 0);
     }
   };
 
@@ -450,39 +539,48 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // transposed fragment reads.  The 32 pixel rows of a K step are assigned to MFMA k positions by the
-  // SAME permutation for both operands (lane group q reads rows 4q..4q+3 and 16+4q..16+4q+3), which keeps
-  // every ds_read_b64_tr_b16 conflict-free at this pitch; any consistent k permutation leaves the sum unchanged.
+  // transposed fragment reads.  The 32 pixel rows of a K step are assigned to MFMA k positions by the SAME
+  // permutation for both operands (lane group q reads rows 4q..4q+3 and 16+4q..16+4q+3); any consistent k
+  // permutation leaves the sum unchanged.
   const int q16 = lane >> 4, i16 = lane & 15;
   const int trow = 4 * q16 + (i16 >> 2);   // row supplied by this lane (first read); +16 for the second
-  const int tcol = (i16 & 3) * 4;          // first of the 4 columns this lane addresses
-  if (ms_begin < ms_end) {
-    gload(ms_begin);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int ms = ms_begin; ms < ms_end; ++ms) {
-      const bool more = ms + 1 < ms_end;
-      if (more) gload(ms + 1);
-      const unsigned char* sa = smem + cur * STAGE;
-      const unsigned char* sb = sa + A_BYTES;
+  const int tsub = (i16 & 3) * 8;          // byte offset inside the 32-byte block
+  int aoff[MI][2], boff[NI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int R = trow + 16 * h, blk = (wm * WM + mi * 16) / 16;
+      aoff[mi][h] = R * RBA + ((blk ^ lo_tr_swz<RBA>(R)) * 32) + tsub;
+    }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int R = trow + 16 * h, blk = (wn * WN + ni * 16) / 16;
+      boff[ni][h] = A_BYTES + R * RBB + ((blk ^ lo_tr_swz<RBB>(R)) * 32) + tsub;
+    }
+
+  if (nk > 0) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s, ms_begin + s);
+    int rs = 0, ws = D % NSTAGE;
+    for (int it = 0; it < nk; ++it) {
+      LO_VMCNT(LPT * (D - 1));
+      __builtin_amdgcn_s_barrier();
+      issue(ws, ms_begin + it + D);
+      const unsigned char* sbase = smem + rs * STAGE;
       f16x8 af[MI], bf[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        int col = wm * WM + mi * 16 + tcol;
-        h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (h16x4 __attribute__((address_space(3)))*)(sa + trow * PITCH_A + col * 2));
-        h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (h16x4 __attribute__((address_space(3)))*)(sa + (trow + 16) * PITCH_A + col * 2));
+        h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + aoff[mi][0]));
+        h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + aoff[mi][1]));
         af[mi] = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        int col = wn * WN + ni * 16 + tcol;
-        h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (h16x4 __attribute__((address_space(3)))*)(sb + trow * PITCH_B + col * 2));
-        h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (h16x4 __attribute__((address_space(3)))*)(sb + (trow + 16) * PITCH_B + col * 2));
+        h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + boff[ni][0]));
+        h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + boff[ni][1]));
         bf[ni] = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
       }
 #pragma unroll
@@ -490,15 +588,15 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-      if (more) lstore(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
+      rs = (rs + 1 == NSTAGE) ? 0 : rs + 1;
+      ws = (ws + 1 == NSTAGE) ? 0 : ws + 1;
     }
+    LO_VMCNT(0);
   }
   // D[n][c] block (mi, ni): lane holds column c = ni*16 + (lane&15), rows n = mi*16 + (lane>>4)*4 + j
   float* slab = a.slab + (size_t)split * a.packed_elems + g.wofs[phase];
   const int Ktot = g.T[phase] * g.Cin;
-  const int rs = g.rs[phase][t];
+  const int rs_w = g.rs[phase][t];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -507,8 +605,10 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int n = n0 + wm * WM + mi * 16 + (lane >> 4) * 4 + j;
-        if (a.direct) a.grad[(size_t)n * g.sn + (size_t)c * g.sc + rs] = acc[mi][ni][j] * a.scale;
-        else slab[(size_t)n * Ktot + t * g.Cin + c] = acc[mi][ni][j];
+        if (n < g.Cout) {
+          if (a.direct) a.grad[(size_t)n * g.sn + (size_t)c * g.sc + rs_w] = acc[mi][ni][j] * a.scale;
+          else slab[(size_t)n * Ktot + t * g.Cin + c] = acc[mi][ni][j];
+        }
       }
     }
 }
@@ -535,19 +635,38 @@ __global__ void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __
 // ---------------------------------------------------------------------------------------------
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st) {
   int total = geom_packed_elems(g);
+  LoProfScope _p("lo_pack_weight", 0, 6.0 * total, st);
   hipLaunchKernelGGL(lo_pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g, total);
   LO_LAUNCH_CHECK("pack_weight");
   return LO_OK;
 }
 
+static inline double geom_flops(const LoGeom& g) {
+  double f = 0;
+  for (int p = 0; p < g.n_phase; ++p) f += 2.0 * g.B * g.GH * g.GW * (double)g.Cout * g.T[p] * g.Cin;
+  return f;
+}
+// algorithmic bytes: input read once + output written once (fp16) + packed weights once
+static inline double geom_bytes(const LoGeom& g) {
+  return 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + (double)g.B * g.Hout * g.Wout * g.Cout + geom_packed_elems(g));
+}
+
 template <int BM, int BN, int BK>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   const LoGeom& g = a.g;
-  dim3 grid((a.M + BM - 1) / BM, g.Cout / BN, a.nsplit > 1 ? a.nsplit : g.n_phase);
+  static char name[64];
+  snprintf(name, sizeof(name), "lo_igemm_nt<%d,%d,%d>%s", BM, BN, BK, a.nsplit > 1 ? "/splitK" : "");  // same text for every call of this instantiation
+  LoProfScope _p(name, geom_flops(g), geom_bytes(g), st);
+  dim3 grid(((a.M + BM - 1) / BM) * (g.Cout / BN) * (a.nsplit > 1 ? a.nsplit : g.n_phase));
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);
+  static const int deep = getenv("LO_DEEP_PIPE") ? atoi(getenv("LO_DEEP_PIPE")) : 0;   // tuning knob: one more LDS stage
   if (a.nsplit > 1)
-    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, true>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE, true>), grid, dim3(256), 0, st, a);
+  else if (deep)
+    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE + 1, false>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE, false>), grid, dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("igemm");
   return LO_OK;
 }
@@ -603,23 +722,26 @@ int lo_conv_tile_m(const LoGeom& g) {
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit,
                      hipStream_t st) {
   int total = M * N;
+  LoProfScope _p("lo_splitk_reduce", 0, 4.0 * total * (nsplit + 1), st);
   hipLaunchKernelGGL(lo_splitk_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, bias, out32, out16, M, N, nsplit);
   LO_LAUNCH_CHECK("splitk_reduce");
   return LO_OK;
 }
 
+static inline int wgrad_bmw(const LoGeom& g) { return g.Cout % 128 == 0 ? 128 : 64; }
+static inline int wgrad_bnw(const LoGeom& g) { return g.Cin % 128 == 0 ? 128 : 64; }
+
 // number of pixel splits the wgrad launcher will use for this geometry (callers size the slab with it)
 int lo_wgrad_nsplit(const LoGeom& g) {
-  int bmw = g.Cout % 128 == 0 ? 128 : (g.Cout % 64 == 0 ? 64 : 32);
-  int bnw = g.Cin % 128 == 0 ? 128 : (g.Cin % 64 == 0 ? 64 : 32);
+  int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g);
   int taps = 0;
   for (int p = 0; p < g.n_phase; ++p) taps += g.T[p];
-  long tiles = (long)(g.Cout / bmw) * (g.Cin / bnw) * taps;
+  long tiles = (long)((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps;
   int M = g.B * g.GH * g.GW;
   int ms_total = (M + 31) / 32;
-  long want = (1024 + tiles - 1) / tiles;  // aim at >= 1024 workgroups
+  long want = (768 + tiles - 1) / tiles;  // aim at >= 768 workgroups
   if (want < 1) want = 1;
-  if (want > ms_total / 4) want = ms_total / 4 > 0 ? ms_total / 4 : 1;   // at least 4 K steps per split
+  if (want > ms_total / 8) want = ms_total / 8 > 0 ? ms_total / 8 : 1;   // at least 8 K steps per split
   if (want > 256) want = 256;
   return (int)want;
 }
@@ -633,26 +755,25 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   a.direct = (a.nsplit == 1 && g.sc == 1) ? 1 : 0;
   int ms_total = (a.M + 31) / 32;
   a.msteps_per_split = (ms_total + a.nsplit - 1) / a.nsplit;
-  LO_REQUIRE(g.Cin % 32 == 0 && g.Cout % 32 == 0, "lo_wgrad_run: channels must be multiples of 32 (Cin=%d Cout=%d)", g.Cin, g.Cout);
+  LO_REQUIRE(g.Cin % 64 == 0 && g.Cout % 32 == 0, "lo_wgrad_run: need Cin %% 64 == 0 and Cout %% 32 == 0 (Cin=%d Cout=%d)", g.Cin, g.Cout);
   int taps = 0;
   for (int p = 0; p < g.n_phase; ++p) taps += g.T[p];
-  int bmw = g.Cout % 128 == 0 ? 128 : (g.Cout % 64 == 0 ? 64 : 32);
-  int bnw = g.Cin % 128 == 0 ? 128 : (g.Cin % 64 == 0 ? 64 : 32);
-  dim3 grid((g.Cout / bmw) * (g.Cin / bnw), taps, a.nsplit);
-#define LO_WG(BMW, BNW) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW>), grid, dim3(256), 0, st, a)
-  if (bmw == 128 && bnw == 128) LO_WG(128, 128);
-  else if (bmw == 128 && bnw == 64) LO_WG(128, 64);
-  else if (bmw == 64 && bnw == 128) LO_WG(64, 128);
-  else if (bmw == 64 && bnw == 64) LO_WG(64, 64);
-  else if (bmw == 32 && bnw == 64) LO_WG(32, 64);
-  else if (bmw == 64 && bnw == 32) LO_WG(64, 32);
-  else if (bmw == 128 && bnw == 32) LO_WG(128, 32);
-  else if (bmw == 32 && bnw == 128) LO_WG(32, 128);
-  else { lo_set_error("lo_wgrad_run: unsupported tile %dx%d", bmw, bnw); return LO_ERR_ARG; }
+  int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g);
+  a.taps = taps;
+  dim3 grid(((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps * a.nsplit);
+  {
+    LoProfScope _p("lo_wgrad_tn", geom_flops(g), geom_bytes(g), st);
+#define LO_WG(BMW, BNW) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 3>), grid, dim3(256), 0, st, a)
+    if (bmw == 128 && bnw == 128) LO_WG(128, 128);
+    else if (bmw == 128 && bnw == 64) LO_WG(128, 64);
+    else if (bmw == 64 && bnw == 128) LO_WG(64, 128);
+    else LO_WG(64, 64);
 #undef LO_WG
+  }
   LO_LAUNCH_CHECK("wgrad_tn");
   if (a.direct) return LO_OK;
   int total = a.packed_elems;
+  LoProfScope _p2("lo_wgrad_reduce", 0, 4.0 * total * (a.nsplit + 1), st);
   hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
   LO_LAUNCH_CHECK("wgrad_reduce");
   return LO_OK;

@@ -116,14 +116,24 @@ __global__ __launch_bounds__(256) void lo_first_conv_wgrad_kernel(const float* _
   }
 }
 
-// generic deterministic column sum:  out[j] = scale * sum_k partial[k][j]
-__global__ void lo_colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nrow, int ncol,
-                                 int stride, float scale) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncol) return;
+// generic deterministic column sum:  out[j] = scale * sum_k partial[k*stride + j]
+// block = 16 columns x 16 row-lanes; each lane sums rows lane, lane+16, ... then the 16 lane sums are added in order
+__global__ __launch_bounds__(256) void lo_colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nrow,
+                                                        int ncol, int stride, float scale) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
   float t = 0.f;
-  for (int k = 0; k < nrow; ++k) t += partial[(size_t)k * stride + j];
-  out[j] = t * scale;
+  if (j < ncol)
+    for (int k = r; k < nrow; k += 16) t += partial[(size_t)k * stride + j];
+  red[r][c] = t;
+  __syncthreads();
+  if (r == 0 && j < ncol) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][c];
+    out[j] = tot * scale;
+  }
 }
 
 // =============================================================================================
@@ -327,25 +337,28 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
 // launchers
 // =============================================================================================
 int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v, float* gn_partial, int B, hipStream_t st) {
+  LoProfScope _p("lo_first_conv_fwd", 2.0 * B * 4096 * 64 * 27, (double)B * (3 * 16384 * 4 + 4096 * 64 * 2), st);
   hipLaunchKernelGGL(lo_first_conv_fwd_kernel, dim3(64, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
   LO_LAUNCH_CHECK("first_conv_fwd");
   return LO_OK;
 }
 // partial: B*8*1728 floats
 int lo_first_conv_wgrad(const float* x, const f16* dv, float* partial, float* dw, int B, float scale, hipStream_t st) {
+  LoProfScope _p("lo_first_conv_wgrad(+sum)", 2.0 * B * 4096 * 64 * 27, (double)B * (3 * 16384 * 4 + 4096 * 64 * 2), st);
   hipLaunchKernelGGL(lo_first_conv_wgrad_kernel, dim3(8, B), dim3(256), 0, st, x, dv, partial);
   LO_LAUNCH_CHECK("first_conv_wgrad");
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((1728 + 63) / 64), dim3(64), 0, st, partial, dw, B * 8, 1728, 1728, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, dw, B * 8, 1728, 1728, scale);
   LO_LAUNCH_CHECK("first_conv_wgrad_sum");
   return LO_OK;
 }
 int lo_colsum(const float* partial, float* out, int nrow, int ncol, int stride, float scale, hipStream_t st) {
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((ncol + 63) / 64), dim3(64), 0, st, partial, out, nrow, ncol, stride, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((ncol + 15) / 16), dim3(256), 0, st, partial, out, nrow, ncol, stride, scale);
   LO_LAUNCH_CHECK("colsum");
   return LO_OK;
 }
 int lo_final_conv_fwd(const f16* a4, const float* w, const float* bias, const float* target, float* recon,
                       float* mse_partial, int B, hipStream_t st) {
+  LoProfScope _p("lo_final_conv_fwd", 2.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 + 3 * 4 * 2), st);
   hipLaunchKernelGGL(lo_final_conv_fwd_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
   LO_LAUNCH_CHECK("final_conv_fwd");
   return LO_OK;
@@ -355,12 +368,13 @@ int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const f
                       const float* coef, float gscale, f16* da4, float* partial, float* dw, float* db, int B, float scale,
                       hipStream_t st) {
   LcBwdArgs a{a4, w, recon, target, drecon, coef, gscale, da4, partial};
+  LoProfScope _p("lo_final_conv_bwd(+sums)", 4.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 * 2 + 3 * 4 * 2), st);
   hipLaunchKernelGGL(lo_final_conv_bwd_kernel, dim3(8, 8, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("final_conv_bwd");
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 63) / 64), dim3(64), 0, st, partial, dw, B * 64, 864, 867, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * 64, 864, 867, scale);
   LO_LAUNCH_CHECK("final_conv_dw");
   // bias: columns 864..866 of the same partial matrix
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3(1), dim3(64), 0, st, partial + 864, db, B * 64, 3, 867, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3(1), dim3(256), 0, st, partial + 864, db, B * 64, 3, 867, scale);
   LO_LAUNCH_CHECK("final_conv_db");
   return LO_OK;
 }

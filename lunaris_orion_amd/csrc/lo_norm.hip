@@ -81,21 +81,34 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
   }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
-  for (int r = slot; r < rows; r += nslot) {
-    size_t off = base + (size_t)r * C;
-    f16x8 h = *reinterpret_cast<const f16x8*>(a.v + off);
-    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.mode != GN_MODE_PLAIN) o = *reinterpret_cast<const f16x8*>(a.other + off);
-    f16x8 y;
+  constexpr int U = 4;   // rows in flight per thread (memory-level parallelism)
+  for (int r = slot; r < rows; r += U * nslot) {
+    f16x8 h[U], o[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float u = (float)h[j] * sc[j] + sh[j];
-      float m = lo_mish(u);
-      if (a.mode == GN_MODE_SKIP) m += (float)o[j];
-      else if (a.mode == GN_MODE_RES) m = lo_mish(m + (float)o[j]);
-      y[j] = (f16)m;
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < rows) {
+        size_t off = base + (size_t)rr * C;
+        h[u] = *reinterpret_cast<const f16x8*>(a.v + off);
+        if (a.mode != GN_MODE_PLAIN) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
+      }
     }
-    *reinterpret_cast<f16x8*>(a.y + off) = y;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < rows) {
+        f16x8 y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float uu = (float)h[u][j] * sc[j] + sh[j];
+          float m = lo_mish(uu);
+          if (a.mode == GN_MODE_SKIP) m += (float)o[u][j];
+          else if (a.mode == GN_MODE_RES) m = lo_mish(m + (float)o[u][j]);
+          y[j] = (f16)m;
+        }
+        *reinterpret_cast<f16x8*>(a.y + base + (size_t)rr * C) = y;
+      }
+    }
   }
 }
 
@@ -155,22 +168,35 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
   for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
-  for (int r = slot; r < rows; r += nslot) {
-    size_t off = base + (size_t)r * C;
-    f16x8 h = *reinterpret_cast<const f16x8*>(a.v + off);
-    f16x8 d = *reinterpret_cast<const f16x8*>(a.dy + off);
-    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.mode == GN_MODE_RES) o = *reinterpret_cast<const f16x8*>(a.other + off);
-    f16x8 dso;
+  constexpr int U = 4;
+  for (int r = slot; r < rows; r += U * nslot) {
+    f16x8 h[U], d[U], o[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float du, xh, dsv;
-      gn_du(a, (float)h[j], (float)d[j], (float)o[j], sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
-      a1[j] += du;
-      a2[j] += du * xh;
-      dso[j] = (f16)dsv;
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < rows) {
+        size_t off = base + (size_t)rr * C;
+        h[u] = *reinterpret_cast<const f16x8*>(a.v + off);
+        d[u] = *reinterpret_cast<const f16x8*>(a.dy + off);
+        if (a.mode == GN_MODE_RES) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
+      }
     }
-    if (a.mode == GN_MODE_RES) *reinterpret_cast<f16x8*>(a.ds + off) = dso;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < rows) {
+        f16x8 dso;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float du, xh, dsv;
+          gn_du(a, (float)h[u][j], (float)d[u][j], a.mode == GN_MODE_RES ? (float)o[u][j] : 0.f, sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
+          a1[j] += du;
+          a2[j] += du * xh;
+          dso[j] = (f16)dsv;
+        }
+        if (a.mode == GN_MODE_RES) *reinterpret_cast<f16x8*>(a.ds + base + (size_t)rr * C) = dso;
+      }
+    }
   }
   // reduce over the row slots in a fixed order
 #pragma unroll
@@ -231,23 +257,36 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
-  for (int r = slot; r < rows; r += nslot) {
-    size_t off = base + (size_t)r * C;
-    f16x8 h = *reinterpret_cast<const f16x8*>(a.v + off);
-    f16x8 d = *reinterpret_cast<const f16x8*>(a.dy + off);
-    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.mode == GN_MODE_RES) o = *reinterpret_cast<const f16x8*>(a.other + off);
-    f16x8 out;
+  constexpr int U = 4;
+  for (int r = slot; r < rows; r += U * nslot) {
+    f16x8 h[U], d[U], o[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float du, xh, dsv;
-      gn_du(a, (float)h[j], (float)d[j], (float)o[j], sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
-      float dv = rstd[j] * (gm[j] * du - k1[j] - xh * k2[j]);
-      f16 dvh = (f16)dv;
-      out[j] = dvh;
-      acc[j] += (float)dvh;   // bias gradient = sum of the values the weight-gradient GEMM will also see
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < rows) {
+        size_t off = base + (size_t)rr * C;
+        h[u] = *reinterpret_cast<const f16x8*>(a.v + off);
+        d[u] = *reinterpret_cast<const f16x8*>(a.dy + off);
+        if (a.mode == GN_MODE_RES) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
+      }
     }
-    *reinterpret_cast<f16x8*>(a.dv + off) = out;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < rows) {
+        f16x8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float du, xh, dsv;
+          gn_du(a, (float)h[u][j], (float)d[u][j], a.mode == GN_MODE_RES ? (float)o[u][j] : 0.f, sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
+          float dv = rstd[j] * (gm[j] * du - k1[j] - xh * k2[j]);
+          f16 dvh = (f16)dv;
+          out[j] = dvh;
+          acc[j] += (float)dvh;   // bias gradient = sum of the values the weight-gradient GEMM will also see
+        }
+        *reinterpret_cast<f16x8*>(a.dv + base + (size_t)rr * C) = out;
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[j];
@@ -260,20 +299,30 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
   }
 }
 
-// dgamma, dbeta, dbias from the partials (fixed summation order)
-__global__ void lo_gn_param_finalize_kernel(const float* __restrict__ P1, const float* __restrict__ P2, float* dgamma,
-                                            float* dbeta, float* dbias, int nblk, int C, float scale) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma, dbeta, dbias from the partials (fixed summation order): block = 16 channels x 16 row-lanes
+__global__ __launch_bounds__(256) void lo_gn_param_finalize_kernel(const float* __restrict__ P1, const float* __restrict__ P2,
+                                                                   float* dgamma, float* dbeta, float* dbias, int nblk, int C,
+                                                                   float scale) {
+  __shared__ float red[3][16][17];
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float g1 = 0.f, g2 = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    g1 += P1[((size_t)k * C + c) * 2];
-    g2 += P1[((size_t)k * C + c) * 2 + 1];
-    b += P2[(size_t)k * C + c];
+  if (c < C)
+    for (int k = r; k < nblk; k += 16) {
+      f32x2 p = *reinterpret_cast<const f32x2*>(P1 + ((size_t)k * C + c) * 2);
+      g1 += p[0];
+      g2 += p[1];
+      b += P2[(size_t)k * C + c];
+    }
+  red[0][r][cl] = g1; red[1][r][cl] = g2; red[2][r][cl] = b;
+  __syncthreads();
+  if (r < 3 && c < C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[r][q][cl];
+    tot *= scale;
+    if (r == 0) dbeta[c] = tot; else if (r == 1) dgamma[c] = tot; else dbias[c] = tot;
   }
-  dbeta[c] = g1 * scale;
-  dgamma[c] = g2 * scale;
-  dbias[c] = b * scale;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,6 +353,7 @@ int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, co
               f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_fwd: C=%d unsupported", C);
   GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode};
+  LoProfScope _p("lo_gn_fwd", 0, 2.0 * B * HW * C * (mode ? 3 : 2), st);
   hipLaunchKernelGGL(lo_gn_fwd_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("gn_fwd");
   return LO_OK;
@@ -314,11 +364,18 @@ int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats,
               int mode, float scale, hipStream_t st) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_bwd: C=%d unsupported", C);
   GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, lo_gn_nchunk(HW, C), mode};
-  hipLaunchKernelGGL(lo_gn_bwd_reduce_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  {
+    LoProfScope _p("lo_gn_bwd_reduce", 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 2), st);
+    hipLaunchKernelGGL(lo_gn_bwd_reduce_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  }
   LO_LAUNCH_CHECK("gn_bwd_reduce");
-  hipLaunchKernelGGL(lo_gn_bwd_apply_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  {
+    LoProfScope _p("lo_gn_bwd_apply", 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 3), st);
+    hipLaunchKernelGGL(lo_gn_bwd_apply_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  }
   LO_LAUNCH_CHECK("gn_bwd_apply");
-  hipLaunchKernelGGL(lo_gn_param_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, P1, P2, dgamma, dbeta, dbias,
+  LoProfScope _p3("lo_gn_param_finalize", 0, 0, st);
+  hipLaunchKernelGGL(lo_gn_param_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, P1, P2, dgamma, dbeta, dbias,
                      B * a.nchunk, C, scale);
   LO_LAUNCH_CHECK("gn_param_finalize");
   return LO_OK;
@@ -326,12 +383,14 @@ int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats,
 
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
   int total = B * HW * C;
+  LoProfScope _p("lo_layout_transpose", 0, 4.0 * total, st);
   hipLaunchKernelGGL(lo_nhwc_to_nchw_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, HW, C, total);
   LO_LAUNCH_CHECK("nhwc_to_nchw");
   return LO_OK;
 }
 int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
   int total = B * HW * C;
+  LoProfScope _p("lo_layout_transpose", 0, 4.0 * total, st);
   hipLaunchKernelGGL(lo_nchw_to_nhwc_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, HW, C, total);
   LO_LAUNCH_CHECK("nchw_to_nhwc");
   return LO_OK;

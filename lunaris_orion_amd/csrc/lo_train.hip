@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
 int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, uint64_t seed, float* mu, float* logvar,
                    f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st) {
   int nb = (B * L + 255) / 256;
+  LoProfScope _p("lo_head_reduce", 0, 4.0 * B * 2 * L * (nsplit + 2), st);
   hipLaunchKernelGGL(lo_head_reduce_kernel, dim3(nb), dim3(256), 0, st, slab, bias, eps_in, seed, mu, logvar, z, eps_out,
                      kl_partial, B, L, nsplit);
   LO_LAUNCH_CHECK("head_reduce");
@@ -250,6 +251,7 @@ int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, ui
 int lo_loss_finalize(const float* mse_partial, int n_mse, const float* kl_partial, int n_kl, float rw, float kw, float adv,
                      const float* adv_dev, float accum, float ls, float* losses, float* coefs, float n_rec, float n_lat,
                      hipStream_t st) {
+  LoProfScope _p("lo_loss_finalize", 0, 0, st);
   hipLaunchKernelGGL(lo_loss_finalize_kernel, dim3(1), dim3(256), 0, st, mse_partial, n_mse, kl_partial, n_kl, rw, kw, adv,
                      accum, ls, adv_dev, losses, coefs, n_rec, n_lat);
   LO_LAUNCH_CHECK("loss_finalize");
@@ -258,12 +260,14 @@ int lo_loss_finalize(const float* mse_partial, int n_mse, const float* kl_partia
 int lo_latent_bwd(const f16* dz, const float* mu, const float* logvar, const float* eps, const float* coefs,
                   const float* gmu, const float* glv, float gscale, f16* dml, int B, int L, hipStream_t st) {
   int n = B * L;
+  LoProfScope _p("lo_latent_bwd", 0, 0, st);
   hipLaunchKernelGGL(lo_latent_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dz, mu, logvar, eps, coefs, gmu, glv,
                      gscale, dml, B, L);
   LO_LAUNCH_CHECK("latent_bwd");
   return LO_OK;
 }
 int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream_t st) {
+  LoProfScope _p("lo_colsum_f16", 0, 2.0 * M * N, st);
   hipLaunchKernelGGL(lo_colsum_f16_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, out, M, N, scale);
   LO_LAUNCH_CHECK("colsum_f16");
   return LO_OK;
@@ -272,17 +276,20 @@ int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st) {
   LO_REQUIRE(n % 4 == 0, "lo_cast_f32_f16: n must be a multiple of 4");
   size_t n4 = n / 4;
   int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  LoProfScope _p("lo_cast_f32_f16", 0, 6.0 * n, st);
   hipLaunchKernelGGL(lo_cast_f32_f16_kernel, dim3(nb), dim3(256), 0, st, src, dst, n4);
   LO_LAUNCH_CHECK("cast");
   return LO_OK;
 }
 int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st) {
+  LoProfScope _p("lo_transpose_cast", 0, 6.0 * R * C, st);
   hipLaunchKernelGGL(lo_transpose_cast_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, dst, R, C);
   LO_LAUNCH_CHECK("transpose_cast");
   return LO_OK;
 }
 #define LO_NORM_BLOCKS 1024
 int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial /*>=1024*/, float* norm_out, hipStream_t st) {
+  LoProfScope _p("lo_gradnorm", 0, 4.0 * n, st);
   hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS), dim3(256), 0, st, g, n, partial);
   LO_LAUNCH_CHECK("sumsq");
   hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out);
@@ -295,6 +302,7 @@ int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float
   float bc2 = 1.0f - powf(beta2, (float)step);
   double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
   (void)bc1; (void)bc2;
+  LoProfScope _p("lo_adamw", 0, 28.0 * n, st);
   hipLaunchKernelGGL(lo_adamw_kernel, dim3(2048), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
                      (float)bc1d, (float)sqrt(bc2d));
   LO_LAUNCH_CHECK("adamw");

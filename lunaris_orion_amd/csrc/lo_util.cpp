@@ -11,3 +11,45 @@ int lo_check_hip(hipError_t e, const char* what) {
   lo_set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
   return LO_ERR_HIP;
 }
+
+// ---- HIP-event profiler -------------------------------------------------------------------------
+#include <string>
+#include <vector>
+bool g_lo_prof_on = false;
+namespace {
+struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_used = 0;
+hipEvent_t take_event() {
+  if (g_pool_used == g_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_pool.push_back(e);
+  }
+  return g_pool[g_pool_used++];
+}
+}  // namespace
+void lo_prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
+  Rec r{name, flops, bytes, take_event(), take_event()};
+  if (r.e0) (void)hipEventRecord(r.e0, st);
+  g_recs.push_back(r);
+}
+void lo_prof_end(hipStream_t st) {
+  if (!g_recs.empty() && g_recs.back().e1) (void)hipEventRecord(g_recs.back().e1, st);
+}
+extern "C" void lo_prof_enable(int on) {
+  g_lo_prof_on = on != 0;
+  if (on) { g_recs.clear(); g_pool_used = 0; }
+}
+extern "C" int lo_prof_count(void) { return (int)g_recs.size(); }
+// call after the stream has been synchronised
+extern "C" int lo_prof_get(int i, char* name, int name_cap, double* ms, double* flops, double* bytes) {
+  if (i < 0 || i >= (int)g_recs.size()) return LO_ERR_ARG;
+  const Rec& r = g_recs[i];
+  float t = 0.f;
+  if (!r.e0 || !r.e1 || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = -1.f;
+  snprintf(name, name_cap, "%s", r.name);
+  *ms = t; *flops = r.flops; *bytes = r.bytes;
+  return LO_OK;
+}

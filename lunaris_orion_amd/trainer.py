@@ -17,7 +17,7 @@ The teacher's contribution is the detached scalar ``mean_advantage`` (SURVEY §3
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 
@@ -37,7 +37,8 @@ def cosine_warm_restarts_lr(base_lr: float, eta_min: float, t0: int, t_mult: int
 class VAEStepper:
     def __init__(self, vae: LunarisCoreVAE, lr: float = 1e-4, min_lr: float = 1e-6, scheduler_t0: int = 10,
                  weight_decay: float = 0.01, max_grad_norm: float = 1.0, recon_weight: float = 1.0, kl_weight: float = 0.1,
-                 gradient_accumulation_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8):
+                 gradient_accumulation_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8,
+                 grad_sync: Optional[Callable[[torch.Tensor], None]] = None):
         _lib.require_gpu()
         self.vae = vae
         self.base_lr, self.min_lr, self.t0 = lr, min_lr, scheduler_t0
@@ -45,6 +46,7 @@ class VAEStepper:
         self.recon_weight, self.kl_weight = recon_weight, kl_weight
         self.accum = max(1, int(gradient_accumulation_steps))
         self.betas, self.eps = betas, eps
+        self.grad_sync = grad_sync      # data parallel: averages the flat gradient buffer across ranks (RCCL)
         flat = vae.flat_parameters()
         self.grads = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
@@ -73,6 +75,8 @@ class VAEStepper:
             _lib.check(_lib.lib.lo_vae_backward(eng.handle, images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
                                                 images.data_ptr(), 1, None, None, None, float(vae.loss_scale),
                                                 self.grads.data_ptr(), st), "lo_vae_backward")
+            if self.grad_sync is not None:
+                self.grad_sync(self.grads)
             lr = self.lr
             self.opt_steps += 1
             _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
