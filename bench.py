@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-fp16", action="store_true", help="fp16 wire format for the gradient all-reduce (off: fp32)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
 
@@ -112,8 +113,8 @@ def main():
     model = LunarisCoreVAE(latent_dim=args.latent).to("cuda")
     grad_sync = None
     if world > 1:
-        def grad_sync(flat_grads):
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.AVG)
+        from lunaris_orion_amd.parallel import FlatGradSync
+        grad_sync = FlatGradSync(compress_fp16=args.dp_fp16)
     st = VAEStepper(model, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
                     kl_weight=0.1, gradient_accumulation_steps=1, grad_sync=grad_sync)
     B = args.batch

@@ -106,6 +106,7 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_wp_f, o_wp_d;     // workspace offsets: packed fp16 weights (fwd, dgrad)
   size_t o_v, o_a;           // raw conv output, activation after GN+Mish(+...)
   size_t o_part, o_stats;    // GN partial sums, saved stats
+  size_t o_P1, o_P2;         // GN backward partial sums (kept until the fused finalize at the end of backward)
   int MT;
 };
 
@@ -138,6 +139,11 @@ struct LoVae {
   size_t o_msep, o_losses, o_coefs;
   // backward scratch
   size_t o_G[4], o_skipg[3], o_P1, o_P2, o_wslab, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
+  size_t o_packjobs;
+  std::vector<LoPackJob> packjobs_host;   // kept alive: source of the asynchronous table upload
+  int n_packjobs, pack_blocks;
+  const void* packjobs_for_ws;     // workspace / parameter pointers the uploaded job table was built for
+  const void* packjobs_for_params;
   size_t ws_bytes;
   int idx_fc_mu_w, idx_fc_mu_b, idx_fc_lv_w, idx_fc_lv_b, idx_dfc_w, idx_dfc_b, idx_final_w, idx_final_b;
   bool forward_done, loss_done;
@@ -165,6 +171,9 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   c.o_a = ar.take(act);
   c.o_part = ar.take((size_t)B * c.MT * 16 * 4);
   c.o_stats = ar.take((size_t)B * 16 * 4);
+  int nchunk = lo_gn_nchunk(c.Ho * c.Wo, Cout);
+  c.o_P1 = ar.take((size_t)B * nchunk * Cout * 2 * 4);
+  c.o_P2 = ar.take((size_t)B * nchunk * Cout * 4);
   return LO_OK;
 }
 
@@ -283,6 +292,8 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
   h->o_dz = ar.take((size_t)B * L * 2);
   h->o_dml = ar.take((size_t)B * 2 * L * 2);
   h->o_slab_dz = ar.take((size_t)h->dfcd_split * B * L * 4);
+  h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
+  h->packjobs_for_ws = h->packjobs_for_params = nullptr;
   h->ws_bytes = ar.off;
   *out = h;
   return LO_OK;
@@ -302,18 +313,35 @@ extern "C" size_t lo_vae_workspace_bytes(const LoVae* h) { return h->ws_bytes; }
 extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
   LO_REQUIRE(h && P && ws, "lo_vae_pack: null argument");
   hipStream_t st = S(stream);
-  for (int s = 0; s < 4; ++s)
-    for (int k = 0; k < 3; ++k) {
-      if (s == 0 && k == 0) continue;
-      ConvLayer& c = h->enc[s][k];
-      LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_f), c.gf, st));
-      LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_d), c.gd, st));
+  if (h->packjobs_for_ws != ws || h->packjobs_for_params != (const void*)P) {
+    // (re)build the job table of the fused pack launch and upload it into the workspace
+    std::vector<LoPackJob>& jobs = h->packjobs_host;
+    jobs.clear();
+    int blocks = 0;
+    auto add = [&](ConvLayer& c, const LoGeom& g, size_t o_dst) {
+      LoPackJob j;
+      j.src = PRM(c.p_w); j.dst = WSP(f16, o_dst); j.total = (int)lo_packed_weight_elems(g); j.block0 = blocks; j.g = g;
+      blocks += (j.total + 255) / 256;
+      jobs.push_back(j);
+    };
+    for (int s = 0; s < 4; ++s)
+      for (int k = 0; k < 3; ++k) {
+        if (s == 0 && k == 0) continue;
+        add(h->enc[s][k], h->enc[s][k].gf, h->enc[s][k].o_wp_f);
+        add(h->enc[s][k], h->enc[s][k].gd, h->enc[s][k].o_wp_d);
+      }
+    for (int s = 0; s < 4; ++s) {
+      add(h->dec[s], h->dec[s].gf, h->dec[s].o_wp_f);
+      add(h->dec[s], h->dec[s].gd, h->dec[s].o_wp_d);
     }
-  for (int s = 0; s < 4; ++s) {
-    ConvLayer& c = h->dec[s];
-    LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_f), c.gf, st));
-    LO_TRY(lo_pack_weight(PRM(c.p_w), WSP(f16, c.o_wp_d), c.gd, st));
+    LO_REQUIRE(jobs.size() <= 64, "too many pack jobs");
+    LO_HIP(hipMemcpyAsync(WSP(void, h->o_packjobs), jobs.data(), jobs.size() * sizeof(LoPackJob), hipMemcpyHostToDevice, st));
+    h->n_packjobs = (int)jobs.size();
+    h->pack_blocks = blocks;
+    h->packjobs_for_ws = ws;
+    h->packjobs_for_params = (const void*)P;
   }
+  LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, st));
   const int L = h->L;
   // encoder head: [fc_mu.weight ; fc_logvar.weight] is one contiguous [2L][32768] fp32 matrix in the flat buffer
   LO_REQUIRE(h->p_off[h->idx_fc_lv_w] == h->p_off[h->idx_fc_mu_w] + (size_t)L * 32768, "flat layout: head weights not adjacent");
@@ -400,8 +428,8 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
 static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, int mode, const f16* layer_in, f16* ds,
                        f16* dv, f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale,
                        hipStream_t st) {
-  LO_TRY(lo_gn_bwd(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv, WSP(float, h->o_P1),
-                   WSP(float, h->o_P2), GRD(c.p_gw), GRD(c.p_gb), GRD(c.p_b), h->B, c.Ho * c.Wo, c.Cout, mode, inv_scale, st));
+  LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
+                           WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st));
   LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st));
   if (din) LO_TRY(lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st));
   return LO_OK;
@@ -475,10 +503,26 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
       LO_TRY(conv_gn_bwd(h, c0, Gd, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Gc, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
                          ws, inv, st));
     } else {
-      LO_TRY(lo_gn_bwd(Gd, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gc,
-                       WSP(float, h->o_P1), WSP(float, h->o_P2), GRD(c0.p_gw), GRD(c0.p_gb), GRD(c0.p_b), B, 64 * 64, 64, 0, inv, st));
+      LO_TRY(lo_gn_bwd_nofinal(Gd, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gc,
+                               WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st));
       LO_TRY(lo_first_conv_wgrad(x, Gc, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
+  }
+  // ---- GroupNorm affine + conv bias gradients of all 16 layers in one launch
+  {
+    LoGnFinJobs jobs;
+    jobs.n = 0;
+    int blocks = 0;
+    auto add = [&](ConvLayer& c) {
+      LoGnFinJob& j = jobs.j[jobs.n++];
+      j.P1 = WSP(float, c.o_P1); j.P2 = WSP(float, c.o_P2);
+      j.dgamma = GRD(c.p_gw); j.dbeta = GRD(c.p_gb); j.dbias = GRD(c.p_b);
+      j.nblk = B * lo_gn_nchunk(c.Ho * c.Wo, c.Cout); j.C = c.Cout; j.block0 = blocks;
+      blocks += (c.Cout + 15) / 16;
+    };
+    for (int s = 0; s < 4; ++s) for (int k = 0; k < 3; ++k) add(h->enc[s][k]);
+    for (int s = 0; s < 4; ++s) add(h->dec[s]);
+    LO_TRY(lo_gn_finalize_all(jobs, inv, st));
   }
   return LO_OK;
 }

@@ -87,6 +87,14 @@ struct LoGeom {
   int sn, sc;
 };
 
+struct LoPackJob {
+  const float* src;   // canonical fp32 weight
+  f16* dst;           // packed fp16 operand
+  int total;          // packed elements
+  int block0;         // first block of this job in the fused launch
+  LoGeom g;
+};
+
 enum LoConvKind {
   LO_CONV3_S1 = 0,        // Conv2d k3 s1 p1 forward
   LO_CONV3_S2 = 1,        // Conv2d k3 s2 p1 forward

@@ -125,6 +125,25 @@ __global__ void lo_pack_weight_kernel(const float* __restrict__ w, f16* __restri
   wp[i] = (f16)w[(size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t]];
 }
 
+// all packs of a model in ONE launch: jobs live in device memory (uploaded once per workspace by the executor)
+__global__ __launch_bounds__(256) void lo_pack_all_kernel(const LoPackJob* __restrict__ jobs, int njobs) {
+  // blockIdx.x -> job by linear search over the (<= 64) block prefix sums
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
+  const LoPackJob& J = jobs[j];
+  int i = ((int)blockIdx.x - J.block0) * 256 + threadIdx.x;
+  if (i >= J.total) return;
+  const LoGeom& g = J.g;
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < LO_MAX_PHASE; ++q) if (q < g.n_phase && i >= g.wofs[q]) p = q;
+  int jj = i - g.wofs[p];
+  int K = g.T[p] * g.Cin;
+  int n = jj / K, k = jj - n * K;
+  int t = k / g.Cin, c = k - t * g.Cin;
+  J.dst[i] = (f16)J.src[(size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t]];
+}
+
 // ---------------------------------------------------------------------------------------------
 // NT implicit GEMM
 // ---------------------------------------------------------------------------------------------
@@ -633,6 +652,13 @@ __global__ void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st) {
+  LoProfScope _p("lo_pack_all", 0, 0, st);
+  hipLaunchKernelGGL(lo_pack_all_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  LO_LAUNCH_CHECK("pack_all");
+  return LO_OK;
+}
+
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st) {
   int total = geom_packed_elems(g);
   LoProfScope _p("lo_pack_weight", 0, 6.0 * total, st);

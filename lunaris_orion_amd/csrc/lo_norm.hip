@@ -6,7 +6,7 @@
 // Reference ops replaced: nn.GroupNorm(8, C) + nn.Mish (lunar_generate.py:37-38,42-43,96-97,103-104,110-111,
 // 117-118,170-171,176-177,182-183,188-189), the ResBlock tail mish(out + identity) (:49-53) and the decoder
 // skip additions (:212-222).
-#include "lo_common.h"
+#include "lo_internal.h"
 
 #define GN_EPS 1e-5f
 
@@ -325,6 +325,34 @@ __global__ __launch_bounds__(256) void lo_gn_param_finalize_kernel(const float* 
   }
 }
 
+// the same for every GroupNorm layer of the model in ONE launch (jobs in the kernel argument)
+__global__ __launch_bounds__(256) void lo_gn_finalize_all_kernel(LoGnFinJobs jobs, float scale) {
+  __shared__ float red[3][16][17];
+  int jb = 0;
+  while (jb + 1 < jobs.n && (int)blockIdx.x >= jobs.j[jb + 1].block0) ++jb;
+  const LoGnFinJob& J = jobs.j[jb];
+  const int C = J.C, nblk = J.nblk;
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = ((int)blockIdx.x - J.block0) * 16 + cl;
+  float g1 = 0.f, g2 = 0.f, b = 0.f;
+  if (c < C)
+    for (int k = r; k < nblk; k += 16) {
+      f32x2 p = *reinterpret_cast<const f32x2*>(J.P1 + ((size_t)k * C + c) * 2);
+      g1 += p[0];
+      g2 += p[1];
+      b += J.P2[(size_t)k * C + c];
+    }
+  red[0][r][cl] = g1; red[1][r][cl] = g2; red[2][r][cl] = b;
+  __syncthreads();
+  if (r < 3 && c < C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[r][q][cl];
+    tot *= scale;
+    if (r == 0) J.dbeta[c] = tot; else if (r == 1) J.dgamma[c] = tot; else J.dbias[c] = tot;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // small layout helpers
 // ---------------------------------------------------------------------------------------------
@@ -359,9 +387,8 @@ int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, co
   return LO_OK;
 }
 
-int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
-              f16* ds, f16* dv, float* P1, float* P2, float* dgamma, float* dbeta, float* dbias, int B, int HW, int C,
-              int mode, float scale, hipStream_t st) {
+int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
+                      f16* ds, f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_bwd: C=%d unsupported", C);
   GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, lo_gn_nchunk(HW, C), mode};
   {
@@ -374,10 +401,27 @@ int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats,
     hipLaunchKernelGGL(lo_gn_bwd_apply_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
   }
   LO_LAUNCH_CHECK("gn_bwd_apply");
+  return LO_OK;
+}
+
+int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
+              f16* ds, f16* dv, float* P1, float* P2, float* dgamma, float* dbeta, float* dbias, int B, int HW, int C,
+              int mode, float scale, hipStream_t st) {
+  int r = lo_gn_bwd_nofinal(dy, v, other, stats, gamma, beta, ds, dv, P1, P2, B, HW, C, mode, st);
+  if (r != LO_OK) return r;
   LoProfScope _p3("lo_gn_param_finalize", 0, 0, st);
   hipLaunchKernelGGL(lo_gn_param_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, P1, P2, dgamma, dbeta, dbias,
-                     B * a.nchunk, C, scale);
+                     B * lo_gn_nchunk(HW, C), C, scale);
   LO_LAUNCH_CHECK("gn_param_finalize");
+  return LO_OK;
+}
+
+int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st) {
+  int nblocks = 0;
+  for (int i = 0; i < jobs.n; ++i) nblocks += (jobs.j[i].C + 15) / 16;
+  LoProfScope _p("lo_gn_finalize_all", 0, 0, st);
+  hipLaunchKernelGGL(lo_gn_finalize_all_kernel, dim3(nblocks), dim3(256), 0, st, jobs, scale);
+  LO_LAUNCH_CHECK("gn_finalize_all");
   return LO_OK;
 }
 

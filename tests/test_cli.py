@@ -1,0 +1,66 @@
+"""CLI contract: the 35 reference flags with the reference defaults (train_hybrid.py:1076-1133); a small end-to-end
+run on synthetic sprites on the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REFERENCE_DEFAULTS = {
+    "output_dir": "output", "resume_from": None, "batch_size": 16, "gradient_accumulation_steps": 2, "chunk_size": 32,
+    "num_epochs": 100, "num_workers": 4, "seed": 42, "compile": False, "mixed_precision": False, "latent_dim": 256,
+    "embedding_dim": 64, "feature_dim": 128, "num_experts": 4, "vae_lr": 1e-4, "teacher_lr": 1e-4, "min_lr": 1e-6,
+    "weight_decay": 0.01, "max_grad_norm": 1.0, "scheduler_t0": 10, "recon_weight": 1.0, "kl_weight": 0.1,
+    "quality_weight": 0.5, "log_every": 100, "save_every": 1000, "sample_every": 500, "keep_n_checkpoints": 5,
+    "early_stopping_patience": 7, "eval_save_freq": 500, "reward_scale": 0.1, "semantic_weight": 0.5,
+    "baseline_momentum": 0.9, "force_cpu": False, "memory_efficient": False,
+}
+
+
+def test_cli_flags_and_defaults_match_reference():
+    sys.path.insert(0, ROOT)
+    import train_hybrid
+    args = train_hybrid.build_parser().parse_args(["--data_dir", "x"])
+    for k, v in REFERENCE_DEFAULTS.items():
+        assert getattr(args, k) == v, k
+    assert len(REFERENCE_DEFAULTS) + 1 == 35      # + data_dir
+
+
+def test_teacher_on_is_refused_loudly(tmp_path):
+    sys.path.insert(0, ROOT)
+    import train_hybrid
+    with pytest.raises(SystemExit) as e:
+        train_hybrid.main(["--data_dir", str(tmp_path)])
+    assert "teacher" in str(e.value).lower()
+
+
+def _make_data(d, n=24):
+    rng = np.random.default_rng(0)
+    np.save(os.path.join(d, "sprites_000.npy"), rng.integers(0, 256, (n, 128, 128, 3), dtype=np.uint8))
+    with open(os.path.join(d, "labels_000.csv"), "w") as f:
+        f.write("filename,category,prompt,seed,pixel_size,guidance_scale,pag_scale,num_steps\n")
+        for i in range(n):
+            f.write(f"s{i}.png,cat,prompt {i},{i},4,5.0,2.0,20\n")
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_on_gpu(tmp_path):
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_data(str(data))
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
+                        "--vae_only", "--batch_size", "4", "--gradient_accumulation_steps", "1", "--num_epochs", "2",
+                        "--log_every", "1", "--latent_dim", "256"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = (out / "training.log").read_text()
+    assert "Average Loss" in log and "nan" not in log.split("Average Loss")[1][:12]
+    assert (out / "checkpoints" / "latest.pt").exists()
+    import torch
+    ck = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
+    assert set(ck.keys()) >= {"global_step", "vae_state_dict", "teacher_state_dict", "vae_optimizer", "teacher_optimizer",
+                              "vae_scheduler", "teacher_scheduler", "best_loss", "args"}
+    assert len(ck["vae_state_dict"]) == 72

@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""`train_hybrid.py` for the MI355X-native build: the reference CLI (same 35 flags, same defaults:
+/root/reference/train_hybrid.py:1076-1133) driving the native VAE step (lunaris_orion_amd.trainer.VAEStepper).
+
+What is the same: flags/defaults (the five dead flags are accepted and ignored like in the reference), seeds
+(:1138-1141), the dataset contract (`sprites*.npy` uint8 (N,128,128,3) + `labels*.csv`, :100-201), 90/10 split with
+drop_last (:551-569), the step semantics of `_process_batch` (:838-954) including its accumulation rule, the 12 metric
+names (:929-942), the checkpoint dictionary keys (:596-606), SIGINT -> checkpoint (:587-592).
+
+What differs, deliberately: the teacher (`LunarMoETeacher`) forward is not built in this round, so the run must be
+VAE-only — pass `--reward_scale 0 --quality_weight 0` (or `--vae_only`); with those values the reference's VAE
+update is exactly what runs here and the teacher-only metrics are reported as 0.  The reference's
+defects are not inherited: no tensorboard hard dependency, no DataLoader timeout assertion, per-epoch average
+loss is a real number, checkpoints are written.  Launch one process per GPU with torch.distributed.run for DP.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import logging
+import os
+import signal
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Hybrid Training for Lunaris: Generator and Evaluator (MI355X-native VAE path)")
+    p.add_argument("--data_dir", type=str, required=True)
+    p.add_argument("--output_dir", type=str, default="output")
+    p.add_argument("--resume_from", type=str)
+    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--gradient_accumulation_steps", type=int, default=2)
+    p.add_argument("--chunk_size", type=int, default=32)                 # dead in the reference
+    p.add_argument("--num_epochs", type=int, default=100)
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--compile", action="store_true")                     # no tracing compiler here: accepted, ignored
+    p.add_argument("--mixed_precision", action="store_true")             # the native path always runs fp16 MFMA / fp32 accumulate
+    p.add_argument("--latent_dim", type=int, default=256)
+    p.add_argument("--embedding_dim", type=int, default=64)
+    p.add_argument("--feature_dim", type=int, default=128)
+    p.add_argument("--num_experts", type=int, default=4)
+    p.add_argument("--vae_lr", type=float, default=1e-4)
+    p.add_argument("--teacher_lr", type=float, default=1e-4)
+    p.add_argument("--min_lr", type=float, default=1e-6)
+    p.add_argument("--weight_decay", type=float, default=0.01)
+    p.add_argument("--max_grad_norm", type=float, default=1.0)
+    p.add_argument("--scheduler_t0", type=int, default=10)
+    p.add_argument("--recon_weight", type=float, default=1.0)
+    p.add_argument("--kl_weight", type=float, default=0.1)
+    p.add_argument("--quality_weight", type=float, default=0.5)
+    p.add_argument("--log_every", type=int, default=100)
+    p.add_argument("--save_every", type=int, default=1000)               # dead in the reference
+    p.add_argument("--sample_every", type=int, default=500)              # dead in the reference
+    p.add_argument("--keep_n_checkpoints", type=int, default=5)          # dead in the reference
+    p.add_argument("--early_stopping_patience", type=int, default=7)
+    p.add_argument("--eval_save_freq", type=int, default=500)
+    p.add_argument("--reward_scale", type=float, default=0.1)
+    p.add_argument("--semantic_weight", type=float, default=0.5)
+    p.add_argument("--baseline_momentum", type=float, default=0.9)
+    p.add_argument("--force_cpu", action="store_true")
+    p.add_argument("--memory_efficient", action="store_true")            # dead in the reference
+    # additions of this build (defaults keep the reference behaviour)
+    p.add_argument("--vae_only", action="store_true", help="shorthand for --reward_scale 0 --quality_weight 0")
+    p.add_argument("--max_steps", type=int, default=0, help="stop after this many micro-batches (0 = no limit)")
+    return p
+
+
+class SpriteShards:
+    """sprites*.npy (uint8 [N,128,128,3], memory-mapped) + labels*.csv; only the images feed the step (train_hybrid.py:995)."""
+
+    def __init__(self, data_dir: str):
+        files = sorted(glob.glob(os.path.join(data_dir, "sprites*.npy")))
+        labels = sorted(glob.glob(os.path.join(data_dir, "labels*.csv")))
+        if not files or not labels:
+            raise ValueError(f"No sprites or labels files found in {data_dir}")
+        self.shards = [np.load(f, mmap_mode="r") for f in files]
+        for f, s in zip(files, self.shards):
+            if s.shape[1:] != (128, 128, 3):
+                raise ValueError(f"Expected 128x128x3 images in {f}, got {s.shape[1:]}")
+        self.cum = np.cumsum([0] + [len(s) for s in self.shards])
+        n_rows = 0
+        for lf in labels:
+            with open(lf, "rb") as fh:
+                n_rows += max(0, sum(1 for _ in fh) - 1)
+        if n_rows != len(self):
+            raise AssertionError(f"Mismatch between total sprites ({len(self)}) and labels ({n_rows})")
+
+    def __len__(self):
+        return int(self.cum[-1])
+
+    def batch_u8(self, idx: np.ndarray) -> torch.Tensor:
+        out = np.empty((len(idx), 128, 128, 3), dtype=np.uint8)
+        for j, i in enumerate(idx):
+            f = int(np.searchsorted(self.cum, i, side="right") - 1)
+            out[j] = self.shards[f][i - self.cum[f]]
+        return torch.from_numpy(out)
+
+
+def normalise_on_device(u8_hwc: torch.Tensor, device) -> torch.Tensor:
+    """train_hybrid.py:181-182 on the GPU: uint8 HWC -> float32/127.5 - 1, CHW."""
+    return (u8_hwc.to(device, non_blocking=True).float() / 127.5 - 1.0).permute(0, 3, 1, 2).contiguous()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.vae_only:
+        args.reward_scale, args.quality_weight = 0.0, 0.0
+    if args.force_cpu:
+        raise SystemExit("--force_cpu: this build has no CPU path (the CPU oracle under oracle/ is test infrastructure only)")
+    if args.reward_scale != 0.0 or args.quality_weight != 0.0:
+        raise SystemExit("The LunarMoETeacher forward is not built in this round: run VAE-only with "
+                         "--reward_scale 0 --quality_weight 0 (or --vae_only). With those values the VAE update equals the reference's.")
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    torch.cuda.manual_seed_all(args.seed)
+
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    grad_sync = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        from lunaris_orion_amd.parallel import FlatGradSync
+        grad_sync = FlatGradSync()
+
+    out_dir = Path(args.output_dir)
+    (out_dir / "checkpoints").mkdir(parents=True, exist_ok=True)
+    (out_dir / "eval_samples").mkdir(exist_ok=True)
+    log = logging.getLogger("TrainHybrid")
+    log.setLevel(logging.DEBUG)
+    if rank == 0 and not log.handlers:
+        fh = logging.FileHandler(out_dir / "training.log")
+        fh.setLevel(logging.DEBUG)
+        ch = logging.StreamHandler()
+        ch.setLevel(logging.INFO)
+        for h in (fh, ch):
+            h.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
+            log.addHandler(h)
+    writer = None
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        writer = SummaryWriter(log_dir=str(out_dir / "tensorboard")) if rank == 0 else None
+    except Exception:
+        log.info("tensorboard not installed: scalar logging goes to training.log only")
+
+    from lunaris_orion_amd.trainer import VAEStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    vae = LunarisCoreVAE(latent_dim=args.latent_dim).to("cuda")
+    stepper = VAEStepper(vae, lr=args.vae_lr, min_lr=args.min_lr, scheduler_t0=args.scheduler_t0, weight_decay=args.weight_decay,
+                         max_grad_norm=args.max_grad_norm, recon_weight=args.recon_weight, kl_weight=args.kl_weight,
+                         gradient_accumulation_steps=args.gradient_accumulation_steps, grad_sync=grad_sync)
+    log.info(f"VAE Parameters - Total: {sum(p.numel() for p in vae.parameters()):,}")
+    global_step, best_loss = 0, float("inf")
+
+    def save_checkpoint(tag="latest"):
+        if rank != 0:
+            return
+        torch.cuda.synchronize()
+        ckpt = {"global_step": global_step, "vae_state_dict": {k: v.detach().cpu() for k, v in vae.state_dict().items()},
+                "teacher_state_dict": {}, "vae_optimizer": {"exp_avg": stepper.exp_avg.cpu(), "exp_avg_sq": stepper.exp_avg_sq.cpu(),
+                                                            "opt_steps": stepper.opt_steps},
+                "teacher_optimizer": {}, "vae_scheduler": {"last_epoch": stepper.opt_steps}, "teacher_scheduler": {},
+                "best_loss": best_loss, "args": vars(args)}
+        torch.save(ckpt, out_dir / "checkpoints" / f"{tag}.pt")
+
+    if args.resume_from:
+        ck = torch.load(args.resume_from, map_location="cpu", weights_only=True)
+        vae.load_state_dict(ck["vae_state_dict"], strict=False)
+        vae = vae.to("cuda")
+        global_step, best_loss = ck.get("global_step", 0), ck.get("best_loss", float("inf"))
+        opt = ck.get("vae_optimizer") or {}
+        if "exp_avg" in opt:
+            vae.flat_parameters()
+            stepper.exp_avg.copy_(opt["exp_avg"])
+            stepper.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            stepper.opt_steps = int(opt.get("opt_steps", 0))
+
+    data = SpriteShards(args.data_dir)
+    n_train = int(0.9 * len(data))
+    perm = torch.randperm(len(data)).numpy()                 # random_split(:555)
+    train_idx = perm[:n_train]
+    per_rank = args.batch_size
+    steps_per_epoch = (n_train // world) // per_rank          # drop_last (:569)
+    log.info(f"Dataset initialized with {len(data)} samples; {steps_per_epoch} batches/epoch/rank")
+
+    interrupted = {"flag": False}
+    signal.signal(signal.SIGINT, lambda *_: interrupted.__setitem__("flag", True))
+    done = False
+    for epoch in range(args.num_epochs):
+        t0 = time.time()
+        order = np.random.permutation(train_idx)[rank::world]
+        epoch_losses = []
+        for b in range(steps_per_epoch):
+            idx = np.sort(order[b * per_rank:(b + 1) * per_rank])
+            images = normalise_on_device(data.batch_u8(idx), "cuda")
+            stepper.step(images, batch_idx=b)
+            global_step += 1
+            if global_step % args.log_every == 0 or b == steps_per_epoch - 1:
+                m = stepper.metrics()
+                metrics = {"recon_loss": m["recon_loss"], "kl_loss": m["kl_loss"], "quality_loss": 0.0, "pg_loss": m["pg_loss"],
+                           "semantic_reward": 0.0, "quality_reward": 0.0, "baseline": 0.0, "advantage": 0.0,
+                           "vae_loss": m["vae_loss"], "teacher_loss": 0.0, "total_loss": m["vae_loss"], "quality_scores": 0.0}
+                epoch_losses.append(metrics["total_loss"])
+                if writer is not None:
+                    for k, v in metrics.items():
+                        writer.add_scalar(k, v, global_step)
+                log.info(f"step {global_step} loss {metrics['total_loss']:.4f} recon {metrics['recon_loss']:.4f} "
+                         f"kl {metrics['kl_loss']:.4f} lr {m['lr']:.2e} grad_norm {m['grad_norm']:.3f}")
+            if interrupted["flag"] or (args.max_steps and global_step >= args.max_steps):
+                done = True
+                break
+        avg = float(np.mean(epoch_losses)) if epoch_losses else float("nan")
+        log.info(f"Epoch {epoch + 1} Summary: Time {(time.time() - t0) / 60:.2f} min, Average Loss {avg:.4f}, Best Loss {best_loss:.4f}")
+        if avg < best_loss:
+            best_loss = avg
+            save_checkpoint("best")
+        save_checkpoint("latest")
+        if done:
+            break
+    if writer is not None:
+        writer.close()
+    log.info("Training completed.")
+
+
+if __name__ == "__main__":
+    main()
