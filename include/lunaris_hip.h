@@ -67,7 +67,7 @@ int lo_conv_wgrad(int kind, int B, int H, int W, int Cin, int Cout, const void* 
 int lo_gn_mish_forward(const void* v, const float* gn_partial, int MT, const float* gamma, const float* beta,
                        const void* other, void* y, float* stats, int B, int HW, int C, int mode, void* stream);
 /* backward of the above: dv (fp16), ds (mode 2: gradient of the identity branch), dgamma/dbeta/dbias (fp32 * scale).
- * P1: B*nchunk*C*2 floats, P2: B*nchunk*C floats of scratch (nchunk = lo_gn_nchunk(HW,C) <= 64). */
+ * P1: B*nchunk*C*2 floats, P2: B*nchunk*C floats of scratch (nchunk = lo_gn_nchunk_for(HW,C) <= 256). */
 int lo_gn_nchunk_for(int HW, int C);
 int lo_gn_mish_backward(const void* dy, const void* v, const void* other, const float* stats, const float* gamma,
                         const float* beta, void* ds, void* dv, float* P1, float* P2, float* dgamma, float* dbeta,

@@ -4,6 +4,7 @@
 #include "../../include/lunaris_hip.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -138,7 +139,7 @@ struct LoVae {
   size_t o_xflat, o_slab_head, o_eps, o_z, o_klp, o_mu, o_lv, o_yfc, o_h0;
   size_t o_msep, o_losses, o_coefs;
   // backward scratch
-  size_t o_G[4], o_skipg[3], o_P1, o_P2, o_wslab, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
+  size_t o_G[6], o_skipg[3], o_P1, o_P2, o_wslab, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
   size_t o_packjobs;
   std::vector<LoPackJob> packjobs_host;   // kept alive: source of the asynchronous table upload
   int n_packjobs, pack_blocks;
@@ -147,6 +148,11 @@ struct LoVae {
   size_t ws_bytes;
   int idx_fc_mu_w, idx_fc_mu_b, idx_fc_lv_w, idx_fc_lv_b, idx_dfc_w, idx_dfc_b, idx_final_w, idx_final_b;
   bool forward_done, loss_done;
+  // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
+  hipStream_t side;
+  hipEvent_t ev_dv[2], ev_wg[2], ev_join;
+  int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
+  bool overlap;
 };
 
 static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin, int Cout, int p_w, Arena& ar, bool first) {
@@ -266,7 +272,7 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
   h->o_coefs = ar.take(16 * 4);
   // backward scratch
   size_t max_act = (size_t)B * 128 * 128 * 32 * 2;
-  for (int i = 0; i < 4; ++i) h->o_G[i] = ar.take(max_act);
+  for (int i = 0; i < 6; ++i) h->o_G[i] = ar.take(max_act);
   h->o_skipg[0] = ar.take((size_t)B * 64 * 64 * 64 * 2);    // grad wrt (up3.act + enc1.out)
   h->o_skipg[1] = ar.take((size_t)B * 32 * 32 * 128 * 2);   // grad wrt (up2.act + enc2.out)
   h->o_skipg[2] = ar.take((size_t)B * 16 * 16 * 256 * 2);   // grad wrt (up1.act + enc3.out)
@@ -295,11 +301,29 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
   h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
   h->ws_bytes = ar.off;
+  h->side = nullptr;
+  h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
+  if (h->overlap) {
+    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&h->ev_wg[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); h->overlap = false; }   // no GPU in this process (CPU-side planning only)
+  }
   *out = h;
   return LO_OK;
 }
 
-extern "C" void lo_vae_destroy(LoVae* h) { delete h; }
+extern "C" void lo_vae_destroy(LoVae* h) {
+  if (!h) return;
+  if (h->overlap) {
+    (void)hipStreamDestroy(h->side);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_dv[i]); (void)hipEventDestroy(h->ev_wg[i]); }
+    (void)hipEventDestroy(h->ev_join);
+  }
+  delete h;
+}
 extern "C" int lo_vae_num_params(const LoVae* h) { return h->nparam; }
 extern "C" size_t lo_vae_param_offset(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_off[i] : (size_t)-1; }
 extern "C" size_t lo_vae_param_numel(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_numel[i] : 0; }
@@ -426,11 +450,23 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
 // backward of one conv+GN+Mish layer.  dy: gradient wrt the layer's activation output (after mish, before any skip add).
 // Produces the parameter gradients and, when din != null, the gradient wrt the layer input (+ add_src).
 static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, int mode, const f16* layer_in, f16* ds,
-                       f16* dv, f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale,
-                       hipStream_t st) {
+                       f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale, hipStream_t st) {
+  // dv alternates between two buffers so that the side-stream weight gradient of layer k may still be reading its
+  // dv while the main stream already produces the dv of layer k+1
+  const int k = h->bwd_layer++;
+  f16* dv = WSP(f16, h->o_G[4 + (k & 1)]);
+  const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
+  if (ov && k >= 2) LO_HIP(hipStreamWaitEvent(st, h->ev_wg[k & 1], 0));
   LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
                            WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st));
-  LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st));
+  if (ov) {
+    LO_HIP(hipEventRecord(h->ev_dv[k & 1], st));
+    LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[k & 1], 0));
+    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
+    LO_HIP(hipEventRecord(h->ev_wg[k & 1], h->side));
+  } else {
+    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st));
+  }
   if (din) LO_TRY(lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st));
   return LO_OK;
 }
@@ -449,6 +485,7 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
   f16* Gb = WSP(f16, h->o_G[1]);
   f16* Gc = WSP(f16, h->o_G[2]);
   f16* Gd = WSP(f16, h->o_G[3]);
+  h->bwd_layer = 0;
   // padding elements of the flat gradient buffer stay zero
   LO_HIP(hipMemsetAsync(G, 0, h->flat_elems * sizeof(float), st));
   // ---- final conv (+tanh, + fused MSE gradient)
@@ -469,7 +506,7 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
     const f16* layer_in = s > 0 ? WSP(f16, h->dec[s - 1].o_a) : WSP(f16, h->o_h0);
     f16* din = s > 0 ? WSP(f16, h->o_skipg[3 - s]) : Ga;   // up4->skipg[0] (wrt up3 out), up3->skipg[1], up2->skipg[2], up1->Ga
     // mode 1 (skip add) has the same du as mode 0; the skip branch receives gout unchanged (kept in skipg)
-    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, Gb, din, nullptr, P, G, ws, inv, st));
+    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, din, nullptr, P, G, ws, inv, st));
     gout = din;
   }
   // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
@@ -494,19 +531,24 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
     ConvLayer& c0 = h->enc[s][0];
     ConvLayer& c1 = h->enc[s][1];
     ConvLayer& c2 = h->enc[s][2];
-    // ResBlock tail + conv2:  dy = Ga -> ds = Gb (identity branch), dv2 = Gc ; dgrad -> Gd (grad wrt conv1 activation)
-    LO_TRY(conv_gn_bwd(h, c2, Ga, WSP(f16, c0.o_a), 2, WSP(f16, c1.o_a), Gb, Gc, Gd, nullptr, P, G, ws, inv, st));
-    // conv1: dy = Gd -> dv1 = Gc ; dgrad (+ ds) -> Gd (grad wrt the block input = c0 activation)
-    LO_TRY(conv_gn_bwd(h, c1, Gd, nullptr, 0, WSP(f16, c0.o_a), nullptr, Gc, Gd, Gb, P, G, ws, inv, st));
+    // ResBlock tail + conv2:  dy = Ga -> ds = Gb (identity branch) ; dgrad -> Gd (grad wrt conv1 activation)
+    LO_TRY(conv_gn_bwd(h, c2, Ga, WSP(f16, c0.o_a), 2, WSP(f16, c1.o_a), Gb, Gd, nullptr, P, G, ws, inv, st));
+    // conv1: dy = Gd ; dgrad (+ ds) -> Gc (grad wrt the block input = c0 activation)
+    LO_TRY(conv_gn_bwd(h, c1, Gd, nullptr, 0, WSP(f16, c0.o_a), nullptr, Gc, Gb, P, G, ws, inv, st));
     if (s > 0) {
-      // strided conv: dy = Gd -> dv0 = Gc ; dgrad (+ decoder skip gradient) -> Ga (grad wrt the previous stage output)
-      LO_TRY(conv_gn_bwd(h, c0, Gd, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Gc, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
+      // strided conv: dy = Gc ; dgrad (+ decoder skip gradient) -> Ga (grad wrt the previous stage output)
+      LO_TRY(conv_gn_bwd(h, c0, Gc, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
                          ws, inv, st));
     } else {
-      LO_TRY(lo_gn_bwd_nofinal(Gd, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gc,
+      LO_TRY(lo_gn_bwd_nofinal(Gc, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gd,
                                WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st));
-      LO_TRY(lo_first_conv_wgrad(x, Gc, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
+      LO_TRY(lo_first_conv_wgrad(x, Gd, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
+  }
+  // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer
+  if (h->overlap && !g_lo_prof_on) {
+    LO_HIP(hipEventRecord(h->ev_join, h->side));
+    LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   }
   // ---- GroupNorm affine + conv bias gradients of all 16 layers in one launch
   {

@@ -74,6 +74,7 @@ struct LoGeom {
   int Hout, Wout, Cout;
   int GH, GW;          // output grid per phase (powers of two)
   int lgh, lgw;        // log2(GH), log2(GW)
+  int lg_hin, lg_win, lg_cin, lg_hout, lg_wout, lg_cout;   // log2 of the tensor dims, or -1 when not a power of two
   int in_stride, out_stride;
   int n_phase;
   int T[LO_MAX_PHASE];

@@ -94,6 +94,9 @@ int lo_make_geom(LoGeom* g, int kind, int B, int H, int W, int Cin, int Cout) {
   }
   while ((1 << g->lgh) < g->GH) ++g->lgh;
   while ((1 << g->lgw) < g->GW) ++g->lgw;
+  auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  g->lg_hin = lg2(g->Hin); g->lg_win = lg2(g->Win); g->lg_cin = lg2(g->Cin);
+  g->lg_hout = lg2(g->Hout); g->lg_wout = lg2(g->Wout); g->lg_cout = lg2(g->Cout);
   for (int p = 0; p < g->n_phase; ++p)
     for (int t = 0; t < g->T[p]; ++t) {
       g->dyc[p] |= (uint32_t)(g->dy[p][t] + 1) << (2 * t);
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2; // wave tile (2 x 2 waves)
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;     // epilogue staging pitch (bytes)
-  constexpr int LDS_BYTES = (NSTAGE * STAGE > BM * OPITCH + 4096) ? NSTAGE * STAGE : BM * OPITCH + 4096;
+  constexpr int LDS_BYTES = (NSTAGE * STAGE > BM * OPITCH + 6400) ? NSTAGE * STAGE : BM * OPITCH + 6400;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
 
   const LoGeom& g = a.g;
@@ -401,29 +404,45 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     }
   }
   if (a.gn_partial) {
-    // deterministic block reduction: per-thread (sum, sumsq) of the two 4-channel halves of its chunk
-    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);  // 256*4 floats
+    // deterministic block reduction of the per-thread (sum, sumsq) of the two 4-channel halves of each chunk:
+    //   level 1: 256 threads, each adds ORPP/P row slots of one (chunk, value)   level 2: P partials -> chunk sums
+    //   level 3: half-chunks of a group (<= 16) -> group sums
+    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);  // [256][4] floats, then [P][NV], then [NV]
     red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
+    constexpr int NV = OCPR * 4;          // values per row slot
+    constexpr int P = 256 / NV;           // parts
+    constexpr int RPP2 = ORPP / P;        // row slots per part
+    static_assert(P >= 1 && RPP2 * P == ORPP, "epilogue reduction shape");
+    float* red2 = red + 1024;
+    float* red3 = red2 + 256;
     __syncthreads();
-    // groups covered by this tile: half-chunks of 4 channels -> group = (n0 + hc*4) / G
-    const int ngroups = (BN >= G) ? BN / G : 1;
+    {
+      const int o = tid % NV, part = tid / NV;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPP2; ++r) t += red[((part * RPP2 + r) * OCPR) * 4 + o];
+      red2[part * NV + o] = t;
+    }
+    __syncthreads();
+    if (tid < NV) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < P; ++q) t += red2[q * NV + tid];
+      red3[tid] = t;                      // index = chunk*4 + half*2 + which
+    }
+    __syncthreads();
+    const int ngroups = BN / G;           // BN >= G is checked by the launcher
     if (tid < ngroups * 2) {
-      int gl = tid >> 1, which = tid & 1;               // which: 0 = sum, 1 = sumsq
-      int hc_begin = gl * G / 4, hc_end = (gl + 1) * G / 4;  // half-chunk range of this group inside the tile
-      if (BN < G) { hc_begin = 0; hc_end = BN / 4; }
+      int gl = tid >> 1, which = tid & 1;
+      int hc_begin = gl * G / 4, hc_end = (gl + 1) * G / 4;
       float tot = 0.f;
-      for (int r = 0; r < ORPP; ++r)
-        for (int hc = hc_begin; hc < hc_end; ++hc) {
-          int t = r * OCPR + (hc >> 1);
-          tot += red[t * 4 + (hc & 1) * 2 + which];
-        }
-      // partial index: [n_img][mtile_in_sample (phase-major)][group][2]
+      for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[(hc >> 1) * 4 + (hc & 1) * 2 + which];
       int per_sample = g.GH * g.GW;
       int n_img = m0 / per_sample;
       int mt = (m0 - n_img * per_sample) / BM;
-      int MT = (per_sample / BM) * g.n_phase;
+      int MTs = (per_sample / BM) * g.n_phase;
       int grp = (n0 / G) + gl;
-      a.gn_partial[(((size_t)n_img * MT + phase * (per_sample / BM) + mt) * 8 + grp) * 2 + which] = tot;
+      a.gn_partial[(((size_t)n_img * MTs + phase * (per_sample / BM) + mt) * 8 + grp) * 2 + which] = tot;
     }
   }
 }
@@ -472,9 +491,9 @@ __device__ __forceinline__ int lo_tr_swz(int row) {
   return RB == 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
-template <int BMW, int BNW, int NSTAGE>
+template <int BMW, int BNW, int NSTAGE, int BKP>
 __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
-  constexpr int BKP = 32;                        // pixels per K step
+  static_assert(BKP == 32 || BKP == 64, "pixels per K step");
   constexpr int RBA = BMW * 2, RBB = BNW * 2;    // row bytes
   static_assert((RBA == 128 || RBA == 256) && (RBB == 128 || RBB == 256), "tile rows must be 128 or 256 bytes");
   constexpr int A_BYTES = BKP * RBA, B_BYTES = BKP * RBB;
@@ -525,6 +544,9 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
     b_col[i] = c0 + chunk * 8;
   }
   const int pmask_w = g.GW - 1, pmask_h = g.GH - 1;
+  // all tensor dims on this path are powers of two (checked by the launcher): multiplies become shifts
+  const int sh_hin = g.lg_hin, sh_win = g.lg_win, sh_cin = g.lg_cin, sh_hout = g.lg_hout, sh_wout = g.lg_wout;
+  const bool cout_pow2 = g.lg_cout >= 0;
 
   auto issue = [&](int stage, int ms) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE;
@@ -536,7 +558,8 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
       int gx = m & pmask_w, gy = (m >> g.lgw) & pmask_h, n_img = m >> (g.lgw + g.lgh);
       int oy = gy * g.out_stride + ooy, ox = gx * g.out_stride + oox;
       bool ok = live && m < a.M && a_col[i] < g.Cout;
-      const f16* src = ok ? a.dy + ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * g.Cout + a_col[i] : zpage;
+      const int pix = (((n_img << sh_hout) + oy) << sh_wout) + ox;
+      const f16* src = ok ? a.dy + (cout_pow2 ? ((size_t)pix << g.lg_cout) : (size_t)pix * g.Cout) + a_col[i] : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sa + (wave * IA + i) * 1024), 16, 0, 0);
     }
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
       int gx = m & pmask_w, gy = (m >> g.lgw) & pmask_h, n_img = m >> (g.lgw + g.lgh);
       int iy = gy * g.in_stride + dyo, ix = gx * g.in_stride + dxo;
       bool ok = live && m < a.M && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-      const f16* src = ok ? a.x + ((size_t)(n_img * g.Hin + iy) * g.Win + ix) * g.Cin + b_col[i] : zpage;
+      const f16* src = ok ? a.x + ((size_t)((((n_img << sh_hin) + iy) << sh_win) + ix) << sh_cin) + b_col[i] : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + (wave * IB + i) * 1024), 16, 0, 0);
     }
@@ -558,24 +581,25 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // transposed fragment reads.  The 32 pixel rows of a K step are assigned to MFMA k positions by the SAME
+  // transposed fragment reads.  Each group of 32 pixel rows is assigned to the MFMA k positions by the SAME
   // permutation for both operands (lane group q reads rows 4q..4q+3 and 16+4q..16+4q+3); any consistent k
   // permutation leaves the sum unchanged.
   const int q16 = lane >> 4, i16 = lane & 15;
   const int trow = 4 * q16 + (i16 >> 2);   // row supplied by this lane (first read); +16 for the second
   const int tsub = (i16 & 3) * 8;          // byte offset inside the 32-byte block
-  int aoff[MI][2], boff[NI][2];
+  constexpr int KS = BKP / 32;
+  int aoff[MI][2 * KS], boff[NI][2 * KS];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 2 * KS; ++h) {
       int R = trow + 16 * h, blk = (wm * WM + mi * 16) / 16;
       aoff[mi][h] = R * RBA + ((blk ^ lo_tr_swz<RBA>(R)) * 32) + tsub;
     }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 2 * KS; ++h) {
       int R = trow + 16 * h, blk = (wn * WN + ni * 16) / 16;
       boff[ni][h] = A_BYTES + R * RBB + ((blk ^ lo_tr_swz<RBB>(R)) * 32) + tsub;
     }
@@ -589,24 +613,27 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
       __builtin_amdgcn_s_barrier();
       issue(ws, ms_begin + it + D);
       const unsigned char* sbase = smem + rs * STAGE;
-      f16x8 af[MI], bf[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + aoff[mi][0]));
-        h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + aoff[mi][1]));
-        af[mi] = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8 af[MI], bf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + aoff[mi][2 * ks]));
+          h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + aoff[mi][2 * ks + 1]));
+          af[mi] = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + boff[ni][2 * ks]));
+          h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + boff[ni][2 * ks + 1]));
+          bf[ni] = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + boff[ni][0]));
-        h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sbase + boff[ni][1]));
-        bf[ni] = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       rs = (rs + 1 == NSTAGE) ? 0 : rs + 1;
       ws = (ws + 1 == NSTAGE) ? 0 : ws + 1;
     }
@@ -633,9 +660,10 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 }
 
 // sum the split slabs and scatter to the canonical fp32 gradient:  grad[n*sn + c*sc + rs] = scale * sum_s slab
-__global__ void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
-                                       int total, int nsplit, float scale) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one thread = 4 consecutive packed elements (same n and tap, consecutive c): 16-byte slab loads
+__global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
+                                                              int total, int nsplit, float scale) {
+  int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   int p = 0;
 #pragma unroll
@@ -644,9 +672,11 @@ __global__ void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __
   int K = g.T[p] * g.Cin;
   int n = j / K, k = j - n * K;
   int t = k / g.Cin, c = k - t * g.Cin;
-  float v = 0.f;
-  for (int s = 0; s < nsplit; ++s) v += slab[(size_t)s * total + i];
-  grad[(size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t]] = v * scale;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s) v += *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + i);
+  float* dst = grad + (size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dst[(size_t)e * g.sc] = v[e] * scale;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -697,6 +727,8 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   return LO_OK;
 }
 
+void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out);
+
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st) {
@@ -717,32 +749,58 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
     LO_REQUIRE(BK == 64 && g.Cout % 64 == 0, "lo_conv_run: split-K path needs Cin%%64==0 and Cout%%64==0");
     return launch_igemm<64, 64, 64>(a, st);
   }
-  // tile choice: BM=128 when a sample's grid holds whole tiles and the launch still fills the chip
-  int bm = (per_sample % 128 == 0 && (size_t)a.M * g.Cout * g.n_phase >= (size_t)128 * 128 * 384) ? 128 : 64;
+  // tile choice
+  int bm, bn;
+  lo_conv_pick_tile(g, &bm, &bn);
   if (gn_partial) {
-    LO_REQUIRE(per_sample % bm == 0, "lo_conv_run: GN partials need whole tiles per sample");
-    LO_REQUIRE(a.M % bm == 0, "lo_conv_run: M %% BM");
+    LO_REQUIRE(per_sample % bm == 0 && a.M % bm == 0, "lo_conv_run: GN partials need whole tiles per sample");
+    LO_REQUIRE((g.Cout >> 3) <= bn, "lo_conv_run: GroupNorm group wider than the N tile");
   }
   if (BK == 32) {
     LO_REQUIRE(g.Cout % 64 == 0, "lo_conv_run: BK=32 path needs Cout%%64==0");
     if (bm == 128) return launch_igemm<128, 64, 32>(a, st);
     return launch_igemm<64, 64, 32>(a, st);
   }
-  if (g.Cout % 128 == 0 && bm == 128) return launch_igemm<128, 128, 64>(a, st);
-  if (g.Cout % 64 == 0) {
-    // GN groups wider than the N tile are not supported by the fused partials
-    if (gn_partial) LO_REQUIRE((g.Cout >> 3) <= 64, "lo_conv_run: group wider than tile");
-    if (bm == 128) return launch_igemm<128, 64, 64>(a, st);
-    return launch_igemm<64, 64, 64>(a, st);
-  }
-  if (bm == 128) return launch_igemm<128, 32, 64>(a, st);
-  return launch_igemm<64, 32, 64>(a, st);
+  if (bm == 128 && bn == 128) return launch_igemm<128, 128, 64>(a, st);
+  if (bm == 128 && bn == 64) return launch_igemm<128, 64, 64>(a, st);
+  if (bm == 64 && bn == 128) return launch_igemm<64, 128, 64>(a, st);
+  if (bm == 64 && bn == 64) return launch_igemm<64, 64, 64>(a, st);
+  if (bm == 128 && bn == 32) return launch_igemm<128, 32, 64>(a, st);
+  if (bm == 64 && bn == 32) return launch_igemm<64, 32, 64>(a, st);
+  lo_set_error("lo_conv_run: no kernel for tile %dx%d", bm, bn);
+  return LO_ERR_ARG;
 }
 
-int lo_conv_tile_m(const LoGeom& g) {
+// Largest tile (BM=128 preferred) that still gives >= 512 workgroups (two per CU); measured on MI355X at B=64:
+// 128x128 wins at M=65536/N=128, 128x64 at M=16384/N=256, 64x64 at M=4096/N=512.
+void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out) {
   const int per_sample = g.GH * g.GW;
-  size_t M = (size_t)g.B * per_sample;
-  return (per_sample % 128 == 0 && M * g.Cout * g.n_phase >= (size_t)128 * 128 * 384) ? 128 : 64;
+  const size_t M = (size_t)g.B * per_sample;
+  const int BK = (g.Cin % 64 == 0) ? 64 : 32;
+  static const int min_wgs = getenv("LO_MIN_WGS") ? atoi(getenv("LO_MIN_WGS")) : 512;
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  int bm = 64, bn = (g.Cout % 64 == 0) ? 64 : 32;
+  if (BK == 32) {
+    bn = 64;
+    bm = (per_sample % 128 == 0 && (M / 128) * (g.Cout / 64) * g.n_phase >= (size_t)min_wgs) ? 128 : 64;
+  } else if (g.Cout % 64 != 0) {
+    bm = (per_sample % 128 == 0 && (M / 128) * (g.Cout / 32) * g.n_phase >= (size_t)min_wgs) ? 128 : 64;
+  } else {
+    for (int i = 0; i < 4; ++i) {
+      int cm = cand[i][0], cn = cand[i][1];
+      if (per_sample % cm || g.Cout % cn || (g.Cout >> 3) > cn) continue;   // whole tiles per sample; GN group inside a tile
+      bm = cm; bn = cn;
+      if (((M + cm - 1) / cm) * (g.Cout / cn) * g.n_phase >= (size_t)min_wgs) break;
+    }
+  }
+  static const char* force = getenv("LO_FORCE_TILE");   // tuning knob "BMxBN"
+  if (force) { int fm = 0, fn = 0; if (sscanf(force, "%dx%d", &fm, &fn) == 2 && g.Cout % fn == 0 && per_sample % fm == 0 && BK == 64) { bm = fm; bn = fn; } }
+  *bm_out = bm; *bn_out = bn;
+}
+int lo_conv_tile_m(const LoGeom& g) {
+  int bm, bn;
+  lo_conv_pick_tile(g, &bm, &bn);
+  return bm;
 }
 
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit,
@@ -757,15 +815,18 @@ int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* ou
 static inline int wgrad_bmw(const LoGeom& g) { return g.Cout % 128 == 0 ? 128 : 64; }
 static inline int wgrad_bnw(const LoGeom& g) { return g.Cin % 128 == 0 ? 128 : 64; }
 
+static inline int wgrad_bkp(const LoGeom& g) { return ((long)g.B * g.GH * g.GW) % 64 == 0 && (long)g.B * g.GH * g.GW >= 1024 ? 64 : 32; }
+
 // number of pixel splits the wgrad launcher will use for this geometry (callers size the slab with it)
 int lo_wgrad_nsplit(const LoGeom& g) {
-  int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g);
+  int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g), bkp = wgrad_bkp(g);
   int taps = 0;
   for (int p = 0; p < g.n_phase; ++p) taps += g.T[p];
   long tiles = (long)((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps;
   int M = g.B * g.GH * g.GW;
-  int ms_total = (M + 31) / 32;
-  long want = (768 + tiles - 1) / tiles;  // aim at >= 768 workgroups
+  int ms_total = (M + bkp - 1) / bkp;
+  static const int target = getenv("LO_WGRAD_WGS") ? atoi(getenv("LO_WGRAD_WGS")) : 768;
+  long want = (target + tiles - 1) / tiles;
   if (want < 1) want = 1;
   if (want > ms_total / 8) want = ms_total / 8 > 0 ? ms_total / 8 : 1;   // at least 8 K steps per split
   if (want > 256) want = 256;
@@ -779,9 +840,12 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   a.packed_elems = geom_packed_elems(g);
   a.nsplit = lo_wgrad_nsplit(g);
   a.direct = (a.nsplit == 1 && g.sc == 1) ? 1 : 0;
-  int ms_total = (a.M + 31) / 32;
+  const int bkp = wgrad_bkp(g);
+  int ms_total = (a.M + bkp - 1) / bkp;
   a.msteps_per_split = (ms_total + a.nsplit - 1) / a.nsplit;
   LO_REQUIRE(g.Cin % 64 == 0 && g.Cout % 32 == 0, "lo_wgrad_run: need Cin %% 64 == 0 and Cout %% 32 == 0 (Cin=%d Cout=%d)", g.Cin, g.Cout);
+  LO_REQUIRE(g.lg_hin >= 0 && g.lg_win >= 0 && g.lg_cin >= 0 && g.lg_hout >= 0 && g.lg_wout >= 0,
+             "lo_wgrad_run: tensor dims must be powers of two");
   int taps = 0;
   for (int p = 0; p < g.n_phase; ++p) taps += g.T[p];
   int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g);
@@ -789,7 +853,11 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   dim3 grid(((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps * a.nsplit);
   {
     LoProfScope _p("lo_wgrad_tn", geom_flops(g), geom_bytes(g), st);
-#define LO_WG(BMW, BNW) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 3>), grid, dim3(256), 0, st, a)
+#define LO_WG(BMW, BNW)                                                                            \
+  do {                                                                                             \
+    if (bkp == 64) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 2, 64>), grid, dim3(256), 0, st, a);   \
+    else hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 3, 32>), grid, dim3(256), 0, st, a);             \
+  } while (0)
     if (bmw == 128 && bnw == 128) LO_WG(128, 128);
     else if (bmw == 128 && bnw == 64) LO_WG(128, 64);
     else if (bmw == 64 && bnw == 128) LO_WG(64, 128);
@@ -800,7 +868,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   if (a.direct) return LO_OK;
   int total = a.packed_elems;
   LoProfScope _p2("lo_wgrad_reduce", 0, 4.0 * total * (a.nsplit + 1), st);
-  hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
+  hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
   LO_LAUNCH_CHECK("wgrad_reduce");
   return LO_OK;
 }

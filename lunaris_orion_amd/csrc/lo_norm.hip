@@ -7,15 +7,17 @@
 // 117-118,170-171,176-177,182-183,188-189), the ResBlock tail mish(out + identity) (:49-53) and the decoder
 // skip additions (:212-222).
 #include "lo_internal.h"
+#include <stdlib.h>
 
 #define GN_EPS 1e-5f
 
 enum { GN_MODE_PLAIN = 0, GN_MODE_SKIP = 1, GN_MODE_RES = 2 };
 
 int lo_gn_nchunk(int HW, int C) {
-  long e = (long)HW * C / 16384;
+  static const long chunk_elems = getenv("LO_GN_CHUNK_ELEMS") ? atol(getenv("LO_GN_CHUNK_ELEMS")) : 16384;
+  long e = (long)HW * C / chunk_elems;
   if (e < 1) e = 1;
-  if (e > 64) e = 64;
+  if (e > 256) e = 256;
   while (HW % e) --e;
   return (int)e;
 }
