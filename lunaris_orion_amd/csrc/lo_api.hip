@@ -108,6 +108,7 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_v, o_a;           // raw conv output, activation after GN+Mish(+...)
   size_t o_part, o_stats;    // GN partial sums, saved stats
   size_t o_P1, o_P2;         // GN backward partial sums (kept until the fused finalize at the end of backward)
+  int np1;                   // >0: P1 rows per sample written by the consumer's fused data-gradient epilogue
   int MT;
 };
 
@@ -153,6 +154,7 @@ struct LoVae {
   hipEvent_t ev_dv[2], ev_wg[2], ev_join;
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
+  bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
 };
 
 static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin, int Cout, int p_w, Arena& ar, bool first) {
@@ -178,7 +180,9 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   c.o_part = ar.take((size_t)B * c.MT * 16 * 4);
   c.o_stats = ar.take((size_t)B * 16 * 4);
   int nchunk = lo_gn_nchunk(c.Ho * c.Wo, Cout);
-  c.o_P1 = ar.take((size_t)B * nchunk * Cout * 2 * 4);
+  int p1rows = nchunk > (c.Ho * c.Wo) / 64 ? nchunk : (c.Ho * c.Wo) / 64;   // >= tiles per sample of any data-gradient epilogue
+  c.np1 = 0;
+  c.o_P1 = ar.take((size_t)B * p1rows * Cout * 2 * 4);
   c.o_P2 = ar.take((size_t)B * nchunk * Cout * 4);
   return LO_OK;
 }
@@ -303,6 +307,7 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
   h->ws_bytes = ar.off;
   h->side = nullptr;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
+  h->fuse_gnb = getenv("LO_GNB_FUSE") != nullptr;   // measured neutral on MI355X (the heavier epilogue cancels the saved launches): off by default
   if (h->overlap) {
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)
@@ -449,8 +454,11 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
 
 // backward of one conv+GN+Mish layer.  dy: gradient wrt the layer's activation output (after mish, before any skip add).
 // Produces the parameter gradients and, when din != null, the gradient wrt the layer input (+ add_src).
+// prod: the conv+GN+Mish layer (mode plain / skip) whose activation gradient this layer's data gradient produces;
+// its GroupNorm-backward reduction is then fused into the data-gradient epilogue (prod->np1 records the row count).
 static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, int mode, const f16* layer_in, f16* ds,
-                       f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale, hipStream_t st) {
+                       f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale, hipStream_t st,
+                       ConvLayer* prod = nullptr) {
   // dv alternates between two buffers so that the side-stream weight gradient of layer k may still be reading its
   // dv while the main stream already produces the dv of layer k+1
   const int k = h->bwd_layer++;
@@ -458,7 +466,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
   if (ov && k >= 2) LO_HIP(hipStreamWaitEvent(st, h->ev_wg[k & 1], 0));
   LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
-                           WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st));
+                           WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
   if (ov) {
     LO_HIP(hipEventRecord(h->ev_dv[k & 1], st));
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[k & 1], 0));
@@ -467,7 +475,16 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   } else {
     LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st));
   }
-  if (din) LO_TRY(lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st));
+  if (din) {
+    LoGnBwdFuse gb, *gbp = nullptr;
+    if (prod && h->fuse_gnb) {
+      gb.v = WSP(f16, prod->o_v); gb.stats = WSP(float, prod->o_stats); gb.gamma = PRM(prod->p_gw); gb.beta = PRM(prod->p_gb);
+      gb.P1 = WSP(float, prod->o_P1);
+      prod->np1 = (c.gd.GH * c.gd.GW / lo_conv_tile_m(c.gd)) * c.gd.n_phase;
+      gbp = &gb;
+    }
+    LO_TRY(lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st, gbp));
+  }
   return LO_OK;
 }
 
@@ -486,6 +503,7 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
   f16* Gc = WSP(f16, h->o_G[2]);
   f16* Gd = WSP(f16, h->o_G[3]);
   h->bwd_layer = 0;
+  for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) h->enc[s][k].np1 = 0; h->dec[s].np1 = 0; }
   // padding elements of the flat gradient buffer stay zero
   LO_HIP(hipMemsetAsync(G, 0, h->flat_elems * sizeof(float), st));
   // ---- final conv (+tanh, + fused MSE gradient)
@@ -506,7 +524,7 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
     const f16* layer_in = s > 0 ? WSP(f16, h->dec[s - 1].o_a) : WSP(f16, h->o_h0);
     f16* din = s > 0 ? WSP(f16, h->o_skipg[3 - s]) : Ga;   // up4->skipg[0] (wrt up3 out), up3->skipg[1], up2->skipg[2], up1->Ga
     // mode 1 (skip add) has the same du as mode 0; the skip branch receives gout unchanged (kept in skipg)
-    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, din, nullptr, P, G, ws, inv, st));
+    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, din, nullptr, P, G, ws, inv, st, s > 0 ? &h->dec[s - 1] : nullptr));
     gout = din;
   }
   // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
@@ -532,16 +550,16 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
     ConvLayer& c1 = h->enc[s][1];
     ConvLayer& c2 = h->enc[s][2];
     // ResBlock tail + conv2:  dy = Ga -> ds = Gb (identity branch) ; dgrad -> Gd (grad wrt conv1 activation)
-    LO_TRY(conv_gn_bwd(h, c2, Ga, WSP(f16, c0.o_a), 2, WSP(f16, c1.o_a), Gb, Gd, nullptr, P, G, ws, inv, st));
+    LO_TRY(conv_gn_bwd(h, c2, Ga, WSP(f16, c0.o_a), 2, WSP(f16, c1.o_a), Gb, Gd, nullptr, P, G, ws, inv, st, &c1));
     // conv1: dy = Gd ; dgrad (+ ds) -> Gc (grad wrt the block input = c0 activation)
-    LO_TRY(conv_gn_bwd(h, c1, Gd, nullptr, 0, WSP(f16, c0.o_a), nullptr, Gc, Gb, P, G, ws, inv, st));
+    LO_TRY(conv_gn_bwd(h, c1, Gd, nullptr, 0, WSP(f16, c0.o_a), nullptr, Gc, Gb, P, G, ws, inv, st, &c0));
     if (s > 0) {
       // strided conv: dy = Gc ; dgrad (+ decoder skip gradient) -> Ga (grad wrt the previous stage output)
       LO_TRY(conv_gn_bwd(h, c0, Gc, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
                          ws, inv, st));
     } else {
       LO_TRY(lo_gn_bwd_nofinal(Gc, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gd,
-                               WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st));
+                               WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st, c0.np1));
       LO_TRY(lo_first_conv_wgrad(x, Gd, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
   }
@@ -559,8 +577,10 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
       LoGnFinJob& j = jobs.j[jobs.n++];
       j.P1 = WSP(float, c.o_P1); j.P2 = WSP(float, c.o_P2);
       j.dgamma = GRD(c.p_gw); j.dbeta = GRD(c.p_gb); j.dbias = GRD(c.p_b);
-      j.nblk = B * lo_gn_nchunk(c.Ho * c.Wo, c.Cout); j.C = c.Cout; j.block0 = blocks;
-      blocks += (c.Cout + 15) / 16;
+      j.nblk2 = B * lo_gn_nchunk(c.Ho * c.Wo, c.Cout);
+      j.nblk1 = c.np1 > 0 ? B * c.np1 : j.nblk2;
+      j.C = c.Cout; j.block0 = blocks;
+      blocks += (c.Cout + 3) / 4;
     };
     for (int s = 0; s < 4; ++s) for (int k = 0; k < 3; ++k) add(h->enc[s][k]);
     for (int s = 0; s < 4; ++s) add(h->dec[s]);

@@ -9,7 +9,7 @@
 //
 // Reference ops replaced (PyTorch ATen, dispatched from /root/reference/lunar_generate.py):
 //   conv2d            :36,41,95,102,109,116   conv_transpose2d :169,175,181,187   linear :124,125,165
-#include "lo_common.h"
+#include "lo_internal.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -158,6 +158,13 @@ struct IgemmArgs {
   f16* out;
   float* gn_partial;   // [B][MT][8][2] or null
   float* slab;         // split-K fp32 partials [nsplit][M][Cout] (SPLITK only)
+  // fused GroupNorm-backward reduction (data-gradient ops): the output of this op is dL/da of a conv+GN+Mish layer
+  // whose raw conv output is gb_v; the epilogue also emits P1[n][mtile][c] = (sum du, sum du*xhat), du = da*mish'(u)
+  const f16* gb_v;
+  const float* gb_stats;   // [B][8][2] mean, rstd
+  const float* gb_gamma;
+  const float* gb_beta;
+  float* gb_P1;
   int M;               // rows per phase = B*GH*GW
   int nsplit;          // >= 1
   int ksteps_per_split;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2; // wave tile (2 x 2 waves)
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;     // epilogue staging pitch (bytes)
-  constexpr int LDS_BYTES = (NSTAGE * STAGE > BM * OPITCH + 6400) ? NSTAGE * STAGE : BM * OPITCH + 6400;
+  constexpr int LDS_BYTES = (NSTAGE * STAGE > BM * OPITCH + 16384 + 1024) ? NSTAGE * STAGE : BM * OPITCH + 16384 + 1024;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
 
   const LoGeom& g = a.g;
@@ -379,6 +386,21 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   const int orow = tid / OCPR, ochunk = tid % OCPR;
   const int G = g.Cout >> 3;          // channels per GroupNorm group (8 groups)
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  // fused GN-backward reduction: per-thread constants of its 8 channels (the tile lies inside one sample)
+  float gsc[8], gsh[8], gmean[8], grstd[8], ga1[8], ga2[8];
+  if (a.gb_v) {
+    const int n_img_t = m0 / (g.GH * g.GW);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = n0 + ochunk * 8 + j;
+      int grp = c / G;
+      gmean[j] = a.gb_stats[n_img_t * 16 + grp * 2];
+      grstd[j] = a.gb_stats[n_img_t * 16 + grp * 2 + 1];
+      gsc[j] = a.gb_gamma[c] * grstd[j];
+      gsh[j] = a.gb_beta[c] - gmean[j] * gsc[j];
+      ga1[j] = 0.f; ga2[j] = 0.f;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < OP; ++i) {
     int ml = orow + i * ORPP;
@@ -396,11 +418,40 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
       for (int j = 0; j < 8; ++j) h[j] = (f16)((float)h[j] + (float)r[j]);
     }
     *reinterpret_cast<f16x8*>(a.out + off) = h;
+    if (a.gb_v) {
+      f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float hv = (float)vv[j];
+        float du = (float)h[j] * lo_mish_grad(hv * gsc[j] + gsh[j]);
+        ga1[j] += du;
+        ga2[j] += du * ((hv - gmean[j]) * grstd[j]);
+      }
+    }
     if (a.gn_partial) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float x = (float)h[j]; s0 += x; q0 += x * x; }
 #pragma unroll
       for (int j = 4; j < 8; ++j) { float x = (float)h[j]; s1 += x; q1 += x * x; }
+    }
+  }
+  if (a.gb_v) {
+    // reduce (ga1, ga2) over the row slots in a fixed order: BN*2 outputs, one per thread (looped)
+    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);   // [256][16] floats
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j * 2] = ga1[j]; red[tid * 16 + j * 2 + 1] = ga2[j]; }
+    __syncthreads();
+    const int per_sample = g.GH * g.GW;
+    const int n_img = m0 / per_sample;
+    const int mt = (m0 - n_img * per_sample) / BM;
+    const int MTs = (per_sample / BM) * g.n_phase;
+    float* dst = a.gb_P1 + (((size_t)n_img * MTs + phase * (per_sample / BM) + mt) * g.Cout + n0) * 2;
+    for (int o = tid; o < BN * 2; o += 256) {
+      int cl = o >> 1, w = o & 1;
+      int ccx = cl >> 3, j = cl & 7;
+      float tot = 0.f;
+      for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
+      dst[o] = tot;
     }
   }
   if (a.gn_partial) {
@@ -731,9 +782,11 @@ void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out);
 
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                float* gn_partial, float* slab, int nsplit, hipStream_t st) {
+                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb) {
   IgemmArgs a;
   a.in = in; a.w = wp; a.bias = bias; a.add_src = add_src; a.out = out; a.gn_partial = gn_partial; a.slab = slab;
+  a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
+  a.gb_beta = gb ? gb->beta : nullptr; a.gb_P1 = gb ? gb->P1 : nullptr;
   a.g = g;
   a.M = g.B * g.GH * g.GW;
   a.nsplit = nsplit < 1 ? 1 : nsplit;
@@ -752,7 +805,7 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   // tile choice
   int bm, bn;
   lo_conv_pick_tile(g, &bm, &bn);
-  if (gn_partial) {
+  if (gn_partial || gb) {
     LO_REQUIRE(per_sample % bm == 0 && a.M % bm == 0, "lo_conv_run: GN partials need whole tiles per sample");
     LO_REQUIRE((g.Cout >> 3) <= bn, "lo_conv_run: GroupNorm group wider than the N tile");
   }

@@ -228,87 +228,90 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[LC_TP * LC_TP * LC_PITCH];  // reused as reduction buffer
   __shared__ __attribute__((aligned(16))) float dp[LC_TP * LC_TP][4];
   __shared__ __attribute__((aligned(16))) float w2[9][3][LC_CI];
-  const int tid = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
-  lc_stage_a4(a.a4, tile, n, ty, tx, tid);
+  __shared__ float bred[8][3];
+  const int tid = threadIdx.x, ty = blockIdx.x, n = blockIdx.y;   // one workgroup = one row of 8 tiles
   const float cf = a.drecon ? a.gscale : *a.coef;
-  for (int p = tid; p < LC_TP * LC_TP; p += 256) {
-    int y = p / LC_TP, xx = p % LC_TP;
-    int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    if ((unsigned)iy < 128u && (unsigned)ix < 128u) {
-      size_t o = ((size_t)n * 3 * 128 + iy) * 128 + ix;
-      float r0 = a.recon[o], r1 = a.recon[o + 16384], r2 = a.recon[o + 32768];
-      float g0, g1, g2;
-      if (a.drecon) { g0 = a.drecon[o]; g1 = a.drecon[o + 16384]; g2 = a.drecon[o + 32768]; }
-      else { g0 = r0 - a.target[o]; g1 = r1 - a.target[o + 16384]; g2 = r2 - a.target[o + 32768]; }
-      d0 = cf * g0 * (1.f - r0 * r0);
-      d1 = cf * g1 * (1.f - r1 * r1);
-      d2 = cf * g2 * (1.f - r2 * r2);
-    }
-    dp[p][0] = d0; dp[p][1] = d1; dp[p][2] = d2; dp[p][3] = 0.f;
-  }
   for (int i = tid; i < 9 * 3 * LC_CI; i += 256) {
     int ci = i % LC_CI, co = (i / LC_CI) % 3, t = i / (3 * LC_CI);
     w2[t][co][ci] = a.w[(co * LC_CI + ci) * 9 + t];
   }
-  __syncthreads();
-  // ---- data gradient: thread = pixel, 32 input channels
-  {
-    const int px = tid & 15, py = tid >> 4;
-    float acc[LC_CI];
-#pragma unroll
-    for (int j = 0; j < LC_CI; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        // output pixel (py,px) of da4 receives dpre at (py + 1 - r, px + 1 - s); tile coords are +1
-        f32x4 d = *reinterpret_cast<const f32x4*>(&dp[(py + 2 - r) * LC_TP + (px + 2 - s)][0]);
-#pragma unroll
-        for (int co = 0; co < 3; ++co) {
-          float dv = d[co];
-#pragma unroll
-          for (int j = 0; j < LC_CI; j += 4) {
-            f32x4 wv = *reinterpret_cast<const f32x4*>(&w2[r * 3 + s][co][j]);
-            acc[j] += dv * wv[0]; acc[j + 1] += dv * wv[1]; acc[j + 2] += dv * wv[2]; acc[j + 3] += dv * wv[3];
-          }
-        }
-      }
-    const int oy = ty * LC_T + py, ox = tx * LC_T + px;
-    f16* dst = a.da4 + (((size_t)n * 128 + oy) * 128 + ox) * LC_CI;
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      f16x8 h;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (f16)acc[ch * 8 + j];
-      *reinterpret_cast<f16x8*>(dst + ch * 8) = h;
-    }
-  }
-  // ---- weight gradient: thread = (ci, pixel subset q of 32 pixels); 27 accumulators (tap, co)
   const int ci = tid & 31, q = tid >> 5;
   float wacc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) wacc[k] = 0.f;
   float bacc0 = 0.f, bacc1 = 0.f, bacc2 = 0.f;
-  for (int pp = q * 32; pp < q * 32 + 32; ++pp) {
-    int py = pp >> 4, px = pp & 15;
-    f32x4 d = *reinterpret_cast<const f32x4*>(&dp[(py + 1) * LC_TP + px + 1][0]);
-    if (ci == 0) { bacc0 += d[0]; bacc1 += d[1]; bacc2 += d[2]; }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        float xv = (float)*reinterpret_cast<const f16*>(tile + ((py + r) * LC_TP + px + s) * LC_PITCH + ci * 2);
-        wacc[(r * 3 + s) * 3 + 0] += d[0] * xv;
-        wacc[(r * 3 + s) * 3 + 1] += d[1] * xv;
-        wacc[(r * 3 + s) * 3 + 2] += d[2] * xv;
+  for (int tx = 0; tx < 8; ++tx) {
+    __syncthreads();                     // previous tile fully consumed
+    lc_stage_a4(a.a4, tile, n, ty, tx, tid);
+    for (int p = tid; p < LC_TP * LC_TP; p += 256) {
+      int y = p / LC_TP, xx = p % LC_TP;
+      int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+      if ((unsigned)iy < 128u && (unsigned)ix < 128u) {
+        size_t o = ((size_t)n * 3 * 128 + iy) * 128 + ix;
+        float r0 = a.recon[o], r1 = a.recon[o + 16384], r2 = a.recon[o + 32768];
+        float g0, g1, g2;
+        if (a.drecon) { g0 = a.drecon[o]; g1 = a.drecon[o + 16384]; g2 = a.drecon[o + 32768]; }
+        else { g0 = r0 - a.target[o]; g1 = r1 - a.target[o + 16384]; g2 = r2 - a.target[o + 32768]; }
+        d0 = cf * g0 * (1.f - r0 * r0);
+        d1 = cf * g1 * (1.f - r1 * r1);
+        d2 = cf * g2 * (1.f - r2 * r2);
       }
+      dp[p][0] = d0; dp[p][1] = d1; dp[p][2] = d2; dp[p][3] = 0.f;
+    }
+    __syncthreads();
+    // ---- data gradient: thread = pixel, 32 input channels
+    {
+      const int px = tid & 15, py = tid >> 4;
+      float acc[LC_CI];
+#pragma unroll
+      for (int j = 0; j < LC_CI; ++j) acc[j] = 0.f;
+#pragma unroll 1
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          // output pixel (py,px) of da4 receives dpre at (py + 1 - r, px + 1 - s); tile coords are +1
+          f32x4 d = *reinterpret_cast<const f32x4*>(&dp[(py + 2 - r) * LC_TP + (px + 2 - s)][0]);
+#pragma unroll
+          for (int co = 0; co < 3; ++co) {
+            float dv = d[co];
+#pragma unroll
+            for (int j = 0; j < LC_CI; j += 4) {
+              f32x4 wv = *reinterpret_cast<const f32x4*>(&w2[r * 3 + s][co][j]);
+              acc[j] += dv * wv[0]; acc[j + 1] += dv * wv[1]; acc[j + 2] += dv * wv[2]; acc[j + 3] += dv * wv[3];
+            }
+          }
+        }
+      const int oy = ty * LC_T + py, ox = tx * LC_T + px;
+      f16* dst = a.da4 + (((size_t)n * 128 + oy) * 128 + ox) * LC_CI;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (f16)acc[ch * 8 + j];
+        *reinterpret_cast<f16x8*>(dst + ch * 8) = h;
+      }
+    }
+    // ---- weight gradient: thread = (ci, pixel subset q of 32 pixels); 27 accumulators (tap, co) kept across tiles
+    for (int pp = q * 32; pp < q * 32 + 32; ++pp) {
+      int py = pp >> 4, px = pp & 15;
+      f32x4 d = *reinterpret_cast<const f32x4*>(&dp[(py + 1) * LC_TP + px + 1][0]);
+      if (ci == 0) { bacc0 += d[0]; bacc1 += d[1]; bacc2 += d[2]; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          float xv = (float)*reinterpret_cast<const f16*>(tile + ((py + r) * LC_TP + px + s) * LC_PITCH + ci * 2);
+          wacc[(r * 3 + s) * 3 + 0] += d[0] * xv;
+          wacc[(r * 3 + s) * 3 + 1] += d[1] * xv;
+          wacc[(r * 3 + s) * 3 + 2] += d[2] * xv;
+        }
+    }
   }
   __syncthreads();                       // everyone is done reading the a4 tile: reuse it for the reduction
   float* red = reinterpret_cast<float*>(tile);   // [4 subsets][27][32] floats = 13824 B
   static_assert(LC_TP * LC_TP * LC_PITCH >= 4 * 27 * 32 * 4, "reduction buffer");
-  float* outp = a.partial + (((size_t)n * gridDim.y + ty) * gridDim.x + tx) * 867;
-  __shared__ float bred[8][3];
+  float* outp = a.partial + ((size_t)n * gridDim.x + ty) * 867;
   if (ci == 0) { bred[q][0] = bacc0; bred[q][1] = bacc1; bred[q][2] = bacc2; }
   // two rounds of 4 pixel subsets each (fixed order)
   for (int round = 0; round < 2; ++round) {
@@ -369,12 +372,12 @@ int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const f
                       hipStream_t st) {
   LcBwdArgs a{a4, w, recon, target, drecon, coef, gscale, da4, partial};
   LoProfScope _p("lo_final_conv_bwd(+sums)", 4.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 * 2 + 3 * 4 * 2), st);
-  hipLaunchKernelGGL(lo_final_conv_bwd_kernel, dim3(8, 8, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(lo_final_conv_bwd_kernel, dim3(8, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("final_conv_bwd");
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * 64, 864, 867, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * 8, 864, 867, scale);
   LO_LAUNCH_CHECK("final_conv_dw");
   // bias: columns 864..866 of the same partial matrix
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3(1), dim3(256), 0, st, partial + 864, db, B * 64, 3, 867, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3(1), dim3(256), 0, st, partial + 864, db, B * 8, 3, 867, scale);
   LO_LAUNCH_CHECK("final_conv_db");
   return LO_OK;
 }

@@ -7,8 +7,9 @@ const char* lo_get_error();
 // lo_conv.hip
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
 int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st);
+struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                float* gn_partial, float* slab, int nsplit, hipStream_t st);
+                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr);
 int lo_conv_tile_m(const LoGeom& g);
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);
 int lo_wgrad_nsplit(const LoGeom& g);
@@ -23,11 +24,13 @@ int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, co
 int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
               f16* ds, f16* dv, float* P1, float* P2, float* dgamma, float* dbeta, float* dbias, int B, int HW, int C,
               int mode, float scale, hipStream_t st);
-struct LoGnFinJob { const float* P1; const float* P2; float* dgamma; float* dbeta; float* dbias; int nblk, C, block0; };
+struct LoGnFinJob { const float* P1; const float* P2; float* dgamma; float* dbeta; float* dbias; int nblk1, nblk2, C, block0; };
 #define LO_GN_FIN_MAX 16
 struct LoGnFinJobs { LoGnFinJob j[LO_GN_FIN_MAX]; int n; };
+// np1 = 0: run the reduce pass here (P1 gets nchunk rows per sample); np1 > 0: P1 already holds np1 rows per sample
+// (written by the fused data-gradient epilogue) and only the apply pass runs
 int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
-                      f16* ds, f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st);
+                      f16* ds, f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st, int np1 = 0);
 int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st);
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
 int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
