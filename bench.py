@@ -161,7 +161,17 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": d_by / (d_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_traffic.py); null when absent
         roof["traffic"] = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            key = next((k for k in tr if k in dom_name or dom_name.split("<")[0] in k), None)
+            if key:
+                roof["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                roof["traffic_unit"] = "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                roof["algorithmic_bytes_per_launch"] = d_by / max(d_n, 1)
+        except Exception:
+            pass
         roof["kernel"] = dom_name
         roof["launches_per_step"] = d_n / max(args.prof_steps, 1)
         roof["avg_launch_ms"] = d_ms / max(d_n, 1)

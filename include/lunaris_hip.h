@@ -117,6 +117,14 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
                     int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                     float* flat_grads, void* stream);
 
+/* The same backward in two calls, for data-parallel overlap: phase 1 = final conv, decoder, decoder.fc, latent, encoder
+ * heads (afterwards the gradients of the three Linear layers — 82 % of the bytes, one contiguous range of the flat
+ * buffer, see lo_vae_linear_grad_range — are final and can be all-reduced while phase 2 runs); phase 2 = encoder. */
+int lo_vae_backward_phase(LoVae* h, int phase, const float* x, const float* flat_params, void* ws, const float* recon,
+                          const float* target, int fused, const float* drecon, const float* gmu, const float* glv,
+                          float loss_scale, float* flat_grads, void* stream);
+int lo_vae_linear_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_elem);
+
 #ifdef __cplusplus
 }
 #endif

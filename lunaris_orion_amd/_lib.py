@@ -57,6 +57,8 @@ SIGNATURES = {
     "lo_vae_forward": (i32, [vp, f32p, f32p, u64, f32p, vp, f32p, f32p, f32p, f32p, vp]),
     "lo_vae_loss": (i32, [vp, vp, flt, flt, flt, f32p, flt, flt, f32p, vp]),
     "lo_vae_backward": (i32, [vp, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),
+    "lo_vae_backward_phase": (i32, [vp, i32, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),
+    "lo_vae_linear_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -488,9 +488,31 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   return LO_OK;
 }
 
+static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon, const float* target,
+                             int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
+                             float* G, void* stream);
+
 extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* ws, const float* recon, const float* target,
                                int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                                float* G, void* stream) {
+  return vae_backward_impl(h, 0, x, P, ws, recon, target, fused, drecon, gmu, glv, loss_scale, G, stream);
+}
+extern "C" int lo_vae_backward_phase(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon,
+                                     const float* target, int fused, const float* drecon, const float* gmu, const float* glv,
+                                     float loss_scale, float* G, void* stream) {
+  LO_REQUIRE(phase == 1 || phase == 2, "lo_vae_backward_phase: phase must be 1 or 2");
+  return vae_backward_impl(h, phase, x, P, ws, recon, target, fused, drecon, gmu, glv, loss_scale, G, stream);
+}
+extern "C" int lo_vae_linear_grad_range(const LoVae* h, size_t* begin, size_t* end) {
+  LO_REQUIRE(h && begin && end, "lo_vae_linear_grad_range: null argument");
+  *begin = h->p_off[h->idx_fc_mu_w];
+  *end = h->p_off[h->idx_dfc_b] + ((h->p_numel[h->idx_dfc_b] + 63) & ~(size_t)63);
+  return LO_OK;
+}
+
+static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon, const float* target,
+                             int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
+                             float* G, void* stream) {
   LO_REQUIRE(h && x && P && ws && recon && G, "lo_vae_backward: null argument");
   if (!h->forward_done) { lo_set_error("lo_vae_backward: forward has not run"); return LO_ERR_STATE; }
   if (fused && (!h->loss_done || !target)) { lo_set_error("lo_vae_backward: fused mode needs lo_vae_loss and a target"); return LO_ERR_STATE; }
@@ -502,6 +524,7 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
   f16* Gb = WSP(f16, h->o_G[1]);
   f16* Gc = WSP(f16, h->o_G[2]);
   f16* Gd = WSP(f16, h->o_G[3]);
+  if (phase != 2) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
   h->bwd_layer = 0;
   for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) h->enc[s][k].np1 = 0; h->dec[s].np1 = 0; }
   // padding elements of the flat gradient buffer stay zero
@@ -544,6 +567,8 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
   LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab), GRD(h->idx_fc_mu_w), inv, st));
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
+  }                   // ---------------- end of part A
+  if (phase == 1) return LO_OK;
   // ---- encoder stages 4..1
   for (int s = 3; s >= 0; --s) {
     ConvLayer& c0 = h->enc[s][0];

@@ -880,6 +880,13 @@ int lo_wgrad_nsplit(const LoGeom& g) {
   int ms_total = (M + bkp - 1) / bkp;
   static const int target = getenv("LO_WGRAD_WGS") ? atoi(getenv("LO_WGRAD_WGS")) : 768;
   long want = (target + tiles - 1) / tiles;
+  // every split writes (and the reduce pass re-reads) one fp32 slab: keep the slab traffic under ~24 MB per launch,
+  // but never go below one workgroup per CU
+  const long slab_bytes = (long)geom_packed_elems(g) * 4;
+  long cap = (24L << 20) / (slab_bytes > 0 ? slab_bytes : 1);
+  long floor_wgs = (256 + tiles - 1) / tiles;
+  if (cap < floor_wgs) cap = floor_wgs;
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
   if (want > ms_total / 8) want = ms_total / 8 > 0 ? ms_total / 8 : 1;   // at least 8 K steps per split
   if (want > 256) want = 256;

@@ -6,9 +6,11 @@ GroupNorm is per-sample and MSE / KL are means, so averaging the per-rank gradie
 
 All 72 gradients live in ONE flat fp32 buffer (lunaris_orion_amd.vae), so the exchange is a single collective on a
 contiguous buffer — no bucketing logic, no per-tensor launches.  `FlatGradSync`:
-  * backend "nccl" (= RCCL on ROCm): `all_reduce(AVG)` on a side stream that waits for the backward's event, joined
-    before clip+AdamW; optional fp16 compression of the payload (halves the xGMI bytes; the sum is still taken in
-    the wire dtype by RCCL, so it is off by default to keep DP == single-process to fp32 rounding);
+  * backend "nccl" (= RCCL on ROCm): asynchronous `all_reduce(AVG)` (RCCL's own stream, ordered after the producing
+    kernels), joined before clip+AdamW.  VAEStepper splits the backward in two native calls so that the exchange of
+    the three Linear weight gradients (82 % of the bytes, contiguous in the flat buffer, final after phase 1)
+    overlaps the encoder backward; the conv gradients (42 MB) follow.  Optional fp16 wire format (halves the xGMI
+    bytes; the sum is then taken in fp16, so it is off by default to keep DP == single-process to fp32 rounding);
   * backend "gloo" (CPU tests): SUM then divide (gloo has no AVG).
 The module is pure host logic on top of torch.distributed and is exercised by world-size-2 gloo tests on CPU.
 """
@@ -21,45 +23,55 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None, compress_fp16: bool = False, side_stream: bool = True):
+    """Averages (slices of) the flat gradient buffer across ranks.
+
+    `sync(flat)` = one blocking-in-stream-order exchange.  `begin(slice)` ... `finish()` = asynchronous exchanges
+    (torch.distributed `async_op=True`: the collective is ordered after the work already enqueued on the current
+    stream and runs on the backend's own stream; `finish()` makes the current stream wait for all of them), used by
+    VAEStepper to overlap the exchange of the Linear-layer gradients with the encoder backward.
+    """
+
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, compress_fp16: bool = False, force: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.compress = compress_fp16
-        self.stream = None
-        self._side = side_stream
-        self._wire = None
+        self.force = force              # tests: issue the collectives even in a one-rank group
+        self._pending = []          # (work, wire_or_None, destination)
+        self._wire = {}
+
+    def _op(self):
+        # gloo has no AVG: SUM, divide in finish()
+        return dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM
+
+    def begin(self, g: torch.Tensor) -> None:
+        if (self.world == 1 and not self.force) or g.numel() == 0:
+            return
+        wire = None
+        if self.compress and g.is_cuda:
+            key = (g.data_ptr(), g.numel())
+            wire = self._wire.get(key)
+            if wire is None:
+                wire = self._wire[key] = torch.empty(g.numel(), dtype=torch.float16, device=g.device)
+            wire.copy_(g)
+        work = dist.all_reduce(wire if wire is not None else g, op=self._op(), group=self.group, async_op=True)
+        self._pending.append((work, wire, g))
+
+    def finish(self) -> None:
+        for work, wire, g in self._pending:
+            work.wait()                      # NCCL: the current stream waits; gloo: the host waits
+            if wire is not None:
+                g.copy_(wire)
+            if self.backend != "nccl":
+                g.div_(self.world)
+        self._pending.clear()
 
     def __call__(self, flat_grads: torch.Tensor) -> None:
-        """Average `flat_grads` in place across ranks; returns when the result is ordered on the current stream."""
-        if self.world == 1:
-            return
-        if flat_grads.is_cuda:
-            self._cuda(flat_grads)
-        else:
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
-            flat_grads.div_(self.world)
-
-    def _cuda(self, g: torch.Tensor) -> None:
-        cur = torch.cuda.current_stream()
-        if self._side and self.stream is None:
-            self.stream = torch.cuda.Stream()
-        st = self.stream if self._side else cur
-        if st is not cur:
-            st.wait_stream(cur)                 # the backward that produced `g` ran on `cur`
-        with torch.cuda.stream(st):
-            if self.compress:
-                if self._wire is None or self._wire.numel() != g.numel():
-                    self._wire = torch.empty_like(g, dtype=torch.float16)
-                self._wire.copy_(g)
-                dist.all_reduce(self._wire, op=dist.ReduceOp.AVG, group=self.group)
-                g.copy_(self._wire)
-            else:
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
-        if st is not cur:
-            cur.wait_stream(st)                 # clip + AdamW on `cur` see the averaged gradients
+        """Average `flat_grads` in place across ranks; the result is ordered on the current stream."""
+        self.begin(flat_grads)
+        self.finish()
 
 
 def shard_batch(global_batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
