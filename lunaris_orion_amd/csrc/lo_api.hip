@@ -35,7 +35,7 @@ extern "C" int lo_conv_forward(int kind, int B, int H, int W, int Cin, int Cout,
                                void* stream) {
   LoGeom g;
   LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
-  if (mt_out) *mt_out = (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
+  if (mt_out) *mt_out = lo_conv_mt(g);
   return lo_conv_run(g, (const f16*)in, (const f16*)wp, bias, (const f16*)add_src, (f16*)out, gn_partial, nullptr, 1, S(stream));
 }
 extern "C" int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab,
@@ -168,7 +168,7 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
     LO_TRY(lo_make_geom(&c.gd, dk, B, c.Ho, c.Wo, Cout, Cin));
     c.o_wp_f = ar.take(lo_packed_weight_elems(c.gf) * 2);
     c.o_wp_d = ar.take(lo_packed_weight_elems(c.gd) * 2);
-    c.MT = (c.gf.GH * c.gf.GW / lo_conv_tile_m(c.gf)) * c.gf.n_phase;
+    c.MT = lo_conv_mt(c.gf);
   } else {
     c.Ho = H / 2; c.Wo = W / 2;
     c.o_wp_f = c.o_wp_d = 0;

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   // fused GN-backward reduction: per-thread constants of its 8 channels (the tile lies inside one sample)
   float gsc[8], gsh[8], gmean[8], grstd[8], ga1[8], ga2[8];
   if (a.gb_v) {
-    const int n_img_t = m0 / (g.GH * g.GW);
+    const int n_img_t = m0 >> (g.lgw + g.lgh);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int c = n0 + ochunk * 8 + j;
@@ -407,9 +407,9 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     int m = m0 + ml;
     if (m >= a.M) continue;
     f16x8 h = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
-    int n_img = m / (g.GH * g.GW);
-    int rem = m - n_img * (g.GH * g.GW);
-    int gy = rem / g.GW, gx = rem - gy * g.GW;
+    // the output grid is a power of two in both directions (lo_make_geom checks): shifts, not divisions
+    int n_img = m >> (g.lgw + g.lgh);
+    int gy = (m >> g.lgw) & (g.GH - 1), gx = m & (g.GW - 1);
     int oy = gy * g.out_stride + g.out_oy[phase], ox = gx * g.out_stride + g.out_ox[phase];
     size_t off = ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * g.Cout + n0 + ochunk * 8;
     if (a.add_src) {
@@ -797,6 +797,8 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   int ksteps = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
+  if (a.nsplit == 1 && !gb && lo_conv3_tiles_per_image(g) > 0)
+    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st);   // fused-tap kernel for 3x3 stride-1
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");
     LO_REQUIRE(BK == 64 && g.Cout % 64 == 0, "lo_conv_run: split-K path needs Cin%%64==0 and Cout%%64==0");
@@ -854,6 +856,11 @@ int lo_conv_tile_m(const LoGeom& g) {
   int bm, bn;
   lo_conv_pick_tile(g, &bm, &bn);
   return bm;
+}
+int lo_conv_mt(const LoGeom& g) {
+  int t = lo_conv3_tiles_per_image(g);
+  if (t > 0) return t;
+  return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
 }
 
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit,
