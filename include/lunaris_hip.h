@@ -83,6 +83,17 @@ int lo_final_conv_backward(const void* a4, const float* w, const float* recon, c
                            const float* coef_dev, float gscale, void* da4, float* partial /*B*64*867*/, float* dw,
                            float* db, int B, float scale, void* stream);
 
+/* PixelArtDataset.__getitem__ arithmetic (train_hybrid.py:181-182) for a whole batch on the device:
+ * uint8 HWC [B,128,128,3] -> float32 CHW [B,3,128,128] = x/127.5 - 1. */
+int lo_decode_sprites_u8(const void* u8_hwc, float* out_chw, int B, void* stream);
+
+/* SelfAttention2d.forward (lunar_generate.py:68-78; the module is defined but never instantiated by the reference):
+ * out = gamma * (V softmax(Q^T K)^T) + x with Q,K = 1x1 convs to C/8 channels, V = 1x1 conv to C channels.  x/out fp32
+ * [B,C,N=H*W]; q,k ([B,C/8,N]) and v ([B,C,N]) are caller-provided scratch/outputs.  C and N multiples of 64, C <= 512. */
+int lo_selfattn2d_forward(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+                          const float* bv, const float* gamma, float* q, float* k, float* v, float* out, int B, int C,
+                          int N, void* stream);
+
 /* clip_grad_norm_ + AdamW over one flat fp32 buffer (train_hybrid.py:913,921; :504-509).  scratch: 1024+4 floats;
  * scratch[1024..1026] = (grad norm, clip coef, finite flag) afterwards. */
 int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float max_norm, float lr, float beta1,
@@ -104,6 +115,8 @@ int lo_vae_pack(LoVae* h, const float* flat_params, void* ws, void* stream);
  * MSE partial sums or NULL.  Outputs recon [B,3,128,128], mu, logvar [B,L] (fp32). */
 int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* flat_params, void* ws,
                    float* recon, float* mu, float* logvar, const float* target, void* stream);
+/* decoder only, without skip connections: LunarisCoreVAE.sample (lunar_generate.py:278-291).  z fp32 [B,L]. */
+int lo_vae_decode(LoVae* h, const float* z, const float* flat_params, void* ws, float* recon, void* stream);
 /* reduce the loss partial sums of the last forward; losses_dev[4] = recon_loss, kl_loss, vae_loss, pg_loss.
  * vae_loss = (recon_weight*recon + kl_weight*kl - mean_advantage*recon)/accum  (train_hybrid.py:886-889,895).
  * adv_dev (device scalar) overrides mean_advantage when not NULL.  Also prepares the gradient seeds for

@@ -45,6 +45,8 @@ SIGNATURES = {
     "lo_first_conv_wgrad_op": (i32, [f32p, vp, f32p, f32p, i32, flt, vp]),
     "lo_final_conv_forward": (i32, [vp, f32p, f32p, f32p, f32p, f32p, i32, vp]),
     "lo_final_conv_backward": (i32, [vp, f32p, f32p, f32p, f32p, f32p, flt, vp, f32p, f32p, f32p, i32, flt, vp]),
+    "lo_decode_sprites_u8": (i32, [vp, f32p, i32, vp]),
+    "lo_selfattn2d_forward": (i32, [f32p] * 12 + [i32, i32, i32, vp]),
     "lo_clip_adamw_step": (i32, [f32p, f32p, f32p, f32p, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),
     "lo_vae_create": (i32, [i32, i32, C.POINTER(C.c_void_p)]),
     "lo_vae_destroy": (None, [vp]),
@@ -55,6 +57,7 @@ SIGNATURES = {
     "lo_vae_workspace_bytes": (sz, [vp]),
     "lo_vae_pack": (i32, [vp, f32p, vp, vp]),
     "lo_vae_forward": (i32, [vp, f32p, f32p, u64, f32p, vp, f32p, f32p, f32p, f32p, vp]),
+    "lo_vae_decode": (i32, [vp, f32p, f32p, vp, f32p, vp]),
     "lo_vae_loss": (i32, [vp, vp, flt, flt, flt, f32p, flt, flt, f32p, vp]),
     "lo_vae_backward": (i32, [vp, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),
     "lo_vae_backward_phase": (i32, [vp, i32, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),

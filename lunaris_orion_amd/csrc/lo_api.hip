@@ -93,6 +93,18 @@ extern "C" int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, 
   return lo_adamw(p, g, m, v, n, scratch + 1024, lr, beta1, beta2, eps, weight_decay, step, S(stream));
 }
 
+extern "C" int lo_decode_sprites_u8(const void* u8_hwc, float* out_chw, int B, void* stream) {
+  LO_REQUIRE(u8_hwc && out_chw && B > 0, "lo_decode_sprites_u8: bad argument");
+  return lo_decode_sprites((const uint8_t*)u8_hwc, out_chw, B, S(stream));
+}
+
+extern "C" int lo_selfattn2d_forward(const float* x, const float* wq, const float* bq, const float* wk, const float* bk,
+                                     const float* wv, const float* bv, const float* gamma, float* q, float* k, float* v,
+                                     float* out, int B, int C, int N, void* stream) {
+  LO_REQUIRE(x && wq && bq && wk && bk && wv && bv && gamma && q && k && v && out, "lo_selfattn2d_forward: null argument");
+  return lo_selfattn2d_fwd(x, wq, bq, wk, bk, wv, bv, gamma, q, k, v, out, B, C, N, S(stream));
+}
+
 // =============================================================================================
 // VAE executor
 // =============================================================================================
@@ -388,6 +400,25 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
                    c.Ho * c.Wo, c.Cout, mode, st);
 }
 
+// decoder (lunar_generate.py:194-229) from the latent z (fp16, in the workspace); use_skips=false is the `skips=[]`
+// call of LunarisCoreVAE.sample (:278-291)
+static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* ws, float* recon, const float* target,
+                               hipStream_t st) {
+  const int B = h->B;
+  LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
+                     nullptr, 1, st));
+  LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st));
+  const f16* cur = WSP(f16, h->o_h0);
+  for (int s = 0; s < 4; ++s) {
+    ConvLayer& c = h->dec[s];
+    const f16* skip = (use_skips && s < 3) ? WSP(f16, h->o_eout[2 - s]) : nullptr;
+    LO_TRY(conv_gn(h, c, cur, skip, WSP(f16, c.o_a), skip ? 1 : 0, P, ws, st));
+    cur = WSP(f16, c.o_a);
+  }
+  return lo_final_conv_fwd(cur, PRM(h->idx_final_w), PRM(h->idx_final_b), target, recon, target ? WSP(float, h->o_msep) : nullptr,
+                           B, st);
+}
+
 extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* P, void* ws,
                               float* recon, float* mu, float* logvar, const float* target, void* stream) {
   LO_REQUIRE(h && x && P && ws && recon && mu && logvar, "lo_vae_forward: null argument");
@@ -420,21 +451,18 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
                         WSP(f16, h->o_z), WSP(float, h->o_eps), WSP(float, h->o_klp), B, L, h->head_split, st));
   LO_HIP(hipMemcpyAsync(mu, WSP(float, h->o_mu), (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
   LO_HIP(hipMemcpyAsync(logvar, WSP(float, h->o_lv), (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
-  // ---- decoder (lunar_generate.py:194-229)
-  LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
-                     nullptr, 1, st));
-  LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st));
-  cur = WSP(f16, h->o_h0);
-  for (int s = 0; s < 4; ++s) {
-    ConvLayer& c = h->dec[s];
-    const f16* skip = s < 3 ? WSP(f16, h->o_eout[2 - s]) : nullptr;
-    LO_TRY(conv_gn(h, c, cur, skip, WSP(f16, c.o_a), s < 3 ? 1 : 0, P, ws, st));
-    cur = WSP(f16, c.o_a);
-  }
-  LO_TRY(lo_final_conv_fwd(cur, PRM(h->idx_final_w), PRM(h->idx_final_b), target, recon, target ? WSP(float, h->o_msep) : nullptr,
-                           B, st));
+  LO_TRY(vae_decoder_forward(h, true, P, ws, recon, target, st));
   h->forward_done = true;
   h->loss_done = false;
+  return LO_OK;
+}
+
+extern "C" int lo_vae_decode(LoVae* h, const float* z, const float* P, void* ws, float* recon, void* stream) {
+  LO_REQUIRE(h && z && P && ws && recon, "lo_vae_decode: null argument");
+  hipStream_t st = S(stream);
+  LO_TRY(lo_cast_f32_f16(z, WSP(f16, h->o_z), (size_t)h->B * h->L, st));
+  LO_TRY(vae_decoder_forward(h, false, P, ws, recon, nullptr, st));
+  h->forward_done = false;   // activations no longer belong to a full forward: a backward must not follow
   return LO_OK;
 }
 

@@ -63,3 +63,9 @@ int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st);
 int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st);
 int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
              float eps, float wd, int step, hipStream_t st);
+
+// lo_attn.hip
+int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+                      const float* bv, const float* gamma, float* q, float* k, float* v, float* out, int B, int C, int N,
+                      hipStream_t st);
+int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st);

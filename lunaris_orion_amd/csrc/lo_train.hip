@@ -124,6 +124,20 @@ __global__ void lo_colsum_f16_kernel(const f16* __restrict__ x, float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// sprite decode: uint8 HWC [B,128,128,3] (sprites_*.npy rows) -> float32 CHW, x/127.5 - 1  (train_hybrid.py:181-182)
+// ---------------------------------------------------------------------------------------------
+__global__ void lo_decode_sprites_kernel(const uint8_t* __restrict__ u8, float* __restrict__ out, int npix_total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // one pixel (3 bytes) per thread
+  if (i >= npix_total) return;
+  int n = i >> 14, p = i & 16383;
+  const uint8_t* s = u8 + (size_t)i * 3;
+  float* d = out + (size_t)n * 3 * 16384 + p;
+  d[0] = (float)s[0] / 127.5f - 1.0f;
+  d[16384] = (float)s[1] / 127.5f - 1.0f;
+  d[32768] = (float)s[2] / 127.5f - 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // casts
 // ---------------------------------------------------------------------------------------------
 __global__ void lo_cast_f32_f16_kernel(const float* __restrict__ src, f16* __restrict__ dst, size_t n4) {
@@ -306,5 +320,13 @@ int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float
   hipLaunchKernelGGL(lo_adamw_kernel, dim3(2048), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
                      (float)bc1d, (float)sqrt(bc2d));
   LO_LAUNCH_CHECK("adamw");
+  return LO_OK;
+}
+
+int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st) {
+  int n = B * 16384;
+  LoProfScope _p("lo_decode_sprites", 0, 15.0 * n, st);
+  hipLaunchKernelGGL(lo_decode_sprites_kernel, dim3((n + 255) / 256), dim3(256), 0, st, u8, out, n);
+  LO_LAUNCH_CHECK("decode_sprites");
   return LO_OK;
 }

@@ -101,6 +101,16 @@ class VAEStepper:
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
 
+    def decode_sprites(self, u8_hwc: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,128,128,3] on the device -> normalised float32 [B,3,128,128] (train_hybrid.py:181-182), native kernel."""
+        if u8_hwc.dtype != torch.uint8 or tuple(u8_hwc.shape[1:]) != (128, 128, 3) or not u8_hwc.is_cuda:
+            raise ValueError("expected a CUDA uint8 tensor of shape [B,128,128,3]")
+        u8_hwc = u8_hwc.contiguous()
+        out = torch.empty(u8_hwc.shape[0], 3, 128, 128, dtype=torch.float32, device=u8_hwc.device)
+        _lib.check(_lib.lib.lo_decode_sprites_u8(u8_hwc.data_ptr(), out.data_ptr(), u8_hwc.shape[0], _lib.stream_ptr()),
+                   "lo_decode_sprites_u8")
+        return out
+
     def metrics(self) -> Dict[str, float]:
         """Host copy of the last step's scalars (this synchronises the stream)."""
         v = torch.cat([self.losses, self.scratch[1024:1027]]).cpu().tolist()

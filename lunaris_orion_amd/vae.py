@@ -46,6 +46,39 @@ class ResBlock(nn.Module):
         self.shortcut = nn.Identity()
 
 
+class SelfAttention2d(nn.Module):
+    """Spatial self-attention block of the reference (lunar_generate.py:56-78), which defines it but never instantiates
+    it.  Same parameters (`query_conv`, `key_conv`, `value_conv`, `gamma`); forward is one fused HIP pass
+    (`lo_selfattn2d_forward`: no N x N tensor is materialised).  Forward only in this round: calling it with
+    autograd enabled on its parameters raises."""
+
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.query_conv = nn.Conv2d(in_channels, in_channels // 8, kernel_size=1)
+        self.key_conv = nn.Conv2d(in_channels, in_channels // 8, kernel_size=1)
+        self.value_conv = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _lib.require_gpu()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("SelfAttention2d backward is not built yet: call under torch.no_grad()")
+        if not x.is_cuda:
+            raise _lib.LunarisHipError("SelfAttention2d needs CUDA (ROCm) tensors; there is no CPU path")
+        B, Cc, H, W = x.shape
+        N = H * W
+        x = x.detach().contiguous().float()
+        q = torch.empty(B, Cc // 8, N, dtype=torch.float32, device=x.device)
+        k = torch.empty_like(q)
+        v = torch.empty(B, Cc, N, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        P = [t.detach().contiguous().float() for t in (self.query_conv.weight, self.query_conv.bias, self.key_conv.weight,
+                                                       self.key_conv.bias, self.value_conv.weight, self.value_conv.bias, self.gamma)]
+        _lib.check(_lib.lib.lo_selfattn2d_forward(x.data_ptr(), *[t.data_ptr() for t in P], q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                  out.data_ptr(), B, Cc, N, _lib.stream_ptr()), "lo_selfattn2d_forward")
+        return out
+
+
 class Encoder(nn.Module):
     """Parameter container: 4 x (Conv k3 s2 -> GN -> Mish -> ResBlock), fc_mu, fc_logvar (lunar_generate.py:84-125)."""
 
@@ -228,6 +261,19 @@ class LunarisCoreVAE(nn.Module):
         std = torch.exp(0.5 * logvar)
         return mu + torch.randn_like(std) * std
 
-    def sample(self, num_samples: int):
-        """lunar_generate.py:278-291 (decoder without skips).  Not on the training hot path; not built yet."""
-        raise NotImplementedError("decoder-only sampling (SURVEY §8 F4) is not built in this round")
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """Decoder without skip connections (`self.decoder(z, skips=[])`, lunar_generate.py:290) on the native path."""
+        z = z.detach().contiguous().float()
+        if z.dim() != 2 or z.shape[1] != self.latent_dim:
+            raise ValueError("z must have shape [B, latent_dim]")
+        eng = self._engine(z.shape[0])
+        recon = torch.empty(z.shape[0], 3, 128, 128, dtype=torch.float32, device=z.device)
+        _lib.check(_lib.lib.lo_vae_decode(eng.handle, z.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
+                                          _lib.stream_ptr()), "lo_vae_decode")
+        return recon
+
+    def sample(self, num_samples: int) -> torch.Tensor:
+        """lunar_generate.py:278-291: images from z ~ N(0, I), decoder without skips."""
+        self._ensure_flat()
+        z = torch.randn(num_samples, self.latent_dim, device=self._flat.device)
+        return self.decode(z)

@@ -287,3 +287,32 @@ def test_clip_adamw_matches_torch():
         sync()
         assert abs(scratch[1024].item() - norm.item()) <= 1e-4 * norm.item()
         assert (pd.cpu() - p_ref.detach()).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 64, 8), (2, 128, 16), (1, 512, 8)])
+def test_selfattention2d_forward(B, C, H):
+    """Fused attention vs the oracle restatement (and vs the golden fixture generated from the reference module)."""
+    import os
+
+    import numpy as np
+
+    from lunaris_orion_amd.vae import SelfAttention2d
+    from oracle import vae_ref as R
+    m = SelfAttention2d(C)
+    sd = {}
+    for k, v in m.state_dict().items():
+        t = R.closed_form_tensor("attn." + k, tuple(v.shape))
+        sd[k] = t if v.dim() > 1 else t * 0 + 0.05
+    sd["gamma"] = torch.tensor([0.7])
+    m.load_state_dict(sd)
+    x = R.closed_form_tensor("attn.x", (B, C, H, H)) * 8.0
+    ref = R.self_attention_2d(x, sd["query_conv.weight"], sd["query_conv.bias"], sd["key_conv.weight"], sd["key_conv.bias"],
+                              sd["value_conv.weight"], sd["value_conv.bias"], sd["gamma"])
+    with torch.no_grad():
+        got = m.cuda()(x.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    if (B, C, H) == (2, 64, 8):
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfattn2d.npz"))
+        assert np.abs(got.numpy() - g["y"]).max() <= 2e-5 * max(1.0, np.abs(g["y"]).max())
+    with pytest.raises(NotImplementedError):
+        m(x.cuda().requires_grad_(True))

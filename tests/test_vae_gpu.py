@@ -226,3 +226,25 @@ print("RCCL_PATH_OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "RCCL_PATH_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_decode_without_skips_matches_oracle():
+    """LunarisCoreVAE.sample path: decoder(z, skips=[]) (lunar_generate.py:278-291)."""
+    L, B = 256, 3
+    m, P = _model(L)
+    z = R.closed_form_eps(B, L, salt=5)
+    ref = R.decoder_forward(z, [], P)
+    got = m.decode(z.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 5e-3
+    s = m.sample(2)
+    assert tuple(s.shape) == (2, 3, 128, 128) and torch.isfinite(s).all() and s.abs().max() <= 1.0
+
+
+def test_decode_sprites_matches_dataset_arithmetic():
+    from lunaris_orion_amd.trainer import VAEStepper
+    m, _ = _model(256)
+    st = VAEStepper(m)
+    u8 = R.closed_form_sprites(3)
+    got = st.decode_sprites(u8.cuda()).cpu()
+    ref = R.normalise_sprites(u8)
+    assert (got - ref).abs().max().item() <= 1.2e-7      # x/127.5 - 1 in fp32: at most 1 ulp apart

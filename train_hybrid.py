@@ -106,11 +106,6 @@ class SpriteShards:
         return torch.from_numpy(out)
 
 
-def normalise_on_device(u8_hwc: torch.Tensor, device) -> torch.Tensor:
-    """train_hybrid.py:181-182 on the GPU: uint8 HWC -> float32/127.5 - 1, CHW."""
-    return (u8_hwc.to(device, non_blocking=True).float() / 127.5 - 1.0).permute(0, 3, 1, 2).contiguous()
-
-
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.vae_only:
@@ -203,7 +198,7 @@ def main(argv=None):
         epoch_losses = []
         for b in range(steps_per_epoch):
             idx = np.sort(order[b * per_rank:(b + 1) * per_rank])
-            images = normalise_on_device(data.batch_u8(idx), "cuda")
+            images = stepper.decode_sprites(data.batch_u8(idx).to("cuda", non_blocking=True))
             stepper.step(images, batch_idx=b)
             global_step += 1
             if global_step % args.log_every == 0 or b == steps_per_epoch - 1:
