@@ -93,3 +93,20 @@ def test_scheduler_restatement_matches_torch():
         assert abs(opt.param_groups[0]["lr"] - R.cosine_warm_restarts_lr(1e-4, 1e-6, 10, 2, k)) <= 1e-15
         opt.step()
         sch.step()
+
+
+def test_teacher_oracle_matches_golden():
+    """LunarMoETeacher restatement (oracle/teacher_ref.py) vs the fixture generated from the reference class."""
+    from oracle import teacher_ref as T
+    g = np.load(os.path.join(GOLD, "teacher_B2.npz"))
+    B = int(g["meta"][0])
+    S = T.closed_form_teacher_state()
+    assert len(S) == 351 and sum(1 for k in S if "running" in k or "tracked" in k or "last_spatial" in k) == 99
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    with torch.no_grad():
+        out, new_stats = T.teacher_forward(x, S, training=True)
+    for k in ("quality_scores", "expert_weights", "style_embedding", "prompt_embedding", "semantic_score"):
+        assert np.abs(out[k].numpy() - g["train/" + k]).max() <= 2e-5, k
+    assert np.abs(new_stats["feature_extractor.fusion.2.running_mean"].numpy() - g["train/feature_extractor.fusion.2.running_mean"]).max() <= 1e-5
+    assert int(g["train/attn_nonbias_positions"]) == 543        # the chunk-index write quirk (SURVEY §3.4)
