@@ -130,6 +130,24 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
                     int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                     float* flat_grads, void* stream);
 
+/* ---- LunarMoETeacher.forward as executed (lunar_evaluator.py:408-462; feature_dim 128, dropout off) --------------- */
+typedef struct LoTeacher LoTeacher;
+int lo_teacher_create(int batch, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out);
+void lo_teacher_destroy(LoTeacher* h);
+/* state table in the reference's state_dict order (351 entries at the defaults); float tensors (parameters, BatchNorm
+ * running statistics) live in ONE flat fp32 buffer at these element offsets; offset -1 = integer buffer kept by the host */
+int lo_teacher_num_tensors(const LoTeacher* h);
+const char* lo_teacher_tensor_name(const LoTeacher* h, int index);
+size_t lo_teacher_tensor_numel(const LoTeacher* h, int index);
+long long lo_teacher_tensor_offset(const LoTeacher* h, int index);
+size_t lo_teacher_flat_elems(const LoTeacher* h);
+size_t lo_teacher_workspace_bytes(const LoTeacher* h);
+int lo_teacher_pack(LoTeacher* h, const float* flat_state, void* ws, void* stream);
+/* training != 0: BatchNorm uses batch statistics and updates running_mean / running_var inside flat_state */
+int lo_teacher_forward(LoTeacher* h, const float* x, float* flat_state, void* ws, int training, float* quality_scores,
+                       float* expert_weights, float* style_embedding, float* prompt_embedding, float* semantic_score,
+                       void* stream);
+
 /* The same backward in two calls, for data-parallel overlap: phase 1 = final conv, decoder, decoder.fc, latent, encoder
  * heads (afterwards the gradients of the three Linear layers — 82 % of the bytes, one contiguous range of the flat
  * buffer, see lo_vae_linear_grad_range — are final and can be all-reduced while phase 2 runs); phase 2 = encoder. */

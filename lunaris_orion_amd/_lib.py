@@ -48,6 +48,16 @@ SIGNATURES = {
     "lo_decode_sprites_u8": (i32, [vp, f32p, i32, vp]),
     "lo_selfattn2d_forward": (i32, [f32p] * 12 + [i32, i32, i32, vp]),
     "lo_clip_adamw_step": (i32, [f32p, f32p, f32p, f32p, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),
+    "lo_teacher_create": (i32, [i32, i32, i32, i32, C.POINTER(C.c_void_p)]),
+    "lo_teacher_destroy": (None, [vp]),
+    "lo_teacher_num_tensors": (i32, [vp]),
+    "lo_teacher_tensor_name": (C.c_char_p, [vp, i32]),
+    "lo_teacher_tensor_numel": (sz, [vp, i32]),
+    "lo_teacher_tensor_offset": (C.c_longlong, [vp, i32]),
+    "lo_teacher_flat_elems": (sz, [vp]),
+    "lo_teacher_workspace_bytes": (sz, [vp]),
+    "lo_teacher_pack": (i32, [vp, f32p, vp, vp]),
+    "lo_teacher_forward": (i32, [vp, f32p, f32p, vp, i32, f32p, f32p, f32p, f32p, f32p, vp]),
     "lo_vae_create": (i32, [i32, i32, C.POINTER(C.c_void_p)]),
     "lo_vae_destroy": (None, [vp]),
     "lo_vae_num_params": (i32, [vp]),

@@ -160,6 +160,9 @@ struct IgemmArgs {
   float* slab;         // split-K fp32 partials [nsplit][M][Cout] (SPLITK only)
   // fused GroupNorm-backward reduction (data-gradient ops): the output of this op is dL/da of a conv+GN+Mish layer
   // whose raw conv output is gb_v; the epilogue also emits P1[n][mtile][c] = (sum du, sum du*xhat), du = da*mish'(u)
+  // teacher path: LeakyReLU(0.2) on (conv + bias) and per-channel BatchNorm partial sums of the stored values
+  int act;                 // 0 none, 1 LeakyReLU(0.2)
+  float* bn_partial;       // [M tiles][Cout][2] (sum, sumsq) or null
   const f16* gb_v;
   const float* gb_stats;   // [B][8][2] mean, rstd
   const float* gb_gamma;
@@ -388,6 +391,8 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   // fused GN-backward reduction: per-thread constants of its 8 channels (the tile lies inside one sample)
   float gsc[8], gsh[8], gmean[8], grstd[8], ga1[8], ga2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
   if (a.gb_v) {
     const int n_img_t = m0 >> (g.lgw + g.lgh);
 #pragma unroll
@@ -417,7 +422,15 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) h[j] = (f16)((float)h[j] + (float)r[j]);
     }
+    if (a.act == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float x = (float)h[j]; h[j] = (f16)(x > 0.f ? x : 0.2f * x); }
+    }
     *reinterpret_cast<f16x8*>(a.out + off) = h;
+    if (a.bn_partial) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float x = (float)h[j]; ga1[j] += x; ga2[j] += x * x; }
+    }
     if (a.gb_v) {
       f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
 #pragma unroll
@@ -434,6 +447,22 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
 #pragma unroll
       for (int j = 4; j < 8; ++j) { float x = (float)h[j]; s1 += x; q1 += x * x; }
     }
+  }
+  if (a.bn_partial) {
+    // per-channel (sum, sumsq) of this tile, fixed summation order -> bn_partial[m tile][channel][2]
+    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);   // [256][16] floats
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j * 2] = ga1[j]; red[tid * 16 + j * 2 + 1] = ga2[j]; }
+    __syncthreads();
+    float* dst = a.bn_partial + ((size_t)(phase * MT + mt_i) * g.Cout + n0) * 2;
+    for (int o = tid; o < BN * 2; o += 256) {
+      int cl = o >> 1, w = o & 1;
+      int ccx = cl >> 3, j = cl & 7;
+      float tot = 0.f;
+      for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
+      dst[o] = tot;
+    }
+    __syncthreads();
   }
   if (a.gb_v) {
     // reduce (ga1, ga2) over the row slots in a fixed order: BN*2 outputs, one per thread (looped)
@@ -782,11 +811,12 @@ void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out);
 
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb) {
+                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb, const LoConvExtra* ex) {
   IgemmArgs a;
   a.in = in; a.w = wp; a.bias = bias; a.add_src = add_src; a.out = out; a.gn_partial = gn_partial; a.slab = slab;
   a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
   a.gb_beta = gb ? gb->beta : nullptr; a.gb_P1 = gb ? gb->P1 : nullptr;
+  a.act = ex ? ex->act : 0; a.bn_partial = ex ? ex->bn_partial : nullptr;
   a.g = g;
   a.M = g.B * g.GH * g.GW;
   a.nsplit = nsplit < 1 ? 1 : nsplit;
@@ -797,7 +827,7 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   int ksteps = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
-  if (a.nsplit == 1 && !gb && lo_conv3_tiles_per_image(g) > 0)
+  if (a.nsplit == 1 && !gb && !ex && lo_conv3_tiles_per_image(g) > 0)
     return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st);   // fused-tap kernel for 3x3 stride-1
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");

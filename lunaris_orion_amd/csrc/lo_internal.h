@@ -8,8 +8,10 @@ const char* lo_get_error();
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
 int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st);
 struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
+struct LoConvExtra { int act; float* bn_partial; };   // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr);
+                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr,
+                const LoConvExtra* ex = nullptr);
 int lo_conv_tile_m(const LoGeom& g);
 int lo_conv_mt(const LoGeom& g);   // GroupNorm partial rows per sample the conv epilogue writes for this geometry
 int lo_conv3_tiles_per_image(const LoGeom& g);

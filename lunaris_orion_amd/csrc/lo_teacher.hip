@@ -1,0 +1,644 @@
+// LunarMoETeacher.forward AS EXECUTED by the reference (lunar_evaluator.py:57-462), forward
+// only (the VAE never receives teacher gradients), dropout off (parity) — fp16 NHWC activations, fp32
+// BatchNorm statistics.  The 24 full-resolution 3x3 convolutions and every 1x1 convolution run on lo_igemm_nt with the
+// teacher epilogue (bias + LeakyReLU + per-channel BatchNorm partial sums); this file adds the glue kernels:
+//   first conv 3->32 (direct), depthwise 3x3/5x5 with BatchNorm-on-load, BatchNorm finalize (batch or running
+//   statistics, running-stat update), BatchNorm apply (+ concat / + layer-scale, identity, LeakyReLU block tail),
+//   the chunk-local attention with the reference's write-offset quirk, global average pooling, and the gate /
+//   quality / semantic / embedding heads (one workgroup per sample).
+#include "lo_internal.h"
+#include "../../include/lunaris_hip.h"
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#define T_HW 16384
+#define T_W 128
+#define BN_EPS 1e-5f
+#define LN_EPS 1e-5f
+
+// ---------------------------------------------------------------------------------------------
+// first conv: x fp32 NCHW [B,3,128,128] -> lrelu(conv3x3 s1 p1 + bias) fp16 NHWC [B,128,128,32]; BN partials per image row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_t_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, f16* __restrict__ out,
+                                                         float* __restrict__ bn_partial) {
+  __shared__ float xs[3][3][T_W + 2];
+  __shared__ float ws[27][32];
+  __shared__ float red[256][2];
+  const int tid = threadIdx.x, oy = blockIdx.x, n = blockIdx.y;
+  for (int i = tid; i < 3 * 3 * (T_W + 2); i += 256) {
+    int col = i % (T_W + 2), r = (i / (T_W + 2)) % 3, ci = i / (3 * (T_W + 2));
+    int iy = oy - 1 + r, ix = col - 1;
+    float v = 0.f;
+    if ((unsigned)iy < 128u && (unsigned)ix < 128u) v = x[(((size_t)n * 3 + ci) * 128 + iy) * 128 + ix];
+    xs[ci][r][col] = v;
+  }
+  for (int i = tid; i < 27 * 32; i += 256) ws[i / 32][i % 32] = w[(i % 32) * 27 + i / 32];
+  __syncthreads();
+  const int px = tid >> 1, cg = tid & 1;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        float xv = xs[ci][r][px + s];
+        const float* wr = &ws[ci * 9 + r * 3 + s][cg * 16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += xv * wr[j];
+      }
+  f16x8 h0, h1;
+  float vals[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float a = acc[j] > 0.f ? acc[j] : 0.2f * acc[j];
+    f16 hh = (f16)a;
+    if (j < 8) h0[j] = hh; else h1[j - 8] = hh;
+    vals[j] = (float)hh;
+  }
+  f16* dst = out + (((size_t)n * 128 + oy) * 128 + px) * 32 + cg * 16;
+  *reinterpret_cast<f16x8*>(dst) = h0;
+  *reinterpret_cast<f16x8*>(dst + 8) = h1;
+  // per-channel sums over the 128 pixels of this row: 16 rounds of a block reduction (channel j of each half)
+  float* dstp = bn_partial + ((size_t)n * 128 + oy) * 32 * 2;
+  for (int j = 0; j < 16; ++j) {
+    red[tid][0] = vals[j];
+    red[tid][1] = vals[j] * vals[j];
+    __syncthreads();
+    if (tid < 4) {                       // (cg, which)
+      int c2 = tid >> 1, which = tid & 1;
+      float t = 0.f;
+      for (int p = 0; p < 128; ++p) t += red[p * 2 + c2][which];
+      dstp[(c2 * 16 + j) * 2 + which] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm finalize: partial [nrow][C][2] -> ss[C][2] = (scale, shift);  training: batch statistics + running-stat
+// update (momentum 0.1, unbiased variance); eval: running statistics.  Optionally pooled[n][c] = mean over the sample of
+// the NORMALISED tensor (= scale * mean_n(raw) + shift), from the same partials (rows_per_sample rows per sample).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __restrict__ partial, int nrow, int C, float count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar, int training,
+                                                             float* __restrict__ ss) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C && training)
+    for (int k = r; k < nrow; k += 16) {
+      f32x2 p = *reinterpret_cast<const f32x2*>(partial + ((size_t)k * C + c) * 2);
+      s += (double)p[0];
+      q += (double)p[1];
+    }
+  red[0][r][cl] = s; red[1][r][cl] = q;
+  __syncthreads();
+  if (r == 0 && c < C) {
+    float mean, var;
+    if (training) {
+      double ts = 0.0, tq = 0.0;
+      for (int k = 0; k < 16; ++k) { ts += red[0][k][cl]; tq += red[1][k][cl]; }
+      double m = ts / (double)count;
+      double v = tq / (double)count - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = (float)m; var = (float)v;
+      rmean[c] = 0.9f * rmean[c] + 0.1f * mean;
+      rvar[c] = 0.9f * rvar[c] + 0.1f * (float)(v * (double)count / ((double)count - 1.0));
+    } else {
+      mean = rmean[c]; var = rvar[c];
+    }
+    float sc = gamma[c] / sqrtf(var + BN_EPS);
+    ss[c * 2] = sc;
+    ss[c * 2 + 1] = beta[c] - mean * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm apply (elementwise, 16-byte vectors over channels)
+//   y[pix][dst_off + c] = raw[pix][c]*scale[c] + shift[c]                                   (mode 0; dst pitch for concat)
+//   y = lrelu( (raw*scale + shift) * ls[c] + identity , 0.2 )                               (mode 1: ExpertBlock tail)
+// optional pool_partial[n][chunk][C] = per-sample, per-channel sums of y (global average pooling)
+// ---------------------------------------------------------------------------------------------
+struct BnApplyArgs {
+  const f16* raw; const float* ss; const float* ls; const f16* identity; f16* y; float* pool_partial;
+  int C, dst_pitch, dst_off, mode, rows_per_block;
+};
+__global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
+  __shared__ float s_red[256 * 8];
+  const int tid = threadIdx.x, n = blockIdx.y, blk = blockIdx.x;
+  const int C = a.C, CC = C >> 3;
+  const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
+  const int c0 = cc * 8;
+  float sc[8], sh[8], lsv[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.ss[(c0 + j) * 2];
+    sh[j] = a.ss[(c0 + j) * 2 + 1];
+    lsv[j] = a.mode == 1 ? a.ls[c0 + j] : 1.f;
+    acc[j] = 0.f;
+  }
+  const size_t row0 = (size_t)n * T_HW + (size_t)blk * a.rows_per_block;
+  constexpr int U = 4;
+  for (int r = slot; r < a.rows_per_block; r += U * nslot) {
+    f16x8 h[U], idv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < a.rows_per_block) {
+        h[u] = *reinterpret_cast<const f16x8*>(a.raw + (row0 + rr) * C + c0);
+        if (a.mode == 1) idv[u] = *reinterpret_cast<const f16x8*>(a.identity + (row0 + rr) * C + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int rr = r + u * nslot;
+      if (rr < a.rows_per_block) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = (float)h[u][j] * sc[j] + sh[j];
+          if (a.mode == 1) {
+            v = v * lsv[j] + (float)idv[u][j];
+            v = v > 0.f ? v : 0.2f * v;
+          }
+          o[j] = (f16)v;
+          acc[j] += (float)o[j];
+        }
+        *reinterpret_cast<f16x8*>(a.y + (row0 + rr) * a.dst_pitch + a.dst_off + c0) = o;
+      }
+    }
+  }
+  if (a.pool_partial) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      int ccx = c >> 3, j = c & 7;
+      float tot = 0.f;
+      for (int s = 0; s < nslot; ++s) tot += s_red[(s * CC + ccx) * 8 + j];
+      a.pool_partial[((size_t)n * gridDim.x + blk) * C + c] = tot;
+    }
+  }
+}
+
+// pooled[n][c] = sum_blk partial[n][blk][c] / HW
+__global__ void lo_pool_finalize_kernel(const float* __restrict__ partial, float* __restrict__ pooled, int nblk, int C, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int n = i / C, c = i - n * C;
+  float t = 0.f;
+  for (int k = 0; k < nblk; ++k) t += partial[((size_t)n * nblk + k) * C + c];
+  pooled[i] = t * (1.0f / (float)T_HW);
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise KxK conv (groups = 32) on BN(raw1): out[pix][c] = bias[c] + sum_taps w[c][tap] * (raw1[pix+tap][c]*scale[c]+shift[c])
+// (zero padding applies to the normalised tensor).  thread = (pixel, 8-channel chunk)
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void lo_t_dwconv_kernel(const f16* __restrict__ raw, const float* __restrict__ ss,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          f16* __restrict__ out, int B) {
+  __shared__ float ws[K * K][32];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * K * 32; i += 256) ws[i / 32][i % 32] = w[(i % 32) * K * K + i / 32];
+  __syncthreads();
+  const size_t gid = (size_t)blockIdx.x * 256 + tid;
+  const size_t pix = gid >> 2;
+  const int c0 = (int)(gid & 3) * 8;
+  if (pix >= (size_t)B * T_HW) return;
+  const int n = (int)(pix >> 14), p = (int)(pix & 16383), y = p >> 7, x = p & 127;
+  float sc[8], sh[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = ss[(c0 + j) * 2]; sh[j] = ss[(c0 + j) * 2 + 1]; acc[j] = bias[c0 + j]; }
+#pragma unroll 1
+  for (int r = 0; r < K; ++r) {
+    int iy = y + r - K / 2;
+    if ((unsigned)iy >= 128u) continue;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      int ix = x + s - K / 2;
+      if ((unsigned)ix >= 128u) continue;
+      f16x8 h = *reinterpret_cast<const f16x8*>(raw + (((size_t)n * 128 + iy) * 128 + ix) * 32 + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += ws[r * K + s][c0 + j] * ((float)h[j] * sc[j] + sh[j]);
+    }
+  }
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
+  *reinterpret_cast<f16x8*>(out + pix * 32 + c0) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunk-local attention with the reference's offset quirk (lunar_evaluator.py:203-216): one wave per written position.
+//   position p <  512 : query = token 32p        (row 0 of chunk p),      keys/values = chunk p
+//   position p >= 512 : query = token 32*511+r,  r = p - 511 (rows 1..31), keys/values = chunk 511
+// qkv: [B][16384][384] fp16, channel = t*128 + head*16 + d.  att: [B][16384][128] fp16 (positions >= 543 stay zero).
+// lane = (head = lane>>3, part = lane&7: keys 4*part..4*part+3)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_t_attn_kernel(const f16* __restrict__ qkv, f16* __restrict__ att, int B) {
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int per_b = 512 + 31;
+  if (wave_g >= B * per_b) return;
+  const int b = wave_g / per_b, p = wave_g - b * per_b;
+  const int chunk = p < 512 ? p : 511;
+  const int qtok = p < 512 ? 32 * p : 32 * 511 + (p - 511);
+  const int head = lane >> 3, part = lane & 7;
+  const f16* base = qkv + (size_t)b * T_HW * 384;
+  f16x8 q0 = *reinterpret_cast<const f16x8*>(base + (size_t)qtok * 384 + head * 16);
+  f16x8 q1 = *reinterpret_cast<const f16x8*>(base + (size_t)qtok * 384 + head * 16 + 8);
+  float sc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16* kp = base + (size_t)(32 * chunk + part * 4 + k) * 384 + 128 + head * 16;
+    f16x8 k0 = *reinterpret_cast<const f16x8*>(kp), k1 = *reinterpret_cast<const f16x8*>(kp + 8);
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) s += (float)q0[d] * (float)k0[d] + (float)q1[d] * (float)k1[d];
+    sc[k] = s * 0.25f;   // head_dim ** -0.5 = 16 ** -0.5; the relative-position term is constant along keys: no effect
+  }
+  float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float e[4], l = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { e[k] = __expf(sc[k] - m); l += e[k]; }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) l += __shfl_xor(l, o, 64);
+  float acc[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16* vp = base + (size_t)(32 * chunk + part * 4 + k) * 384 + 256 + head * 16;
+    f16x8 v0 = *reinterpret_cast<const f16x8*>(vp), v1 = *reinterpret_cast<const f16x8*>(vp + 8);
+    float pw = e[k] / l;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { acc[d] += pw * (float)v0[d]; acc[8 + d] += pw * (float)v1[d]; }
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) acc[d] += __shfl_xor(acc[d], o, 64);
+  if (part == 0) {
+    f16x8 o0, o1;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { o0[d] = (f16)acc[d]; o1[d] = (f16)acc[8 + d]; }
+    f16* dst = att + ((size_t)b * T_HW + p) * 128 + head * 16;
+    *reinterpret_cast<f16x8*>(dst) = o0;
+    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// heads: one workgroup (256 threads) per sample; everything fp32 in LDS
+//   gate: pooled_f[128] -> Linear(128,I) -> lrelu -> Linear(I,E) -> softmax
+//   per expert: pooled_e -> LayerNorm -> Linear(128,I/4) -> lrelu -> Linear(I/4,4)
+//   semantic (expert 0): LN -> Linear(128,I/2) -> lrelu -> Linear(I/2,1) -> sigmoid
+//   comb = sum_e w_e pooled_e ; style / prompt: LN -> Linear(128,I/2) -> lrelu -> Linear(I/2,emb)
+// ---------------------------------------------------------------------------------------------
+struct HeadW { const float *ln_w, *ln_b, *w1, *b1, *w2, *b2; };
+struct HeadsArgs {
+  const float* pooled_f;         // [B][128]
+  const float* pooled_e;         // [E][B][128]
+  const float *g_w1, *g_b1, *g_w2, *g_b2;
+  HeadW q[8];
+  HeadW sem, style, prompt;
+  float *quality, *weights, *style_out, *prompt_out, *sem_out;   // [B][4], [B][E], [B][emb], [B][emb], [B][1]
+  float* raw_q;                  // [B][E][4] pre-weighting quality logits (kept for the backward)
+  int B, E, I, emb;
+};
+__device__ void t_layernorm(const float* x, const float* w, const float* b, float* y, float* scratch, int tid) {
+  // 128 features; threads 0..127
+  float v = tid < 128 ? x[tid] : 0.f;
+  float s = lo_wave_sum(v);
+  if ((tid & 63) == 0) scratch[tid >> 6] = s;
+  __syncthreads();
+  float mean = (scratch[0] + scratch[1]) / 128.f;
+  __syncthreads();
+  float d = tid < 128 ? v - mean : 0.f;
+  float q = lo_wave_sum(d * d);
+  if ((tid & 63) == 0) scratch[tid >> 6] = q;
+  __syncthreads();
+  float var = (scratch[0] + scratch[1]) / 128.f;
+  if (tid < 128) y[tid] = d / sqrtf(var + LN_EPS) * w[tid] + b[tid];
+  __syncthreads();
+}
+__device__ void t_linear(const float* x, int nin, const float* w, const float* b, float* y, int nout, int lrelu, int tid) {
+  for (int o = tid; o < nout; o += 256) {
+    float acc = b[o];
+    for (int i = 0; i < nin; ++i) acc += w[o * nin + i] * x[i];
+    y[o] = (lrelu && acc < 0.f) ? 0.2f * acc : acc;
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
+  __shared__ float xin[128], xn[128], h1[256], o2[512], wts[8], ql[8][4], scratch[8], comb[128];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  // gate
+  if (tid < 128) xin[tid] = a.pooled_f[n * 128 + tid];
+  __syncthreads();
+  t_linear(xin, 128, a.g_w1, a.g_b1, h1, a.I, 1, tid);
+  t_linear(h1, a.I, a.g_w2, a.g_b2, o2, a.E, 0, tid);
+  if (tid == 0) {
+    float m = -INFINITY, l = 0.f;
+    for (int e = 0; e < a.E; ++e) m = fmaxf(m, o2[e]);
+    for (int e = 0; e < a.E; ++e) { wts[e] = __expf(o2[e] - m); l += wts[e]; }
+    for (int e = 0; e < a.E; ++e) { wts[e] /= l; a.weights[n * a.E + e] = wts[e]; }
+  }
+  __syncthreads();
+  if (tid < 128) comb[tid] = 0.f;
+  __syncthreads();
+  for (int e = 0; e < a.E; ++e) {
+    if (tid < 128) { xin[tid] = a.pooled_e[((size_t)e * a.B + n) * 128 + tid]; comb[tid] += wts[e] * xin[tid]; }
+    __syncthreads();
+    t_layernorm(xin, a.q[e].ln_w, a.q[e].ln_b, xn, scratch, tid);
+    t_linear(xn, 128, a.q[e].w1, a.q[e].b1, h1, a.I / 4, 1, tid);
+    t_linear(h1, a.I / 4, a.q[e].w2, a.q[e].b2, o2, 4, 0, tid);
+    if (tid < 4) { ql[e][tid] = o2[tid]; a.raw_q[((size_t)n * a.E + e) * 4 + tid] = o2[tid]; }
+    __syncthreads();
+    if (e == 0) {
+      t_layernorm(xin, a.sem.ln_w, a.sem.ln_b, xn, scratch, tid);
+      t_linear(xn, 128, a.sem.w1, a.sem.b1, h1, a.I / 2, 1, tid);
+      t_linear(h1, a.I / 2, a.sem.w2, a.sem.b2, o2, 1, 0, tid);
+      if (tid == 0) a.sem_out[n] = 1.f / (1.f + __expf(-o2[0]));
+      __syncthreads();
+    }
+  }
+  if (tid < 4) {
+    float t = 0.f;
+    for (int e = 0; e < a.E; ++e) t += ql[e][tid] * wts[e];
+    a.quality[n * 4 + tid] = 1.f / (1.f + __expf(-t));
+  }
+  __syncthreads();
+  for (int which = 0; which < 2; ++which) {
+    const HeadW& hw = which ? a.prompt : a.style;
+    float* dst = which ? a.prompt_out : a.style_out;
+    t_layernorm(comb, hw.ln_w, hw.ln_b, xn, scratch, tid);
+    t_linear(xn, 128, hw.w1, hw.b1, h1, a.I / 2, 1, tid);
+    t_linear(h1, a.I / 2, hw.w2, hw.b2, o2, a.emb, 0, tid);
+    for (int o = tid; o < a.emb; o += 256) dst[(size_t)n * a.emb + o] = o2[o];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan / executor
+// ---------------------------------------------------------------------------------------------
+struct LoTeacher {
+  int B, E, I, emb, layers;
+  std::vector<std::string> names;
+  std::vector<size_t> off, numel;
+  std::vector<char> is_float;
+  size_t flat_elems;
+  // workspace offsets
+  size_t o_raw32, o_dw, o_br[3], o_cat, o_feat, o_x0, o_x1, o_rawA, o_bnA, o_qkv, o_att, o_proj, o_rawB;
+  size_t o_bnp, o_ss, o_poolp, o_pool_f, o_pool_e, o_rawq;
+  size_t o_wp3[8][3][2];      // packed 3x3 weights (expert, layer, conv1/conv2)
+  size_t o_wqkv[8][3], o_wproj[8][3], o_wpw[3], o_wfus;
+  LoGeom g3, gq, gp, gpw, gfus;
+  size_t ws_bytes;
+  bool att_zeroed;
+  const void* att_zeroed_ws;
+};
+
+static size_t t_idx(const LoTeacher* h, const std::string& k) {
+  for (size_t i = 0; i < h->names.size(); ++i) if (h->names[i] == k) return i;
+  return (size_t)-1;
+}
+#define TP(name) (P + h->off[t_idx(h, name)])
+#define TW(T, o) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (o))
+#define LO_TRYT(call) do { int _r = (call); if (_r != LO_OK) return _r; } while (0)
+
+extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out) {
+  LO_REQUIRE(out && B >= 1, "lo_teacher_create: bad argument");
+  LO_REQUIRE(feature_dim == 128, "lo_teacher_create: feature_dim %d is not built (only the CLI default 128)", feature_dim);
+  LO_REQUIRE(num_experts >= 1 && num_experts <= 8, "lo_teacher_create: num_experts %d out of range", num_experts);
+  LO_REQUIRE(embedding_dim >= 1 && embedding_dim <= 512, "lo_teacher_create: embedding_dim %d out of range", embedding_dim);
+  LoTeacher* h = new LoTeacher();
+  h->B = B; h->E = num_experts; h->I = 256; h->emb = embedding_dim; h->layers = 3;
+  h->att_zeroed = false; h->att_zeroed_ws = nullptr;
+  // ---- state table in the reference's state_dict order (lunar_evaluator.py; checked against the oracle in tests)
+  auto add = [&](const std::string& k, size_t n, bool f = true) { h->names.push_back(k); h->numel.push_back(n); h->is_float.push_back(f); };
+  auto conv = [&](const std::string& p, int co, int ci, int k, int groups = 1) { add(p + ".weight", (size_t)co * (ci / groups) * k * k); add(p + ".bias", co); };
+  auto bn = [&](const std::string& p, int c) { add(p + ".weight", c); add(p + ".bias", c); add(p + ".running_mean", c); add(p + ".running_var", c); add(p + ".num_batches_tracked", 1, false); };
+  auto lin = [&](const std::string& p, int o, int i) { add(p + ".weight", (size_t)o * i); add(p + ".bias", o); };
+  std::string fe = "feature_extractor";
+  conv(fe + ".conv1.0", 32, 3, 3); bn(fe + ".conv1.2", 32);
+  const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
+  const int brk[3] = {3, 5, 3};
+  for (int b = 0; b < 3; ++b) {
+    std::string q = fe + "." + brs[b];
+    conv(q + ".0", 32, 32, brk[b], 32); conv(q + ".1", 64, 32, 1); bn(q + ".3", 64);
+  }
+  conv(fe + ".fusion.0", 128, 192, 1); bn(fe + ".fusion.2", 128);
+  for (int e = 0; e < num_experts; ++e)
+    for (int l = 0; l < 3; ++l) {
+      std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
+      add(p + ".layer_scale", 128);
+      conv(p + ".conv1.0", 128, 128, 3); bn(p + ".conv1.2", 128);
+      add(p + ".attention.rel_pos_h", 64); add(p + ".attention.rel_pos_w", 64); add(p + ".attention.last_spatial_shapes", 2);
+      conv(p + ".attention.qkv", 384, 128, 1); conv(p + ".attention.proj", 128, 128, 1);
+      conv(p + ".conv2.0", 128, 128, 3); bn(p + ".conv2.2", 128);
+    }
+  lin("gate.2", 256, 128); lin("gate.5", num_experts, 256);
+  for (int e = 0; e < num_experts; ++e) {
+    std::string p = "quality_heads." + std::to_string(e);
+    add(p + ".2.weight", 128); add(p + ".2.bias", 128); lin(p + ".3", 64, 128); lin(p + ".6", 4, 64);
+  }
+  const char* hn[3] = {"semantic_head", "style_net", "prompt_net"};
+  const int ho[3] = {1, embedding_dim, embedding_dim};
+  for (int k = 0; k < 3; ++k) {
+    std::string p = hn[k];
+    add(p + ".2.weight", 128); add(p + ".2.bias", 128); lin(p + ".3", 128, 128); lin(p + ".6", ho[k], 128);
+  }
+  size_t o = 0;
+  h->off.assign(h->names.size(), 0);
+  for (size_t i = 0; i < h->names.size(); ++i) {
+    h->off[i] = o;
+    if (h->is_float[i]) o += (h->numel[i] + 63) & ~(size_t)63;
+  }
+  h->flat_elems = o;
+  // ---- geometry + workspace
+  LO_TRYT(lo_make_geom(&h->g3, LO_CONV3_S1, B, 128, 128, 128, 128));
+  LO_TRYT(lo_make_geom(&h->gq, LO_LINEAR, B, 128, 128, 128, 384));
+  LO_TRYT(lo_make_geom(&h->gp, LO_LINEAR, B, 128, 128, 128, 128));
+  LO_TRYT(lo_make_geom(&h->gpw, LO_LINEAR, B, 128, 128, 32, 64));
+  LO_TRYT(lo_make_geom(&h->gfus, LO_LINEAR, B, 128, 128, 192, 128));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
+  const size_t px = (size_t)B * T_HW;
+  h->o_raw32 = take(px * 32 * 2); h->o_dw = take(px * 32 * 2);
+  for (int b = 0; b < 3; ++b) h->o_br[b] = take(px * 64 * 2);
+  h->o_cat = take(px * 192 * 2);
+  h->o_feat = take(px * 128 * 2); h->o_x0 = take(px * 128 * 2); h->o_x1 = take(px * 128 * 2);
+  h->o_rawA = take(px * 128 * 2); h->o_bnA = take(px * 128 * 2); h->o_qkv = take(px * 384 * 2);
+  h->o_att = take(px * 128 * 2); h->o_proj = take(px * 128 * 2); h->o_rawB = take(px * 128 * 2);
+  h->o_bnp = take((size_t)B * 128 * 128 * 2 * 4 + 65536);   // rows <= B*128, C <= 128
+  h->o_ss = take(192 * 2 * 4 + 256);
+  h->o_poolp = take((size_t)B * 64 * 128 * 4);
+  h->o_pool_f = take((size_t)B * 128 * 4);
+  h->o_pool_e = take((size_t)num_experts * B * 128 * 4);
+  h->o_rawq = take((size_t)B * num_experts * 4 * 4);
+  for (int e = 0; e < num_experts; ++e)
+    for (int l = 0; l < 3; ++l) {
+      for (int c = 0; c < 2; ++c) h->o_wp3[e][l][c] = take((size_t)128 * 9 * 128 * 2);
+      h->o_wqkv[e][l] = take((size_t)384 * 128 * 2);
+      h->o_wproj[e][l] = take((size_t)128 * 128 * 2);
+    }
+  for (int b = 0; b < 3; ++b) h->o_wpw[b] = take((size_t)64 * 32 * 2);
+  h->o_wfus = take((size_t)128 * 192 * 2);
+  h->ws_bytes = off;
+  *out = h;
+  return LO_OK;
+}
+extern "C" void lo_teacher_destroy(LoTeacher* h) { delete h; }
+extern "C" int lo_teacher_num_tensors(const LoTeacher* h) { return (int)h->names.size(); }
+extern "C" const char* lo_teacher_tensor_name(const LoTeacher* h, int i) { return (i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : nullptr; }
+extern "C" size_t lo_teacher_tensor_numel(const LoTeacher* h, int i) { return (i >= 0 && i < (int)h->names.size()) ? h->numel[i] : 0; }
+extern "C" long long lo_teacher_tensor_offset(const LoTeacher* h, int i) {   // -1 for non-float buffers (kept by the host)
+  if (i < 0 || i >= (int)h->names.size() || !h->is_float[i]) return -1;
+  return (long long)h->off[i];
+}
+extern "C" size_t lo_teacher_flat_elems(const LoTeacher* h) { return h->flat_elems; }
+extern "C" size_t lo_teacher_workspace_bytes(const LoTeacher* h) { return h->ws_bytes; }
+
+extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* stream) {
+  LO_REQUIRE(h && P && ws, "lo_teacher_pack: null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int e = 0; e < h->E; ++e)
+    for (int l = 0; l < 3; ++l) {
+      std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
+      LO_TRYT(lo_pack_weight(TP(p + ".conv1.0.weight"), TW(f16, h->o_wp3[e][l][0]), h->g3, st));
+      LO_TRYT(lo_pack_weight(TP(p + ".conv2.0.weight"), TW(f16, h->o_wp3[e][l][1]), h->g3, st));
+      LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.qkv.weight"), TW(f16, h->o_wqkv[e][l]), (size_t)384 * 128, st));
+      LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.proj.weight"), TW(f16, h->o_wproj[e][l]), (size_t)128 * 128, st));
+    }
+  const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
+  for (int b = 0; b < 3; ++b)
+    LO_TRYT(lo_cast_f32_f16(TP(std::string("feature_extractor.") + brs[b] + ".1.weight"), TW(f16, h->o_wpw[b]), (size_t)64 * 32, st));
+  LO_TRYT(lo_cast_f32_f16(TP("feature_extractor.fusion.0.weight"), TW(f16, h->o_wfus), (size_t)128 * 192, st));
+  return LO_OK;
+}
+
+static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, const std::string& bnp, float* P, void* ws,
+                         int training, hipStream_t st) {
+  LoProfScope _p("lo_bn_finalize", 0, 0, st);
+  hipLaunchKernelGGL(lo_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nrow, C, (float)((size_t)h->B * T_HW),
+                     TP(bnp + ".weight"), TP(bnp + ".bias"), TP(bnp + ".running_mean"), TP(bnp + ".running_var"), training,
+                     TW(float, h->o_ss));
+  LO_LAUNCH_CHECK("bn_finalize");
+  return LO_OK;
+}
+static int t_bn_apply(LoTeacher* h, const f16* raw, const float* ls, const f16* identity, f16* y, int C, int dst_pitch, int dst_off,
+                      int mode, float* pool_partial, void* ws, hipStream_t st) {
+  BnApplyArgs a{raw, TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode, T_HW / 64};
+  LoProfScope _p("lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode ? 3 : 2), st);
+  hipLaunchKernelGGL(lo_bn_apply_kernel, dim3(64, h->B), dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("bn_apply");
+  return LO_OK;
+}
+static int t_pool(LoTeacher* h, float* pooled, int C, void* ws, hipStream_t st) {
+  int total = h->B * C;
+  hipLaunchKernelGGL(lo_pool_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, TW(float, h->o_poolp), pooled, 64, C, total);
+  LO_LAUNCH_CHECK("pool_finalize");
+  return LO_OK;
+}
+
+// x: fp32 NCHW images.  P: flat state (parameters AND BatchNorm running statistics; the latter are updated in place when
+// training != 0).  outputs: quality_scores [B,4], expert_weights [B,E], style/prompt embeddings [B,emb], semantic [B,1].
+extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* ws, int training, float* quality, float* weights,
+                                  float* style, float* prompt, float* semantic, void* stream) {
+  LO_REQUIRE(h && x && P && ws && quality && weights && style && prompt && semantic, "lo_teacher_forward: null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int B = h->B;
+  const size_t px = (size_t)B * T_HW;
+  if (!h->att_zeroed || h->att_zeroed_ws != ws) {
+    LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
+    h->att_zeroed = true; h->att_zeroed_ws = ws;
+  }
+  float* bnp = TW(float, h->o_bnp);
+  LoConvExtra ex{1, bnp};
+  std::string fe = "feature_extractor";
+  // ---- feature extractor (lunar_evaluator.py:105-112)
+  {
+    LoProfScope _p("lo_t_conv1", 2.0 * px * 32 * 27, 0, st);
+    hipLaunchKernelGGL(lo_t_conv1_kernel, dim3(128, B), dim3(256), 0, st, x, TP(fe + ".conv1.0.weight"), TP(fe + ".conv1.0.bias"),
+                       TW(f16, h->o_raw32), bnp);
+  }
+  LO_LAUNCH_CHECK("t_conv1");
+  LO_TRYT(t_bn_finalize(h, bnp, B * 128, 32, fe + ".conv1.2", P, ws, training, st));
+  // the depthwise convs read BN(conv1) through (scale, shift) of o_ss: keep a private copy, o_ss is reused below
+  float* ss32 = TW(float, h->o_ss) + 2 * 192;
+  LO_HIP(hipMemcpyAsync(ss32, TW(float, h->o_ss), 32 * 2 * 4, hipMemcpyDeviceToDevice, st));
+  const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
+  for (int b = 0; b < 3; ++b) {
+    std::string q = fe + "." + brs[b];
+    int nblk = (int)((px * 4 + 255) / 256);
+    {
+      LoProfScope _p("lo_t_dwconv", 0, 0, st);
+      if (b == 1) hipLaunchKernelGGL((lo_t_dwconv_kernel<5>), dim3(nblk), dim3(256), 0, st, TW(f16, h->o_raw32), ss32, TP(q + ".0.weight"), TP(q + ".0.bias"), TW(f16, h->o_dw), B);
+      else hipLaunchKernelGGL((lo_t_dwconv_kernel<3>), dim3(nblk), dim3(256), 0, st, TW(f16, h->o_raw32), ss32, TP(q + ".0.weight"), TP(q + ".0.bias"), TW(f16, h->o_dw), B);
+    }
+    LO_LAUNCH_CHECK("t_dwconv");
+    LO_TRYT(lo_conv_run(h->gpw, TW(f16, h->o_dw), TW(f16, h->o_wpw[b]), TP(q + ".1.bias"), nullptr, TW(f16, h->o_br[b]), nullptr, nullptr, 1, st, nullptr, &ex));
+    int mt = (int)(px / lo_conv_tile_m(h->gpw));
+    LO_TRYT(t_bn_finalize(h, bnp, mt, 64, q + ".3", P, ws, training, st));
+    LO_TRYT(t_bn_apply(h, TW(f16, h->o_br[b]), nullptr, nullptr, TW(f16, h->o_cat), 64, 192, 64 * b, 0, nullptr, ws, st));
+  }
+  LO_TRYT(lo_conv_run(h->gfus, TW(f16, h->o_cat), TW(f16, h->o_wfus), TP(fe + ".fusion.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+  LO_TRYT(t_bn_finalize(h, bnp, (int)(px / lo_conv_tile_m(h->gfus)), 128, fe + ".fusion.2", P, ws, training, st));
+  LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_feat), 128, 128, 0, 0, TW(float, h->o_poolp), ws, st));
+  LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
+  // ---- experts (lunar_evaluator.py:260-275, 422-428)
+  const int mt3 = (int)(px / lo_conv_tile_m(h->g3));
+  for (int e = 0; e < h->E; ++e) {
+    const f16* xin = TW(f16, h->o_feat);
+    for (int l = 0; l < 3; ++l) {
+      std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
+      f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
+      LO_TRYT(lo_conv_run(h->g3, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+      LO_TRYT(t_bn_finalize(h, bnp, mt3, 128, p + ".conv1.2", P, ws, training, st));
+      LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_bnA), 128, 128, 0, 0, nullptr, ws, st));
+      LO_TRYT(lo_conv_run(h->gq, TW(f16, h->o_bnA), TW(f16, h->o_wqkv[e][l]), TP(p + ".attention.qkv.bias"), nullptr, TW(f16, h->o_qkv), nullptr, nullptr, 1, st));
+      {
+        LoProfScope _p("lo_t_attn", 0, 0, st);
+        int nw = B * 543;
+        hipLaunchKernelGGL(lo_t_attn_kernel, dim3((nw + 3) / 4), dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_att), B);
+      }
+      LO_LAUNCH_CHECK("t_attn");
+      LO_TRYT(lo_conv_run(h->gp, TW(f16, h->o_att), TW(f16, h->o_wproj[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_proj), nullptr, nullptr, 1, st));
+      LO_TRYT(lo_conv_run(h->g3, TW(f16, h->o_proj), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), nullptr, TW(f16, h->o_rawB), nullptr, nullptr, 1, st, nullptr, &ex));
+      LO_TRYT(t_bn_finalize(h, bnp, mt3, 128, p + ".conv2.2", P, ws, training, st));
+      LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 1, l == 2 ? TW(float, h->o_poolp) : nullptr, ws, st));
+      xin = xout;
+    }
+    LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
+  }
+  // ---- heads (lunar_evaluator.py:417, 425, 431-449)
+  HeadsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pooled_f = TW(float, h->o_pool_f); a.pooled_e = TW(float, h->o_pool_e);
+  a.g_w1 = TP("gate.2.weight"); a.g_b1 = TP("gate.2.bias"); a.g_w2 = TP("gate.5.weight"); a.g_b2 = TP("gate.5.bias");
+  auto headw = [&](const std::string& p) { return HeadW{TP(p + ".2.weight"), TP(p + ".2.bias"), TP(p + ".3.weight"), TP(p + ".3.bias"), TP(p + ".6.weight"), TP(p + ".6.bias")}; };
+  for (int e = 0; e < h->E; ++e) a.q[e] = headw("quality_heads." + std::to_string(e));
+  a.sem = headw("semantic_head"); a.style = headw("style_net"); a.prompt = headw("prompt_net");
+  a.quality = quality; a.weights = weights; a.style_out = style; a.prompt_out = prompt; a.sem_out = semantic;
+  a.raw_q = TW(float, h->o_rawq);
+  a.B = B; a.E = h->E; a.I = h->I; a.emb = h->emb;
+  {
+    LoProfScope _p("lo_t_heads", 0, 0, st);
+    hipLaunchKernelGGL(lo_t_heads_kernel, dim3(B), dim3(256), 0, st, a);
+  }
+  LO_LAUNCH_CHECK("t_heads");
+  return LO_OK;
+}

@@ -1,0 +1,203 @@
+"""LunarMoETeacher on MI355X: the reference's ``nn.Module`` surface, forward in liblunaris_hip.so.
+
+Drop-in contract (reference: /root/reference/lunar_evaluator.py:278-462): same constructor signature, the same 252
+parameters + 99 buffers under the same ``state_dict`` keys (``feature_extractor.conv1.0.weight`` ...
+``prompt_net.6.bias``; BatchNorm ``running_mean/var/num_batches_tracked``; the attention buffer
+``last_spatial_shapes``), the reference's initialisation (``kaiming_normal_(fan_out, leaky_relu)``, zero biases,
+unit norms, ``rel_pos ~ N(0, 0.02)``, ``layer_scale = 0.1``), ``forward(x, prompt_embedding=None)`` returning the same
+six-key dict.  The sub-modules are containers; ``forward`` is one native call (``lo_teacher_forward``) that reproduces
+the forward AS EXECUTED — including the chunk-index write offset of ``PixelArtAttention``.
+
+Limits of this round (stated, enforced): ``feature_dim == 128`` (the CLI default), dropout is not applied (the
+reference's dropout masks come from the global RNG and cannot be matched on another device anyway; parity is checked
+against the reference built with ``dropout_rate=0``), forward only (the gate / quality-head gradients of
+``teacher_loss``, SURVEY §8 row A13, are not built yet), ``feature_maps`` is always ``None``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class PixelArtFeatureExtractor(nn.Module):
+    """Parameter container (lunar_evaluator.py:57-112)."""
+
+    def __init__(self, in_channels=3, dropout_rate=0.1, feature_dim=128):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, 32, 3, padding=1), nn.LeakyReLU(0.2), nn.BatchNorm2d(32))
+
+        def branch(k):
+            return nn.Sequential(nn.Conv2d(32, 32, k, padding=k // 2, groups=32), nn.Conv2d(32, 64, 1), nn.LeakyReLU(0.2), nn.BatchNorm2d(64))
+        self.edge_branch, self.color_branch, self.detail_branch = branch(3), branch(5), branch(3)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.fusion = nn.Sequential(nn.Conv2d(192, feature_dim, 1), nn.LeakyReLU(0.2), nn.BatchNorm2d(feature_dim))
+
+
+class PixelArtAttention(nn.Module):
+    """Parameter container (lunar_evaluator.py:119-144)."""
+
+    def __init__(self, in_channels, num_heads=8, rel_pos_size=8, dropout=0.1, chunk_size=64):
+        super().__init__()
+        self.num_heads, self.head_dim, self.chunk_size = num_heads, in_channels // num_heads, chunk_size
+        self.qkv = nn.Conv2d(in_channels, in_channels * 3, 1)
+        self.proj = nn.Conv2d(in_channels, in_channels, 1)
+        self.rel_pos_h = nn.Parameter(torch.randn(1, num_heads, rel_pos_size, 1) * 0.02)
+        self.rel_pos_w = nn.Parameter(torch.randn(1, num_heads, 1, rel_pos_size) * 0.02)
+        self.attn_drop, self.proj_drop = nn.Dropout(dropout), nn.Dropout(dropout)
+        self.register_buffer("rel_pos_cache", None)
+        self.register_buffer("last_spatial_shapes", torch.zeros(2))
+
+
+class ExpertBlock(nn.Module):
+    """Parameter container (lunar_evaluator.py:234-258)."""
+
+    def __init__(self, in_channels, out_channels, dropout_rate=0.1, rel_pos_size=8, layer_scale_init=0.1):
+        super().__init__()
+        def cb(ci):
+            return nn.Sequential(nn.Conv2d(ci, out_channels, 3, padding=1), nn.LeakyReLU(0.2), nn.BatchNorm2d(out_channels), nn.Dropout2d(dropout_rate))
+        self.conv1 = cb(in_channels)
+        self.attention = PixelArtAttention(out_channels, rel_pos_size=rel_pos_size, dropout=dropout_rate)
+        self.conv2 = cb(out_channels)
+        self.shortcut = (nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+                         if in_channels != out_channels else nn.Identity())
+        self.layer_scale = nn.Parameter(torch.ones(1, out_channels, 1, 1) * layer_scale_init)
+
+
+class LunarMoETeacher(nn.Module):
+    def __init__(self, num_experts=4, feature_dim=128, dropout_rate=0.1, rel_pos_size=8, use_checkpointing=True,
+                 expert_layers=3, intermediate_dim=256, embedding_dim=64):
+        super().__init__()
+        if feature_dim != 128 or expert_layers != 3 or intermediate_dim != 256 or rel_pos_size != 8:
+            raise NotImplementedError("only feature_dim=128, expert_layers=3, intermediate_dim=256, rel_pos_size=8 (the CLI defaults) are built")
+        self.num_experts, self.feature_dim, self.dropout_rate = num_experts, feature_dim, dropout_rate
+        self.rel_pos_size, self.use_checkpointing, self.expert_layers = rel_pos_size, use_checkpointing, expert_layers
+        self.intermediate_dim, self.embedding_dim = intermediate_dim, embedding_dim
+        self.feature_extractor = PixelArtFeatureExtractor(3, dropout_rate, 128)
+
+        def expert():
+            blocks, cin = [], 128
+            for _ in range(expert_layers):
+                blocks.append(ExpertBlock(cin, feature_dim, dropout_rate, rel_pos_size))
+                cin = feature_dim
+            return nn.Sequential(*blocks)
+        self.experts = nn.ModuleList([expert() for _ in range(num_experts)])
+        self.gate = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(128, intermediate_dim), nn.LeakyReLU(0.2),
+                                  nn.Dropout(dropout_rate), nn.Linear(intermediate_dim, num_experts), nn.Softmax(dim=1))
+
+        def head(hidden, out, sigmoid=False):
+            mods = [nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.LayerNorm(feature_dim), nn.Linear(feature_dim, hidden), nn.LeakyReLU(0.2),
+                    nn.Dropout(dropout_rate), nn.Linear(hidden, out)]
+            return nn.Sequential(*(mods + ([nn.Sigmoid()] if sigmoid else [])))
+        self.quality_heads = nn.ModuleList([head(intermediate_dim // 4, 4) for _ in range(num_experts)])
+        self.semantic_head = head(intermediate_dim // 2, 1, sigmoid=True)
+        self.style_net = head(intermediate_dim // 2, embedding_dim)
+        self.prompt_net = head(intermediate_dim // 2, embedding_dim)
+        self.apply(self._init_weights)
+        self._flat: Optional[torch.Tensor] = None
+        self._engines: Dict[int, tuple] = {}
+        self._weights_version = 0
+
+    @staticmethod
+    def _init_weights(m):
+        """lunar_evaluator.py:399-406."""
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="leaky_relu")
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, (nn.BatchNorm2d, nn.LayerNorm)):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+    # ---- flat state ---------------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._flat = None
+        self._engines.clear()
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self._weights_version += 1
+        return out
+
+    def mark_weights_changed(self):
+        self._weights_version += 1
+
+    def _named_state(self):
+        params = dict(self.named_parameters())
+        bufs = dict(self.named_buffers())
+        for k in self.state_dict().keys():
+            yield k, (params[k] if k in params else bufs[k])
+
+    def _ensure_flat(self):
+        first = next(self.parameters())
+        if (self._flat is not None and self._flat.device == first.device
+                and self._flat.data_ptr() <= first.data_ptr() < self._flat.data_ptr() + 4 * self._flat.numel()):
+            return
+        _lib.require_gpu()
+        if first.device.type != "cuda":
+            raise _lib.LunarisHipError("LunarMoETeacher must be on the GPU (model.to('cuda')); there is no CPU path")
+        h = C.c_void_p()
+        _lib.check(_lib.lib.lo_teacher_create(1, self.num_experts, self.feature_dim, self.embedding_dim, C.byref(h)), "lo_teacher_create")
+        try:
+            state = list(self._named_state())
+            assert _lib.lib.lo_teacher_num_tensors(h) == len(state), "teacher state table size mismatch"
+            flat = torch.zeros(_lib.lib.lo_teacher_flat_elems(h), dtype=torch.float32, device=first.device)
+            with torch.no_grad():
+                for i, (k, t) in enumerate(state):
+                    assert _lib.lib.lo_teacher_tensor_name(h, i).decode() == k, (i, k)
+                    assert _lib.lib.lo_teacher_tensor_numel(h, i) == t.numel(), k
+                    off = _lib.lib.lo_teacher_tensor_offset(h, i)
+                    if off < 0:
+                        continue                      # integer buffer (num_batches_tracked) stays a normal tensor
+                    flat[off:off + t.numel()].copy_(t.detach().reshape(-1).float())
+                    t.data = flat[off:off + t.numel()].view(t.shape)
+        finally:
+            _lib.lib.lo_teacher_destroy(h)
+        self._flat = flat
+        self._weights_version += 1
+        self._engines.clear()
+
+    def _engine(self, batch: int):
+        self._ensure_flat()
+        eng = self._engines.get(batch)
+        if eng is None:
+            h = C.c_void_p()
+            _lib.check(_lib.lib.lo_teacher_create(batch, self.num_experts, self.feature_dim, self.embedding_dim, C.byref(h)), "lo_teacher_create")
+            ws = torch.empty(_lib.lib.lo_teacher_workspace_bytes(h), dtype=torch.uint8, device=self._flat.device)
+            eng = [h, ws, -1]
+            self._engines[batch] = eng
+        if eng[2] != self._weights_version:
+            _lib.check(_lib.lib.lo_teacher_pack(eng[0], self._flat.data_ptr(), eng[1].data_ptr(), _lib.stream_ptr()), "lo_teacher_pack")
+            eng[2] = self._weights_version
+        return eng
+
+    def forward(self, x: torch.Tensor, prompt_embedding=None):
+        """lunar_evaluator.py:408-462.  ``prompt_embedding`` is accepted and ignored exactly like the reference does
+        (it is overwritten at :438 before any use)."""
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
+            raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B = x.shape[0]
+        h, ws, _ = self._engine(B)
+        dev = x.device
+        q = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        w = torch.empty(B, self.num_experts, dtype=torch.float32, device=dev)
+        st = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
+        pr = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
+        sem = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib.lo_teacher_forward(h, x.data_ptr(), self._flat.data_ptr(), ws.data_ptr(), 1 if self.training else 0,
+                                               q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
+                                               _lib.stream_ptr()), "lo_teacher_forward")
+        if self.training:
+            with torch.no_grad():
+                for m in self.modules():
+                    if isinstance(m, nn.BatchNorm2d):
+                        m.num_batches_tracked += 1
+        return {"quality_scores": q, "expert_weights": w, "style_embedding": st, "prompt_embedding": pr,
+                "semantic_score": sem, "feature_maps": None}
