@@ -148,6 +148,19 @@ int lo_teacher_forward(LoTeacher* h, const float* x, float* flat_state, void* ws
                        float* expert_weights, float* style_embedding, float* prompt_embedding, float* semantic_score,
                        void* stream);
 
+/* gradients of teacher_loss = -(quality_weight/accum) * mean(quality_scores) for the parameters that receive gradients in
+ * the reference step (gate.*, quality_heads.*; train_hybrid.py:891-904 with the reentrant-checkpoint quirk):
+ * one contiguous range [begin,end) of the flat state layout.  rows: B*(end-begin) floats of scratch. */
+int lo_teacher_grad_range(const LoTeacher* h, size_t* begin_elem, size_t* end_elem);
+int lo_teacher_heads_backward(LoTeacher* h, const float* flat_state, void* ws, const float* expert_weights, float coef,
+                              float* rows, float* flat_grads, void* stream);
+/* reward / baseline / advantage bookkeeping of _process_batch (train_hybrid.py:870-892) on the device; state2 =
+ * {baseline, initialised}; out7 = quality_loss, semantic_reward, quality_reward, baseline, advantage, teacher_loss,
+ * mean(quality_scores); adv_dev = mean advantage (input of lo_vae_loss). */
+int lo_hybrid_reward(const float* quality_scores, const float* semantic_score, int B, float semantic_weight,
+                     float reward_scale, float momentum, float quality_weight, float accum, float* state2, float* out7,
+                     float* adv_dev, void* stream);
+
 /* The same backward in two calls, for data-parallel overlap: phase 1 = final conv, decoder, decoder.fc, latent, encoder
  * heads (afterwards the gradients of the three Linear layers — 82 % of the bytes, one contiguous range of the flat
  * buffer, see lo_vae_linear_grad_range — are final and can be all-reduced while phase 2 runs); phase 2 = encoder. */

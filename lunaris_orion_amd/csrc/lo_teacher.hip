@@ -392,6 +392,140 @@ __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A13: gradients of teacher_loss = -(quality_weight/accum) * mean(quality_scores) with respect to the ONLY parameters
+// that receive gradients in the reference step (gate.*, quality_heads.*).  One workgroup per sample
+// recomputes the tiny head forward and writes that sample's parameter-gradient contribution into row n of `rows`
+// (same relative layout as the flat state between gate.2.weight and semantic_head.2.weight); a column sum over the
+// batch then gives the gradient.
+// ---------------------------------------------------------------------------------------------
+struct HeadsBwdArgs {
+  const float* pooled_f; const float* pooled_e; const float* weights; const float* raw_q;
+  const float *g_w1, *g_b1, *g_w2, *g_b2;
+  HeadW q[8];
+  float* rows; size_t row_len;
+  size_t o_g_w1, o_g_b1, o_g_w2, o_g_b2;            // offsets inside a row
+  size_t o_q[8][6];                                 // ln_w, ln_b, w1, b1, w2, b2
+  float scale;                                      // -(quality_weight/accum) / (B*4)
+  int B, E, I;
+};
+__global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
+  __shared__ float x[128], xh[128], ln[128], a1[256], h1[256], dz[8], dw[8], dq[8][4], dh[256], da[256], scratch[8], wts[8];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  float* row = a.rows + (size_t)n * a.row_len;
+  if (tid < a.E) wts[tid] = a.weights[n * a.E + tid];
+  __syncthreads();
+  // d loss / d weighted logits, d q_e, d w_e
+  if (tid < 4) {
+    float t = 0.f;
+    for (int e = 0; e < a.E; ++e) t += a.raw_q[((size_t)n * a.E + e) * 4 + tid] * wts[e];
+    float y = 1.f / (1.f + __expf(-t));
+    float dwq = a.scale * y * (1.f - y);
+    for (int e = 0; e < a.E; ++e) dq[e][tid] = dwq * wts[e];
+    scratch[tid] = dwq;
+  }
+  __syncthreads();
+  if (tid < a.E) {
+    float t = 0.f;
+    for (int j = 0; j < 4; ++j) t += scratch[j] * a.raw_q[((size_t)n * a.E + tid) * 4 + j];
+    dw[tid] = t;
+  }
+  __syncthreads();
+  if (tid < a.E) {
+    float dot = 0.f;
+    for (int k = 0; k < a.E; ++k) dot += wts[k] * dw[k];
+    dz[tid] = wts[tid] * (dw[tid] - dot);
+  }
+  // ---- gate: x = pooled_f ; a1 = W1 x + b1 ; h1 = lrelu(a1) ; z = W2 h1 + b2
+  if (tid < 128) x[tid] = a.pooled_f[n * 128 + tid];
+  __syncthreads();
+  for (int o = tid; o < a.I; o += 256) {
+    float acc = a.g_b1[o];
+    for (int i = 0; i < 128; ++i) acc += a.g_w1[o * 128 + i] * x[i];
+    a1[o] = acc;
+    h1[o] = acc > 0.f ? acc : 0.2f * acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < a.I; i += 256) {
+    float t = 0.f;
+    for (int e = 0; e < a.E; ++e) { t += a.g_w2[e * a.I + i] * dz[e]; row[a.o_g_w2 + (size_t)e * a.I + i] = dz[e] * h1[i]; }
+    da[i] = t * (a1[i] > 0.f ? 1.f : 0.2f);
+    row[a.o_g_b1 + i] = da[i];
+  }
+  if (tid < a.E) row[a.o_g_b2 + tid] = dz[tid];
+  __syncthreads();
+  for (int idx = tid; idx < a.I * 128; idx += 256) row[a.o_g_w1 + idx] = da[idx >> 7] * x[idx & 127];
+  __syncthreads();
+  // ---- quality heads
+  const int H = a.I / 4;
+  for (int e = 0; e < a.E; ++e) {
+    const HeadW& hw = a.q[e];
+    float v = tid < 128 ? a.pooled_e[((size_t)e * a.B + n) * 128 + tid] : 0.f;
+    float s = lo_wave_sum(v);
+    if ((tid & 63) == 0) scratch[tid >> 6] = s;
+    __syncthreads();
+    float mean = (scratch[0] + scratch[1]) / 128.f;
+    __syncthreads();
+    float d = tid < 128 ? v - mean : 0.f;
+    float qv = lo_wave_sum(d * d);
+    if ((tid & 63) == 0) scratch[tid >> 6] = qv;
+    __syncthreads();
+    float rstd = 1.f / sqrtf((scratch[0] + scratch[1]) / 128.f + LN_EPS);
+    if (tid < 128) { xh[tid] = d * rstd; ln[tid] = xh[tid] * hw.ln_w[tid] + hw.ln_b[tid]; }
+    __syncthreads();
+    if (tid < H) {
+      float acc = hw.b1[tid];
+      for (int i = 0; i < 128; ++i) acc += hw.w1[tid * 128 + i] * ln[i];
+      a1[tid] = acc;
+      h1[tid] = acc > 0.f ? acc : 0.2f * acc;
+    }
+    __syncthreads();
+    if (tid < H) {
+      float t = 0.f;
+      for (int j = 0; j < 4; ++j) { t += hw.w2[j * H + tid] * dq[e][j]; row[a.o_q[e][4] + (size_t)j * H + tid] = dq[e][j] * h1[tid]; }
+      da[tid] = t * (a1[tid] > 0.f ? 1.f : 0.2f);
+      row[a.o_q[e][3] + tid] = da[tid];
+    }
+    if (tid < 4) row[a.o_q[e][5] + tid] = dq[e][tid];
+    __syncthreads();
+    for (int idx = tid; idx < H * 128; idx += 256) row[a.o_q[e][2] + idx] = da[idx >> 7] * ln[idx & 127];
+    if (tid < 128) {
+      float t = 0.f;
+      for (int i = 0; i < H; ++i) t += hw.w1[i * 128 + tid] * da[i];
+      row[a.o_q[e][0] + tid] = t * xh[tid];   // d LayerNorm weight
+      row[a.o_q[e][1] + tid] = t;             // d LayerNorm bias
+    }
+    __syncthreads();
+  }
+}
+
+// reward / baseline / advantage bookkeeping of _process_batch (train_hybrid.py:870-892) on the device.
+//   state[0] = baseline, state[1] = 1 once initialised.  out[0..6] = quality_loss, semantic_reward, quality_reward,
+//   baseline, advantage(mean), teacher_loss, mean(quality_scores);  adv_dev[0] = mean advantage (input of lo_vae_loss)
+__global__ void lo_hybrid_reward_kernel(const float* __restrict__ quality, const float* __restrict__ semantic, int B,
+                                        float semantic_weight, float reward_scale, float momentum, float quality_weight,
+                                        float accum, float* __restrict__ state, float* __restrict__ out, float* __restrict__ adv_dev) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sq = 0.0, ss = 0.0;
+  for (int n = 0; n < B; ++n) {
+    sq += ((double)quality[n * 4] + quality[n * 4 + 1] + quality[n * 4 + 2] + quality[n * 4 + 3]) * 0.25;
+    ss += (double)semantic[n];
+  }
+  float quality_reward = (float)(sq / B), semantic_reward = (float)(ss / B);
+  float total = quality_reward + semantic_weight * semantic_reward;
+  float baseline = state[1] != 0.f ? momentum * state[0] + (1.f - momentum) * total : total;
+  state[0] = baseline; state[1] = 1.f;
+  float adv = (total - baseline) * reward_scale;
+  out[0] = -quality_reward;            // quality_loss = -mean(quality_scores)
+  out[1] = semantic_reward;
+  out[2] = quality_reward;
+  out[3] = baseline;
+  out[4] = adv;
+  out[5] = quality_weight * (-quality_reward) / accum;
+  out[6] = quality_reward;
+  adv_dev[0] = adv;
+}
+
+// ---------------------------------------------------------------------------------------------
 // plan / executor
 // ---------------------------------------------------------------------------------------------
 struct LoTeacher {
@@ -640,5 +774,50 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     hipLaunchKernelGGL(lo_t_heads_kernel, dim3(B), dim3(256), 0, st, a);
   }
   LO_LAUNCH_CHECK("t_heads");
+  return LO_OK;
+}
+
+// ---- A13 + reward bookkeeping entry points --------------------------------------------------------------------------
+extern "C" int lo_teacher_grad_range(const LoTeacher* h, size_t* begin, size_t* end) {
+  LO_REQUIRE(h && begin && end, "lo_teacher_grad_range: null argument");
+  *begin = h->off[t_idx(h, "gate.2.weight")];
+  *end = h->off[t_idx(h, "semantic_head.2.weight")];
+  return LO_OK;
+}
+// rows: B * (end - begin) floats of scratch.  grads: flat gradient buffer of the teacher state layout (only [begin,end) is
+// written).  coef = quality_weight / accum.  Must follow lo_teacher_forward on the evaluated batch (uses its pooled features).
+extern "C" int lo_teacher_heads_backward(LoTeacher* h, const float* P, void* ws, const float* expert_weights, float coef,
+                                         float* rows, float* grads, void* stream) {
+  LO_REQUIRE(h && P && ws && expert_weights && rows && grads, "lo_teacher_heads_backward: null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  size_t b0, b1;
+  LO_TRYT(lo_teacher_grad_range(h, &b0, &b1));
+  HeadsBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pooled_f = TW(float, h->o_pool_f); a.pooled_e = TW(float, h->o_pool_e); a.weights = expert_weights; a.raw_q = TW(float, h->o_rawq);
+  a.g_w1 = TP("gate.2.weight"); a.g_b1 = TP("gate.2.bias"); a.g_w2 = TP("gate.5.weight"); a.g_b2 = TP("gate.5.bias");
+  a.o_g_w1 = h->off[t_idx(h, "gate.2.weight")] - b0; a.o_g_b1 = h->off[t_idx(h, "gate.2.bias")] - b0;
+  a.o_g_w2 = h->off[t_idx(h, "gate.5.weight")] - b0; a.o_g_b2 = h->off[t_idx(h, "gate.5.bias")] - b0;
+  const char* sfx[6] = {".2.weight", ".2.bias", ".3.weight", ".3.bias", ".6.weight", ".6.bias"};
+  for (int e = 0; e < h->E; ++e) {
+    std::string p = "quality_heads." + std::to_string(e);
+    a.q[e] = HeadW{TP(p + ".2.weight"), TP(p + ".2.bias"), TP(p + ".3.weight"), TP(p + ".3.bias"), TP(p + ".6.weight"), TP(p + ".6.bias")};
+    for (int k = 0; k < 6; ++k) a.o_q[e][k] = h->off[t_idx(h, p + sfx[k])] - b0;
+  }
+  a.rows = rows; a.row_len = b1 - b0;
+  a.scale = -coef / ((float)h->B * 4.f);
+  a.B = h->B; a.E = h->E; a.I = h->I;
+  LO_HIP(hipMemsetAsync(rows, 0, (size_t)h->B * a.row_len * sizeof(float), st));   // alignment padding inside the rows
+  hipLaunchKernelGGL(lo_t_heads_bwd_kernel, dim3(h->B), dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("t_heads_bwd");
+  return lo_colsum(rows, grads + b0, h->B, (int)a.row_len, (int)a.row_len, 1.0f, st);
+}
+extern "C" int lo_hybrid_reward(const float* quality, const float* semantic, int B, float semantic_weight, float reward_scale,
+                                float momentum, float quality_weight, float accum, float* state2, float* out7, float* adv_dev,
+                                void* stream) {
+  LO_REQUIRE(quality && semantic && state2 && out7 && adv_dev && B > 0, "lo_hybrid_reward: bad argument");
+  hipLaunchKernelGGL(lo_hybrid_reward_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), quality, semantic, B,
+                     semantic_weight, reward_scale, momentum, quality_weight, accum, state2, out7, adv_dev);
+  LO_LAUNCH_CHECK("hybrid_reward");
   return LO_OK;
 }

@@ -120,3 +120,106 @@ class VAEStepper:
     def parameter_grads(self):
         """Views of the flat gradient buffer, one per parameter (state_dict order)."""
         return [self.grads[o:o + n].view(shape) for (o, n, shape) in self.vae._layout]
+
+
+class HybridStepper(VAEStepper):
+    """Full `_process_batch` (train_hybrid.py:838-954): VAE step + the teacher, as the reference EXECUTES it.
+
+    Per micro-batch: VAE forward; teacher(images) (its result is dead in the reference — the prompt embedding it
+    produces is overwritten before use, lunar_evaluator.py:438 — but it runs in train mode, so its BatchNorm
+    running-statistics update is a real side effect and is kept; `run_dead_teacher_call=False` skips it); losses;
+    teacher(recon.detach()); reward / EMA baseline / advantage on the device (`lo_hybrid_reward`); the VAE objective
+    with the detached mean advantage; VAE backward + clip + AdamW; teacher_loss backward for the only parameters that
+    receive gradients in the reference (gate, quality_heads: SURVEY §3.2) + clip + AdamW on exactly those.
+    Teacher dropout is not applied (see lunaris_orion_amd/teacher.py)."""
+
+    def __init__(self, vae: LunarisCoreVAE, teacher, teacher_lr: float = 1e-4, quality_weight: float = 0.5, reward_scale: float = 0.1,
+                 semantic_weight: float = 0.5, baseline_momentum: float = 0.9, run_dead_teacher_call: bool = True, **kw):
+        super().__init__(vae, **kw)
+        self.teacher = teacher
+        self.teacher_base_lr = teacher_lr
+        self.quality_weight, self.reward_scale = quality_weight, reward_scale
+        self.semantic_weight, self.baseline_momentum = semantic_weight, baseline_momentum
+        self.run_dead_teacher_call = run_dead_teacher_call
+        dev = vae.flat_parameters().device
+        self.reward_state = torch.zeros(2, dtype=torch.float32, device=dev)     # baseline, initialised flag
+        self.reward_out = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.adv_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._t_ready = False
+
+    def _teacher_setup(self, batch: int):
+        import ctypes as C
+        t = self.teacher
+        h, ws, _ = t._engine(batch)
+        b, e = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib.lo_teacher_grad_range(h, C.byref(b), C.byref(e)), "lo_teacher_grad_range")
+        if not self._t_ready:
+            self.t_range = (b.value, e.value)
+            n = e.value - b.value
+            self.t_grads = torch.zeros_like(t._flat)
+            self.t_m = torch.zeros(n, dtype=torch.float32, device=t._flat.device)
+            self.t_v = torch.zeros(n, dtype=torch.float32, device=t._flat.device)
+            self.t_scratch = torch.zeros(1028, dtype=torch.float32, device=t._flat.device)
+            self._t_ready = True
+        rows = getattr(self, "_t_rows", None)
+        if rows is None or rows.numel() != batch * (e.value - b.value):
+            self._t_rows = torch.empty(batch * (e.value - b.value), dtype=torch.float32, device=t._flat.device)
+        return h, ws
+
+    def step(self, images: torch.Tensor, batch_idx: int = 0, eps: Optional[torch.Tensor] = None, **_):
+        vae, t = self.vae, self.teacher
+        images = images.detach().contiguous().float()
+        B = images.shape[0]
+        st = _lib.stream_ptr()
+        recon, mu, logvar, eng = vae._native_forward(images, eps, target=images)
+        if self.run_dead_teacher_call:
+            t(images)                                   # train_hybrid.py:853-855 (side effects only)
+        tout = t(recon)                                 # train_hybrid.py:865
+        h, ws = self._teacher_setup(B)
+        _lib.check(_lib.lib.lo_hybrid_reward(tout["quality_scores"].data_ptr(), tout["semantic_score"].data_ptr(), B,
+                                             float(self.semantic_weight), float(self.reward_scale), float(self.baseline_momentum),
+                                             float(self.quality_weight), float(self.accum), self.reward_state.data_ptr(),
+                                             self.reward_out.data_ptr(), self.adv_dev.data_ptr(), st), "lo_hybrid_reward")
+        _lib.check(_lib.lib.lo_vae_loss(eng.handle, eng.ws.data_ptr(), self.recon_weight, self.kl_weight, 0.0, self.adv_dev.data_ptr(),
+                                        float(self.accum), float(vae.loss_scale), self.losses.data_ptr(), st), "lo_vae_loss")
+        if (batch_idx + 1) % self.accum == 0:
+            flat = vae._flat
+            _lib.check(_lib.lib.lo_vae_backward(eng.handle, images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
+                                                images.data_ptr(), 1, None, None, None, float(vae.loss_scale), self.grads.data_ptr(), st),
+                       "lo_vae_backward")
+            if self.grad_sync is not None:
+                self.grad_sync(self.grads)
+            lr = self.lr
+            t_lr = cosine_warm_restarts_lr(self.teacher_base_lr, self.min_lr, self.t0, 2, self.opt_steps)
+            self.opt_steps += 1
+            _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                   self.exp_avg_sq.data_ptr(), flat.numel(), float(self.max_grad_norm), float(lr),
+                                                   float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                   float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st),
+                       "lo_clip_adamw_step")
+            vae.mark_weights_changed()
+            # teacher: gate + quality heads only (train_hybrid.py:891-904, 914, 922)
+            b, e = self.t_range
+            _lib.check(_lib.lib.lo_teacher_heads_backward(h, t._flat.data_ptr(), ws.data_ptr(), tout["expert_weights"].data_ptr(),
+                                                          float(self.quality_weight) / float(self.accum), self._t_rows.data_ptr(),
+                                                          self.t_grads.data_ptr(), st), "lo_teacher_heads_backward")
+            if self.grad_sync is not None:
+                self.grad_sync(self.t_grads[b:e])
+            _lib.check(_lib.lib.lo_clip_adamw_step(t._flat[b:e].data_ptr(), self.t_grads[b:e].data_ptr(), self.t_m.data_ptr(),
+                                                   self.t_v.data_ptr(), e - b, float(self.max_grad_norm), float(t_lr),
+                                                   float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                   float(self.weight_decay), self.opt_steps, self.t_scratch.data_ptr(), st),
+                       "lo_clip_adamw_step(teacher)")
+            # the gate / head weights are read in fp32 by the head kernels: no re-pack needed
+        self.last = (recon, mu, logvar)
+        return recon, mu, logvar
+
+    def metrics(self) -> Dict[str, float]:
+        """The 12 scalars of train_hybrid.py:929-942 (+ grad norm / lr); one host copy."""
+        v = torch.cat([self.losses, self.scratch[1024:1027], self.reward_out[:7]]).cpu().tolist()
+        recon, kl, vae_loss, pg = v[0:4]
+        q_loss, sem_r, q_r, baseline, adv, t_loss, q_mean = v[7:14]
+        return {"recon_loss": recon, "kl_loss": kl, "quality_loss": q_loss, "pg_loss": pg, "semantic_reward": sem_r,
+                "quality_reward": q_r, "baseline": baseline, "advantage": adv, "vae_loss": vae_loss, "teacher_loss": t_loss,
+                "total_loss": vae_loss + t_loss, "quality_scores": q_mean, "grad_norm": v[4], "clip_coef": v[5],
+                "grads_finite": v[6], "lr": self.lr}

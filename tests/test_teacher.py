@@ -61,3 +61,82 @@ def test_teacher_forward_matches_oracle_and_golden(training):
             d = (sd[k].cpu() - new_stats[k]).abs().max().item()
             assert d <= 2e-3 * max(1.0, new_stats[k].abs().max().item()), (k, d)
         assert int(sd["experts.0.0.conv1.2.num_batches_tracked"]) == 1
+
+
+@pytest.mark.gpu
+def test_teacher_head_gradients_match_autograd_of_oracle():
+    """A13: d teacher_loss / d (gate, quality_heads) vs autograd through the oracle restatement."""
+    import ctypes as C
+
+    from lunaris_orion_amd import _lib
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    B = 2
+    S = T.closed_form_teacher_state()
+    m = LunarMoETeacher(dropout_rate=0.0)
+    m.load_state_dict(S)
+    m = m.to("cuda").train()
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    out = m(x.cuda())
+    h, ws, _ = m._engine(B)
+    b, e = C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.lib.lo_teacher_grad_range(h, C.byref(b), C.byref(e)))
+    n = e.value - b.value
+    rows = torch.empty(B * n, device="cuda")
+    grads = torch.zeros_like(m._flat)
+    qw = 0.5
+    _lib.check(_lib.lib.lo_teacher_heads_backward(h, m._flat.data_ptr(), ws.data_ptr(), out["expert_weights"].data_ptr(), qw,
+                                                  rows.data_ptr(), grads.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    # oracle: autograd through the restatement with the original (pre-forward) state
+    S2 = {k: (v.clone().requires_grad_(True) if (k.startswith("gate.") or k.startswith("quality_heads.")) else v) for k, v in S.items()}
+    o, _ = T.teacher_forward(x, S2, training=True)
+    loss = qw * (-o["quality_scores"].mean())
+    loss.backward()
+    for i, (k, t) in enumerate(m._named_state()):
+        if not (k.startswith("gate.") or k.startswith("quality_heads.")):
+            continue
+        off = t.data_ptr() - m._flat.data_ptr()
+        g = grads[off // 4: off // 4 + t.numel()].view(t.shape).cpu()
+        ref = S2[k].grad
+        err = (g - ref).norm().item() / (ref.norm().item() + 1e-12)
+        assert err <= 2e-2, (k, err)
+    # nothing outside the range is written
+    assert float(grads[: b.value].abs().max()) == 0.0 and float(grads[e.value:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_hybrid_step_runs_and_matches_reference_semantics():
+    """One full hybrid step (teacher on): metrics follow train_hybrid.py:870-892 (pg_loss is exactly -0 on the first
+    step because the baseline is initialised to the batch mean), VAE losses equal the VAE-only step's."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.trainer import HybridStepper, VAEStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    L, B = 256, 2
+    P = R.closed_form_params(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps0, eps1 = R.closed_form_eps(B, L, 0).cuda(), R.closed_form_eps(B, L, 1).cuda()
+    vae = LunarisCoreVAE(L); vae.load_state_dict(P); vae = vae.to("cuda")
+    t = LunarMoETeacher(dropout_rate=0.0); t.load_state_dict(T.closed_form_teacher_state()); t = t.to("cuda").train()
+    gate_before = t.gate[2].weight.detach().clone()
+    conv_before = t.experts[0][0].conv1[0].weight.detach().clone()
+    hs = HybridStepper(vae, t, gradient_accumulation_steps=1)
+    hs.step(x, 0, eps0)
+    m0 = hs.metrics()
+    vae2 = LunarisCoreVAE(L); vae2.load_state_dict(P); vae2 = vae2.to("cuda")
+    vs = VAEStepper(vae2, gradient_accumulation_steps=1)
+    vs.step(x, 0, eps0)
+    v0 = vs.metrics()
+    assert set(m0) >= {"recon_loss", "kl_loss", "quality_loss", "pg_loss", "semantic_reward", "quality_reward", "baseline", "advantage",
+                       "vae_loss", "teacher_loss", "total_loss", "quality_scores"}
+    assert m0["recon_loss"] == v0["recon_loss"] and m0["kl_loss"] == v0["kl_loss"]
+    assert m0["advantage"] == 0.0 and m0["pg_loss"] == 0.0                      # first step: baseline == batch mean
+    assert abs(m0["baseline"] - (m0["quality_reward"] + 0.5 * m0["semantic_reward"])) <= 1e-6
+    assert abs(m0["teacher_loss"] - 0.5 * m0["quality_loss"]) <= 1e-7
+    assert 0.3 < m0["quality_scores"] < 0.7
+    hs.step(x, 1, eps1)
+    m1 = hs.metrics()
+    assert np.isfinite(list(m1.values())).all() and m1["grads_finite"] == 1.0
+    # only gate / quality heads of the teacher move (SURVEY §3.2 item 3)
+    assert not torch.equal(t.gate[2].weight, gate_before)
+    assert torch.equal(t.experts[0][0].conv1[0].weight, conv_before)
+    assert int(t.feature_extractor.conv1[2].num_batches_tracked) == 4           # two teacher calls per step
