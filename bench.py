@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-fp16", action="store_true", help="fp16 wire format for the gradient all-reduce (off: fp32)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--hybrid-steps", type=int, default=8, help="extra leg (N=1): full hybrid VAE+teacher steps, BASELINE config 3 (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,13 +201,35 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": f"VAE-only training step (fwd+MSE/KL+bwd+clip+AdamW), per-GPU batch {B}, latent_dim {args.latent}, "
-                                   "teacher scalar 0 (--reward_scale 0 --quality_weight 0; the teacher forward of BASELINE config 3 is not built yet), "
+                                   "teacher scalar 0 (--reward_scale 0 --quality_weight 0; the full hybrid step of BASELINE config 3 is the config3_full_hybrid object at N=1), "
                                    "gradient_accumulation_steps 1, fp16 MFMA operands / fp32 accumulate, fp32 master weights",
                        "global_batch": world * B, "latent_dim": args.latent,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof,
             "final_metrics": {k: met[k] for k in ("recon_loss", "kl_loss", "grad_norm")},
         }
+        if world == 1 and args.hybrid_steps > 0:
+            # BASELINE config 3: batch 64, latent 512, embedding_dim 256, feature_dim 128, teacher on (both teacher forwards of
+            # _process_batch, reward/advantage, gate + quality-head update); teacher dropout not applied
+            from lunaris_orion_amd.teacher import LunarMoETeacher
+            from lunaris_orion_amd.trainer import HybridStepper
+            del st
+            torch.cuda.empty_cache()
+            teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256).to("cuda").train()
+            hs = HybridStepper(model, teacher, gradient_accumulation_steps=1)
+            for i in range(2):
+                hs.step(pool[i % len(pool)], batch_idx=i)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for i in range(args.hybrid_steps):
+                hs.step(pool[i % len(pool)], batch_idx=i)
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - th) / args.hybrid_steps
+            hm = hs.metrics()
+            out["config3_full_hybrid"] = {"value": B / dth, "unit": "sprites/s", "ms_per_step": 1e3 * dth, "steps": args.hybrid_steps,
+                                          "workload": f"full hybrid _process_batch: VAE step + 2 teacher forwards (feature_dim 128, 4 experts, "
+                                                      f"embedding_dim 256) + reward/advantage + gate/quality-head update, batch {B}, latent {args.latent}",
+                                          "quality_scores": hm["quality_scores"], "recon_loss": hm["recon_loss"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.latent, args.cpu_steps)
     if dist is not None:

@@ -121,6 +121,30 @@ __global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __rest
   }
 }
 
+// stage 1 of the finalize for many partial rows: out[split][C][2] = sum of the rows of that split (fixed order)
+__global__ __launch_bounds__(256) void lo_bn_presum_kernel(const float* __restrict__ partial, int nrow, int C, float* __restrict__ out) {
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int per = (nrow + gridDim.y - 1) / gridDim.y;
+  const int k0 = blockIdx.y * per, k1 = min(nrow, k0 + per);
+  float s = 0.f, q = 0.f;
+  if (c < C)
+    for (int k = k0 + r; k < k1; k += 16) {
+      f32x2 p = *reinterpret_cast<const f32x2*>(partial + ((size_t)k * C + c) * 2);
+      s += p[0];
+      q += p[1];
+    }
+  red[0][r][cl] = s; red[1][r][cl] = q;
+  __syncthreads();
+  if (r < 2 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[r][k][cl];
+    out[((size_t)blockIdx.y * C + c) * 2 + r] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm apply (elementwise, 16-byte vectors over channels)
 //   y[pix][dst_off + c] = raw[pix][c]*scale[c] + shift[c]                                   (mode 0; dst pitch for concat)
@@ -536,7 +560,7 @@ struct LoTeacher {
   size_t flat_elems;
   // workspace offsets
   size_t o_raw32, o_dw, o_br[3], o_cat, o_feat, o_x0, o_x1, o_rawA, o_bnA, o_qkv, o_att, o_proj, o_rawB;
-  size_t o_bnp, o_ss, o_poolp, o_pool_f, o_pool_e, o_rawq;
+  size_t o_bnp, o_bnpre, o_ss, o_poolp, o_pool_f, o_pool_e, o_rawq;
   size_t o_wp3[8][3][2];      // packed 3x3 weights (expert, layer, conv1/conv2)
   size_t o_wqkv[8][3], o_wproj[8][3], o_wpw[3], o_wfus;
   LoGeom g3, gq, gp, gpw, gfus;
@@ -618,6 +642,7 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
   h->o_rawA = take(px * 128 * 2); h->o_bnA = take(px * 128 * 2); h->o_qkv = take(px * 384 * 2);
   h->o_att = take(px * 128 * 2); h->o_proj = take(px * 128 * 2); h->o_rawB = take(px * 128 * 2);
   h->o_bnp = take((size_t)B * 128 * 128 * 2 * 4 + 65536);   // rows <= B*128, C <= 128
+  h->o_bnpre = take(64 * 128 * 2 * 4);
   h->o_ss = take(192 * 2 * 4 + 256);
   h->o_poolp = take((size_t)B * 64 * 128 * 4);
   h->o_pool_f = take((size_t)B * 128 * 4);
@@ -667,6 +692,14 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
 static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, const std::string& bnp, float* P, void* ws,
                          int training, hipStream_t st) {
   LoProfScope _p("lo_bn_finalize", 0, 0, st);
+  if (training && nrow > 256) {
+    // two stages: 64 row splits in parallel, then the 64 split sums
+    float* pre = TW(float, h->o_bnpre);
+    hipLaunchKernelGGL(lo_bn_presum_kernel, dim3((C + 15) / 16, 64), dim3(256), 0, st, partial, nrow, C, pre);
+    LO_LAUNCH_CHECK("bn_presum");
+    partial = pre;
+    nrow = 64;
+  }
   hipLaunchKernelGGL(lo_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nrow, C, (float)((size_t)h->B * T_HW),
                      TP(bnp + ".weight"), TP(bnp + ".bias"), TP(bnp + ".running_mean"), TP(bnp + ".running_var"), training,
                      TW(float, h->o_ss));

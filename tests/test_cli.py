@@ -29,12 +29,12 @@ def test_cli_flags_and_defaults_match_reference():
     assert len(REFERENCE_DEFAULTS) + 1 == 35      # + data_dir
 
 
-def test_teacher_on_is_refused_loudly(tmp_path):
+def test_unsupported_feature_dim_is_refused_loudly(tmp_path):
     sys.path.insert(0, ROOT)
     import train_hybrid
     with pytest.raises(SystemExit) as e:
-        train_hybrid.main(["--data_dir", str(tmp_path)])
-    assert "teacher" in str(e.value).lower()
+        train_hybrid.main(["--data_dir", str(tmp_path), "--feature_dim", "512"])
+    assert "feature_dim" in str(e.value)
 
 
 def _make_data(d, n=24):
@@ -64,3 +64,19 @@ def test_cli_end_to_end_on_gpu(tmp_path):
     assert set(ck.keys()) >= {"global_step", "vae_state_dict", "teacher_state_dict", "vae_optimizer", "teacher_optimizer",
                               "vae_scheduler", "teacher_scheduler", "best_loss", "args"}
     assert len(ck["vae_state_dict"]) == 72
+
+
+@pytest.mark.gpu
+def test_cli_hybrid_end_to_end_on_gpu(tmp_path):
+    """Default flags (teacher on) on a tiny dataset: the 12 metrics are logged and the teacher state is checkpointed."""
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_data(str(data), n=12)
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
+                        "--batch_size", "2", "--gradient_accumulation_steps", "1", "--num_epochs", "1", "--log_every", "1",
+                        "--max_steps", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import torch
+    ck = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
+    assert len(ck["teacher_state_dict"]) == 351

@@ -140,3 +140,31 @@ def test_hybrid_step_runs_and_matches_reference_semantics():
     assert not torch.equal(t.gate[2].weight, gate_before)
     assert torch.equal(t.experts[0][0].conv1[0].weight, conv_before)
     assert int(t.feature_extractor.conv1[2].num_batches_tracked) == 4           # two teacher calls per step
+
+
+@pytest.mark.gpu
+def test_hybrid_two_steps_match_reference_trace():
+    """Two full `_process_batch` steps against the trace the REFERENCE's own modules + torch.optim.AdamW +
+    CosineAnnealingWarmRestarts produced on CPU (oracle/make_golden.py::run_hybrid, teacher dropout 0).
+    Tolerances: VAE losses 2e-4 relative (fp16 operands, fp32 accumulate), teacher-derived scalars 3e-3 absolute
+    (three fp16 expert stacks + train-mode BatchNorm), advantage/pg 5e-4 absolute (they are reward_scale-scaled)."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.trainer import HybridStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hybrid_L256_B2.npz"))
+    cols, trace = [str(c) for c in g["cols"]], g["trace"]
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    vae = LunarisCoreVAE(L); vae.load_state_dict(R.closed_form_params(L)); vae = vae.to("cuda")
+    t = LunarMoETeacher(dropout_rate=0.0); t.load_state_dict(T.closed_form_teacher_state()); t = t.to("cuda").train()
+    hs = HybridStepper(vae, t, gradient_accumulation_steps=1)
+    tol = {"recon_loss": ("rel", 2e-4), "kl_loss": ("rel", 2e-4), "vae_loss": ("rel", 1e-3), "pg_loss": ("abs", 5e-4), "advantage": ("abs", 5e-4)}
+    for s in range(trace.shape[0]):
+        hs.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
+        m = hs.metrics()
+        for j, c in enumerate(cols):
+            kind, lim = tol.get(c, ("abs", 3e-3))
+            err = abs(m[c] - trace[s, j]) / (abs(trace[s, j]) if kind == "rel" else 1.0)
+            assert err <= lim, (s, c, m[c], trace[s, j])
+    assert int(g["teacher_params_with_grad"]) == 28
+    np.testing.assert_allclose(t.gate[2].weight.detach().cpu().numpy()[:4, :8], g["gate_w_after"], atol=2e-4)

@@ -7,9 +7,10 @@ What is the same: flags/defaults (the five dead flags are accepted and ignored l
 drop_last (:551-569), the step semantics of `_process_batch` (:838-954) including its accumulation rule, the 12 metric
 names (:929-942), the checkpoint dictionary keys (:596-606), SIGINT -> checkpoint (:587-592).
 
-What differs, deliberately: the teacher (`LunarMoETeacher`) forward is not built in this round, so the run must be
-VAE-only — pass `--reward_scale 0 --quality_weight 0` (or `--vae_only`); with those values the reference's VAE
-update is exactly what runs here and the teacher-only metrics are reported as 0.  The reference's
+What differs, deliberately: with the teacher on (the default flags) `HybridStepper` runs the full `_process_batch`
+as the reference executes it, except that teacher dropout is not applied and `--feature_dim` must stay 128; with
+`--reward_scale 0 --quality_weight 0` (or `--vae_only`) the teacher is not run at all (its result cannot influence the
+VAE then) and the teacher-only metrics are reported as 0.  The reference's
 defects are not inherited: no tensorboard hard dependency, no DataLoader timeout assertion, per-epoch average
 loss is a real number, checkpoints are written.  Launch one process per GPU with torch.distributed.run for DP.
 """
@@ -112,9 +113,9 @@ def main(argv=None):
         args.reward_scale, args.quality_weight = 0.0, 0.0
     if args.force_cpu:
         raise SystemExit("--force_cpu: this build has no CPU path (the CPU oracle under oracle/ is test infrastructure only)")
-    if args.reward_scale != 0.0 or args.quality_weight != 0.0:
-        raise SystemExit("The LunarMoETeacher forward is not built in this round: run VAE-only with "
-                         "--reward_scale 0 --quality_weight 0 (or --vae_only). With those values the VAE update equals the reference's.")
+    teacher_on = args.reward_scale != 0.0 or args.quality_weight != 0.0
+    if teacher_on and args.feature_dim != 128:
+        raise SystemExit("--feature_dim != 128 is not built yet (the teacher kernels are instantiated for the CLI default 128)")
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
@@ -149,12 +150,21 @@ def main(argv=None):
     except Exception:
         log.info("tensorboard not installed: scalar logging goes to training.log only")
 
-    from lunaris_orion_amd.trainer import VAEStepper
+    from lunaris_orion_amd.trainer import HybridStepper, VAEStepper
     from lunaris_orion_amd.vae import LunarisCoreVAE
     vae = LunarisCoreVAE(latent_dim=args.latent_dim).to("cuda")
-    stepper = VAEStepper(vae, lr=args.vae_lr, min_lr=args.min_lr, scheduler_t0=args.scheduler_t0, weight_decay=args.weight_decay,
-                         max_grad_norm=args.max_grad_norm, recon_weight=args.recon_weight, kl_weight=args.kl_weight,
-                         gradient_accumulation_steps=args.gradient_accumulation_steps, grad_sync=grad_sync)
+    common = dict(lr=args.vae_lr, min_lr=args.min_lr, scheduler_t0=args.scheduler_t0, weight_decay=args.weight_decay,
+                  max_grad_norm=args.max_grad_norm, recon_weight=args.recon_weight, kl_weight=args.kl_weight,
+                  gradient_accumulation_steps=args.gradient_accumulation_steps, grad_sync=grad_sync)
+    teacher = None
+    if teacher_on:
+        from lunaris_orion_amd.teacher import LunarMoETeacher
+        teacher = LunarMoETeacher(num_experts=args.num_experts, feature_dim=args.feature_dim, embedding_dim=args.embedding_dim).to("cuda").train()
+        stepper = HybridStepper(vae, teacher, teacher_lr=args.teacher_lr, quality_weight=args.quality_weight, reward_scale=args.reward_scale,
+                                semantic_weight=args.semantic_weight, baseline_momentum=args.baseline_momentum, **common)
+        log.info("teacher on: LunarMoETeacher forward as executed by the reference (dropout is not applied in this build)")
+    else:
+        stepper = VAEStepper(vae, **common)
     log.info(f"VAE Parameters - Total: {sum(p.numel() for p in vae.parameters()):,}")
     global_step, best_loss = 0, float("inf")
 
@@ -163,7 +173,8 @@ def main(argv=None):
             return
         torch.cuda.synchronize()
         ckpt = {"global_step": global_step, "vae_state_dict": {k: v.detach().cpu() for k, v in vae.state_dict().items()},
-                "teacher_state_dict": {}, "vae_optimizer": {"exp_avg": stepper.exp_avg.cpu(), "exp_avg_sq": stepper.exp_avg_sq.cpu(),
+                "teacher_state_dict": ({k: v.detach().cpu() for k, v in teacher.state_dict().items()} if teacher is not None else {}),
+                "vae_optimizer": {"exp_avg": stepper.exp_avg.cpu(), "exp_avg_sq": stepper.exp_avg_sq.cpu(),
                                                             "opt_steps": stepper.opt_steps},
                 "teacher_optimizer": {}, "vae_scheduler": {"last_epoch": stepper.opt_steps}, "teacher_scheduler": {},
                 "best_loss": best_loss, "args": vars(args)}
@@ -203,9 +214,9 @@ def main(argv=None):
             global_step += 1
             if global_step % args.log_every == 0 or b == steps_per_epoch - 1:
                 m = stepper.metrics()
-                metrics = {"recon_loss": m["recon_loss"], "kl_loss": m["kl_loss"], "quality_loss": 0.0, "pg_loss": m["pg_loss"],
-                           "semantic_reward": 0.0, "quality_reward": 0.0, "baseline": 0.0, "advantage": 0.0,
-                           "vae_loss": m["vae_loss"], "teacher_loss": 0.0, "total_loss": m["vae_loss"], "quality_scores": 0.0}
+                keys = ("recon_loss", "kl_loss", "quality_loss", "pg_loss", "semantic_reward", "quality_reward", "baseline", "advantage",
+                        "vae_loss", "teacher_loss", "total_loss", "quality_scores")
+                metrics = {k: m.get(k, m["vae_loss"] if k == "total_loss" else 0.0) for k in keys}
                 epoch_losses.append(metrics["total_loss"])
                 if writer is not None:
                     for k, v in metrics.items():
