@@ -84,17 +84,23 @@ __global__ __launch_bounds__(256) void lo_t_conv1_kernel(const float* __restrict
 // BatchNorm finalize: partial [nrow][C][2] -> ss[C][2] = (scale, shift);  training: batch statistics + running-stat
 // update (momentum 0.1, unbiased variance); eval: running statistics.  Optionally pooled[n][c] = mean over the sample of
 // the NORMALISED tensor (= scale * mean_n(raw) + shift), from the same partials (rows_per_sample rows per sample).
+// Row mask: partial row k counts iff (k % tps) < vtps (tps = partial rows per sample; the compact conv2 of the sparse
+// expert path computes 8 image rows per sample of which 6 are real).  cvec != null adds, analytically, the positions
+// the compact path does not compute: per sample T_CNT[k] positions of value cvec[k][c] (see lo_t_cvec_kernel).
 // ---------------------------------------------------------------------------------------------
+__constant__ float T_CNT[6] = {121.f * 126.f, 121.f, 121.f, 126.f, 1.f, 1.f};   // interior, left, right, bottom, bottom-left, bottom-right
 __global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __restrict__ partial, int nrow, int C, float count,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ rmean, float* __restrict__ rvar, int training,
-                                                             float* __restrict__ ss) {
+                                                             float* __restrict__ ss, int tps, int vtps,
+                                                             const float* __restrict__ cvec, float nsample) {
   __shared__ double red[2][16][17];
   const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double s = 0.0, q = 0.0;
   if (c < C && training)
     for (int k = r; k < nrow; k += 16) {
+      if ((k % tps) >= vtps) continue;
       f32x2 p = *reinterpret_cast<const f32x2*>(partial + ((size_t)k * C + c) * 2);
       s += (double)p[0];
       q += (double)p[1];
@@ -106,6 +112,12 @@ __global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __rest
     if (training) {
       double ts = 0.0, tq = 0.0;
       for (int k = 0; k < 16; ++k) { ts += red[0][k][cl]; tq += red[1][k][cl]; }
+      if (cvec)
+        for (int k = 0; k < 6; ++k) {
+          double v = (double)cvec[k * C + c], n = (double)nsample * (double)T_CNT[k];
+          ts += n * v;
+          tq += n * v * v;
+        }
       double m = ts / (double)count;
       double v = tq / (double)count - m * m;
       if (v < 0.0) v = 0.0;
@@ -122,7 +134,8 @@ __global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __rest
 }
 
 // stage 1 of the finalize for many partial rows: out[split][C][2] = sum of the rows of that split (fixed order)
-__global__ __launch_bounds__(256) void lo_bn_presum_kernel(const float* __restrict__ partial, int nrow, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void lo_bn_presum_kernel(const float* __restrict__ partial, int nrow, int C, float* __restrict__ out,
+                                                           int tps, int vtps) {
   __shared__ float red[2][16][17];
   const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -131,6 +144,7 @@ __global__ __launch_bounds__(256) void lo_bn_presum_kernel(const float* __restri
   float s = 0.f, q = 0.f;
   if (c < C)
     for (int k = k0 + r; k < k1; k += 16) {
+      if ((k % tps) >= vtps) continue;
       f32x2 p = *reinterpret_cast<const f32x2*>(partial + ((size_t)k * C + c) * 2);
       s += p[0];
       q += p[1];
@@ -149,11 +163,14 @@ __global__ __launch_bounds__(256) void lo_bn_presum_kernel(const float* __restri
 // BatchNorm apply (elementwise, 16-byte vectors over channels)
 //   y[pix][dst_off + c] = raw[pix][c]*scale[c] + shift[c]                                   (mode 0; dst pitch for concat)
 //   y = lrelu( (raw*scale + shift) * ls[c] + identity , 0.2 )                               (mode 1: ExpertBlock tail)
+//   mode 2 = mode 1 with the SPARSE raw tensor: image rows 0..5 come from the compact buffer [n][8][128][C], every other
+//   position is one of the six constant vectors cvec[k][C] (interior / left / right / bottom / two bottom corners)
 // optional pool_partial[n][chunk][C] = per-sample, per-channel sums of y (global average pooling)
 // ---------------------------------------------------------------------------------------------
 struct BnApplyArgs {
   const f16* raw; const float* ss; const float* ls; const f16* identity; f16* y; float* pool_partial;
   int C, dst_pitch, dst_off, mode, rows_per_block;
+  const float* cvec;
 };
 __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   __shared__ float s_red[256 * 8];
@@ -166,10 +183,15 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   for (int j = 0; j < 8; ++j) {
     sc[j] = a.ss[(c0 + j) * 2];
     sh[j] = a.ss[(c0 + j) * 2 + 1];
-    lsv[j] = a.mode == 1 ? a.ls[c0 + j] : 1.f;
+    lsv[j] = a.mode >= 1 ? a.ls[c0 + j] : 1.f;
     acc[j] = 0.f;
   }
   const size_t row0 = (size_t)n * T_HW + (size_t)blk * a.rows_per_block;
+  f16x8 hint;
+  if (a.mode == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hint[j] = (f16)a.cvec[c0 + j];
+  }
   constexpr int U = 4;
   for (int r = slot; r < a.rows_per_block; r += U * nslot) {
     f16x8 h[U], idv[U];
@@ -177,8 +199,22 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
     for (int u = 0; u < U; ++u) {
       int rr = r + u * nslot;
       if (rr < a.rows_per_block) {
-        h[u] = *reinterpret_cast<const f16x8*>(a.raw + (row0 + rr) * C + c0);
-        if (a.mode == 1) idv[u] = *reinterpret_cast<const f16x8*>(a.identity + (row0 + rr) * C + c0);
+        if (a.mode == 2) {
+          const int p = blk * a.rows_per_block + rr, py = p >> 7, px = p & 127;
+          if (py < 6) {
+            h[u] = *reinterpret_cast<const f16x8*>(a.raw + ((size_t)n * 1024 + p) * C + c0);
+          } else {
+            const int k = (py == 127 ? 3 : 0) + (px == 0 ? 1 : px == 127 ? 2 : 0);
+            h[u] = hint;
+            if (k) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) h[u][j] = (f16)a.cvec[k * C + c0 + j];
+            }
+          }
+        } else {
+          h[u] = *reinterpret_cast<const f16x8*>(a.raw + (row0 + rr) * C + c0);
+        }
+        if (a.mode >= 1) idv[u] = *reinterpret_cast<const f16x8*>(a.identity + (row0 + rr) * C + c0);
       }
     }
 #pragma unroll
@@ -189,7 +225,7 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float v = (float)h[u][j] * sc[j] + sh[j];
-          if (a.mode == 1) {
+          if (a.mode >= 1) {
             v = v * lsv[j] + (float)idv[u][j];
             v = v > 0.f ? v : 0.2f * v;
           }
@@ -318,6 +354,105 @@ __global__ __launch_bounds__(256) void lo_t_attn_kernel(const f16* __restrict__ 
 #pragma unroll
     for (int d = 0; d < 8; ++d) { o0[d] = (f16)acc[d]; o1[d] = (f16)acc[8 + d]; }
     f16* dst = att + ((size_t)b * T_HW + p) * 128 + head * 16;
+    *reinterpret_cast<f16x8*>(dst) = o0;
+    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse expert path.  The attention output is zero outside positions 0..542 (image rows 0..4), so proj(att) equals
+// fp16(proj.bias) there and conv2 of that constant field is one of six vectors, depending only on which taps fall into
+// the zero padding.  cvec[k][co] = fp16(lrelu(fp16(bias2[co] + sum_{valid taps} sum_ci Wp[co][tap][ci] * fp16(pb[ci])))),
+// exactly the value the dense igemm epilogue stores.  k: 0 interior, 1 left column, 2 right column, 3 bottom row,
+// 4 bottom-left, 5 bottom-right.  grid = 6, block = 128 (one output channel per thread).  Weights only: runs at pack time.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void lo_t_cvec_kernel(const f16* __restrict__ wp, const float* __restrict__ bias2,
+                                                        const float* __restrict__ proj_bias, float* __restrict__ cvec) {
+  __shared__ float pb[128];
+  const int k = blockIdx.x, co = threadIdx.x;
+  pb[co] = (float)(f16)proj_bias[co];
+  __syncthreads();
+  const bool left = (k == 1 || k == 4), right = (k == 2 || k == 5), bottom = k >= 3;
+  float acc = 0.f;
+  for (int t = 0; t < 9; ++t) {
+    const int r = t / 3, sx = t % 3;
+    if ((left && sx == 0) || (right && sx == 2) || (bottom && r == 2)) continue;
+    const f16* w = wp + ((size_t)co * 9 + t) * 128;
+    float a = 0.f;
+    for (int ci = 0; ci < 128; ci += 8) {
+      f16x8 h = *reinterpret_cast<const f16x8*>(w + ci);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += (float)h[j] * pb[ci + j];
+    }
+    acc += a;
+  }
+  float v = (float)(f16)(acc + bias2[co]);
+  v = v > 0.f ? v : 0.2f * v;
+  cvec[k * 128 + co] = (float)(f16)v;
+}
+
+// query rows: qin[b][p][128] = bnA[b][qtok(p)][128] for p < 543 (16-byte chunks; thread = (b, p, chunk))
+__global__ __launch_bounds__(256) void lo_t_gather_q_kernel(const f16* __restrict__ bnA, f16* __restrict__ qin, int B) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = gid & 15, row = gid >> 4;
+  if (row >= B * 543) return;
+  const int b = row / 543, p = row - b * 543;
+  const int qtok = p < 512 ? 32 * p : 32 * 511 + (p - 511);
+  *reinterpret_cast<f16x8*>(qin + ((size_t)b * 1024 + p) * 128 + chunk * 8) =
+      *reinterpret_cast<const f16x8*>(bnA + ((size_t)b * T_HW + qtok) * 128 + chunk * 8);
+}
+
+// the attention above on the split operands of the sparse path: q [B][1024][128] (row p = query of written position p),
+// kv [B][16384][256] (k | v), att [B][1024][128] (rows >= 543 stay zero)
+__global__ __launch_bounds__(256) void lo_t_attn_sparse_kernel(const f16* __restrict__ qc, const f16* __restrict__ kv,
+                                                               f16* __restrict__ att, int B) {
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int per_b = 512 + 31;
+  if (wave_g >= B * per_b) return;
+  const int b = wave_g / per_b, p = wave_g - b * per_b;
+  const int chunk = p < 512 ? p : 511;
+  const int head = lane >> 3, part = lane & 7;
+  const f16* qp = qc + ((size_t)b * 1024 + p) * 128 + head * 16;
+  const f16* base = kv + (size_t)b * T_HW * 256;
+  f16x8 q0 = *reinterpret_cast<const f16x8*>(qp), q1 = *reinterpret_cast<const f16x8*>(qp + 8);
+  float sc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16* kp = base + (size_t)(32 * chunk + part * 4 + k) * 256 + head * 16;
+    f16x8 k0 = *reinterpret_cast<const f16x8*>(kp), k1 = *reinterpret_cast<const f16x8*>(kp + 8);
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) s += (float)q0[d] * (float)k0[d] + (float)q1[d] * (float)k1[d];
+    sc[k] = s * 0.25f;
+  }
+  float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float e[4], l = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { e[k] = __expf(sc[k] - m); l += e[k]; }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) l += __shfl_xor(l, o, 64);
+  float acc[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16* vp = base + (size_t)(32 * chunk + part * 4 + k) * 256 + 128 + head * 16;
+    f16x8 v0 = *reinterpret_cast<const f16x8*>(vp), v1 = *reinterpret_cast<const f16x8*>(vp + 8);
+    float pw = e[k] / l;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { acc[d] += pw * (float)v0[d]; acc[8 + d] += pw * (float)v1[d]; }
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) acc[d] += __shfl_xor(acc[d], o, 64);
+  if (part == 0) {
+    f16x8 o0, o1;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { o0[d] = (f16)acc[d]; o1[d] = (f16)acc[8 + d]; }
+    f16* dst = att + ((size_t)b * 1024 + p) * 128 + head * 16;
     *reinterpret_cast<f16x8*>(dst) = o0;
     *reinterpret_cast<f16x8*>(dst + 8) = o1;
   }
@@ -564,6 +699,10 @@ struct LoTeacher {
   size_t o_wp3[8][3][2];      // packed 3x3 weights (expert, layer, conv1/conv2)
   size_t o_wqkv[8][3], o_wproj[8][3], o_wpw[3], o_wfus;
   LoGeom g3, gq, gp, gpw, gfus;
+  // sparse expert path (default; LO_T_DENSE=1 selects the dense one): k|v projection, compact (8 image rows) q / proj / conv2
+  bool sparse;
+  LoGeom gkv, gpc, g3c;
+  size_t o_qin, o_qc, o_attc, o_projc, o_rawBc, o_cvec[8][3];
   size_t ws_bytes;
   bool att_zeroed;
   const void* att_zeroed_ws;
@@ -656,6 +795,16 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
     }
   for (int b = 0; b < 3; ++b) h->o_wpw[b] = take((size_t)64 * 32 * 2);
   h->o_wfus = take((size_t)128 * 192 * 2);
+  const char* dense = getenv("LO_T_DENSE");
+  h->sparse = !(dense && atoi(dense) != 0);
+  LO_TRYT(lo_make_geom(&h->gkv, LO_LINEAR, B, 128, 128, 128, 256));
+  LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, 128, 128));
+  LO_TRYT(lo_make_geom(&h->g3c, LO_CONV3_S1, B, 8, 128, 128, 128));
+  const size_t cpx = (size_t)B * 1024;
+  h->o_qin = take(cpx * 128 * 2); h->o_qc = take(cpx * 128 * 2); h->o_attc = take(cpx * 128 * 2);
+  h->o_projc = take(cpx * 128 * 2); h->o_rawBc = take(cpx * 128 * 2);
+  for (int e = 0; e < num_experts; ++e)
+    for (int l = 0; l < 3; ++l) h->o_cvec[e][l] = take(6 * 128 * 4);
   h->ws_bytes = off;
   *out = h;
   return LO_OK;
@@ -681,6 +830,9 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
       LO_TRYT(lo_pack_weight(TP(p + ".conv2.0.weight"), TW(f16, h->o_wp3[e][l][1]), h->g3, st));
       LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.qkv.weight"), TW(f16, h->o_wqkv[e][l]), (size_t)384 * 128, st));
       LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.proj.weight"), TW(f16, h->o_wproj[e][l]), (size_t)128 * 128, st));
+      hipLaunchKernelGGL(lo_t_cvec_kernel, dim3(6), dim3(128), 0, st, TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"),
+                         TP(p + ".attention.proj.bias"), TW(float, h->o_cvec[e][l]));
+      LO_LAUNCH_CHECK("t_cvec");
     }
   const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
   for (int b = 0; b < 3; ++b)
@@ -690,26 +842,26 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
 }
 
 static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, const std::string& bnp, float* P, void* ws,
-                         int training, hipStream_t st) {
+                         int training, hipStream_t st, int tps = 1, int vtps = 1, const float* cvec = nullptr) {
   LoProfScope _p("lo_bn_finalize", 0, 0, st);
   if (training && nrow > 256) {
     // two stages: 64 row splits in parallel, then the 64 split sums
     float* pre = TW(float, h->o_bnpre);
-    hipLaunchKernelGGL(lo_bn_presum_kernel, dim3((C + 15) / 16, 64), dim3(256), 0, st, partial, nrow, C, pre);
+    hipLaunchKernelGGL(lo_bn_presum_kernel, dim3((C + 15) / 16, 64), dim3(256), 0, st, partial, nrow, C, pre, tps, vtps);
     LO_LAUNCH_CHECK("bn_presum");
     partial = pre;
-    nrow = 64;
+    nrow = 64; tps = 1; vtps = 1;
   }
   hipLaunchKernelGGL(lo_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nrow, C, (float)((size_t)h->B * T_HW),
                      TP(bnp + ".weight"), TP(bnp + ".bias"), TP(bnp + ".running_mean"), TP(bnp + ".running_var"), training,
-                     TW(float, h->o_ss));
+                     TW(float, h->o_ss), tps, vtps, cvec, (float)h->B);
   LO_LAUNCH_CHECK("bn_finalize");
   return LO_OK;
 }
 static int t_bn_apply(LoTeacher* h, const f16* raw, const float* ls, const f16* identity, f16* y, int C, int dst_pitch, int dst_off,
-                      int mode, float* pool_partial, void* ws, hipStream_t st) {
-  BnApplyArgs a{raw, TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode, T_HW / 64};
-  LoProfScope _p("lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode ? 3 : 2), st);
+                      int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr) {
+  BnApplyArgs a{raw, TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode, T_HW / 64, cvec};
+  LoProfScope _p("lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode == 1 ? 3 : 2), st);
   hipLaunchKernelGGL(lo_bn_apply_kernel, dim3(64, h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("bn_apply");
   return LO_OK;
@@ -731,6 +883,8 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   const size_t px = (size_t)B * T_HW;
   if (!h->att_zeroed || h->att_zeroed_ws != ws) {
     LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
+    LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * 128 * 2, st));
+    LO_HIP(hipMemsetAsync(TW(void, h->o_qin), 0, (size_t)B * 1024 * 128 * 2, st));
     h->att_zeroed = true; h->att_zeroed_ws = ws;
   }
   float* bnp = TW(float, h->o_bnp);
@@ -776,6 +930,31 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
       LO_TRYT(lo_conv_run(h->g3, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
       LO_TRYT(t_bn_finalize(h, bnp, mt3, 128, p + ".conv1.2", P, ws, training, st));
       LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_bnA), 128, 128, 0, 0, nullptr, ws, st));
+      if (h->sparse) {
+        // k | v at every position (rows 128..383 of the qkv weight), q only for the 543 written positions
+        LO_TRYT(lo_conv_run(h->gkv, TW(f16, h->o_bnA), TW(f16, h->o_wqkv[e][l]) + 128 * 128, TP(p + ".attention.qkv.bias") + 128, nullptr,
+                            TW(f16, h->o_qkv), nullptr, nullptr, 1, st));
+        {
+          LoProfScope _p("lo_t_attn", 0, 0, st);
+          hipLaunchKernelGGL(lo_t_gather_q_kernel, dim3((B * 543 * 16 + 255) / 256), dim3(256), 0, st, TW(f16, h->o_bnA), TW(f16, h->o_qin), B);
+        }
+        LO_LAUNCH_CHECK("t_gather_q");
+        LO_TRYT(lo_conv_run(h->gpc, TW(f16, h->o_qin), TW(f16, h->o_wqkv[e][l]), TP(p + ".attention.qkv.bias"), nullptr, TW(f16, h->o_qc), nullptr, nullptr, 1, st));
+        {
+          LoProfScope _p("lo_t_attn", 0, 0, st);
+          hipLaunchKernelGGL(lo_t_attn_sparse_kernel, dim3((B * 543 + 3) / 4), dim3(256), 0, st, TW(f16, h->o_qc), TW(f16, h->o_qkv), TW(f16, h->o_attc), B);
+        }
+        LO_LAUNCH_CHECK("t_attn_sparse");
+        LO_TRYT(lo_conv_run(h->gpc, TW(f16, h->o_attc), TW(f16, h->o_wproj[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_projc), nullptr, nullptr, 1, st));
+        LO_TRYT(lo_conv_run(h->g3c, TW(f16, h->o_projc), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), nullptr, TW(f16, h->o_rawBc), nullptr, nullptr, 1, st, nullptr, &ex));
+        const int tm = lo_conv_tile_m(h->g3c);
+        LO_REQUIRE(tm == 64 || tm == 128, "teacher sparse path: unexpected conv tile height %d", tm);
+        const float* cv = TW(float, h->o_cvec[e][l]);
+        LO_TRYT(t_bn_finalize(h, bnp, B * 1024 / tm, 128, p + ".conv2.2", P, ws, training, st, 1024 / tm, 6 * 128 / tm, cv));
+        LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawBc), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 2, l == 2 ? TW(float, h->o_poolp) : nullptr, ws, st, cv));
+        xin = xout;
+        continue;
+      }
       LO_TRYT(lo_conv_run(h->gq, TW(f16, h->o_bnA), TW(f16, h->o_wqkv[e][l]), TP(p + ".attention.qkv.bias"), nullptr, TW(f16, h->o_qkv), nullptr, nullptr, 1, st));
       {
         LoProfScope _p("lo_t_attn", 0, 0, st);

@@ -168,3 +168,26 @@ def test_hybrid_two_steps_match_reference_trace():
             assert err <= lim, (s, c, m[c], trace[s, j])
     assert int(g["teacher_params_with_grad"]) == 28
     np.testing.assert_allclose(t.gate[2].weight.detach().cpu().numpy()[:4, :8], g["gate_w_after"], atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+def test_sparse_expert_path_equals_dense_path(training, monkeypatch):
+    """The default expert path computes conv2 / proj only on the 6 image rows the attention quirk leaves non-constant and
+    k|v instead of q|k|v; LO_T_DENSE=1 runs every convolution in full.  Same outputs, same BatchNorm running statistics."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(3)).cuda()
+    outs, stats = [], []
+    for dense in ("0", "1"):
+        monkeypatch.setenv("LO_T_DENSE", dense)
+        t = LunarMoETeacher(dropout_rate=0.0); t.load_state_dict(S); t = t.to("cuda")
+        t.train(training)
+        o = t(x)
+        outs.append({k: v.detach().cpu() for k, v in o.items() if v is not None})
+        stats.append({k: v.detach().cpu().clone() for k, v in t.state_dict().items() if "running_" in k})
+    for k in outs[0]:
+        assert (outs[0][k] - outs[1][k]).abs().max().item() <= 5e-4, k
+    for k in stats[0]:
+        ref = stats[1][k]
+        assert (stats[0][k] - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), k
