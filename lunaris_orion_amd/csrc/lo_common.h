@@ -44,13 +44,14 @@ int lo_check_hip(hipError_t e, const char* what);
 // one predictable branch per launcher.
 // ---------------------------------------------------------------------------------------------
 extern bool g_lo_prof_on;
+extern const char* g_lo_prof_tag;   // when set, replaces the name of the records opened while it is set (per-call-site breakdowns)
 void lo_prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void lo_prof_end(hipStream_t st);
 struct LoProfScope {
   hipStream_t st;
   bool on;
   LoProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s), on(g_lo_prof_on) {
-    if (on) lo_prof_begin(name, flops, bytes, s);
+    if (on) lo_prof_begin(g_lo_prof_tag ? g_lo_prof_tag : name, flops, bytes, s);
   }
   ~LoProfScope() {
     if (on) lo_prof_end(st);

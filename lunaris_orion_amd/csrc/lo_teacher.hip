@@ -391,71 +391,150 @@ __global__ __launch_bounds__(128) void lo_t_cvec_kernel(const f16* __restrict__ 
   cvec[k * 128 + co] = (float)(f16)v;
 }
 
-// query rows: qin[b][p][128] = bnA[b][qtok(p)][128] for p < 543 (16-byte chunks; thread = (b, p, chunk))
-__global__ __launch_bounds__(256) void lo_t_gather_q_kernel(const f16* __restrict__ bnA, f16* __restrict__ qin, int B) {
+// ---- folded attention ------------------------------------------------------------------------------------------
+// With x = BN(conv1 output) (fp16), q = Wq x_q + bq, k_j = Wk x_j + bk, v_j = Wv x_j + bv and a softmax over the 32 keys
+// of one chunk, the q.bk term is constant along the keys and drops out, so per head h
+//     score_j = (0.25 Wk_h^T (Wq_h x_q + bq_h)) . x_j  =: u_h . x_j          (0.25 = head_dim^-0.5)
+//     proj(att)  = sum_h (Wp[:,h] Wv_h) (sum_j p_hj x_j) + Wp bv + bp       (sum_j p_hj = 1)
+// i.e. k and v are never materialised: U = Xq WU^T + ub (one GEMM over the 543 query rows per sample, WU = the 8
+// stacked 128x128 matrices 0.25 Wk_h^T Wq_h), the kernel below turns (U row, 32 x rows) into z_h = sum_j p_hj x_j, and
+// proj = [z_1..z_8, 1] WZ^T + bp (one GEMM, K = 1024 + 64).  Weight-only products WU / ub / WZ are built at pack time.
+
+// WU[(h,c)][c'] = 0.25 sum_d Wk[h16+d][c] Wq[h16+d][c'];  ub[(h,c)] = 0.25 sum_d Wk[h16+d][c] bq[h16+d].  grid 1024, block 128
+__global__ __launch_bounds__(128) void lo_t_fold_qk_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                           f16* __restrict__ wu, float* __restrict__ ub) {
+  const int r = blockIdx.x, h = r >> 7, c = r & 127, cp = threadIdx.x;
+  float acc = 0.f, accb = 0.f;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    float wk = wqkv[(size_t)(128 + h * 16 + d) * 128 + c];
+    acc += wk * wqkv[(size_t)(h * 16 + d) * 128 + cp];
+    accb += wk * bqkv[h * 16 + d];
+  }
+  wu[(size_t)r * 128 + cp] = (f16)(0.25f * acc);
+  if (cp == 0) ub[r] = 0.25f * accb;
+}
+// WZ[o][(h,c)] = sum_d Wp[o][h16+d] Wv[h16+d][c];  WZ[o][1024] = sum_hd Wp[o][hd] bv[hd];  WZ[o][1025..1087] = 0.  grid 128, block 256
+__global__ __launch_bounds__(256) void lo_t_fold_pv_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                           const float* __restrict__ wp, f16* __restrict__ wz) {
+  const int o = blockIdx.x;
+  for (int col = threadIdx.x; col < 1088; col += 256) {
+    float acc = 0.f;
+    if (col < 1024) {
+      const int h = col >> 7, c = col & 127;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) acc += wp[o * 128 + h * 16 + d] * wqkv[(size_t)(256 + h * 16 + d) * 128 + c];
+    } else if (col == 1024) {
+      for (int k = 0; k < 128; ++k) acc += wp[o * 128 + k] * bqkv[256 + k];
+    }
+    wz[(size_t)o * 1088 + col] = (f16)acc;
+  }
+}
+
+// query rows: qin[b*543 + p][128] = fp16(BN(raw[b][qtok(p)]))  (16-byte chunks; thread = (row, chunk))
+__global__ __launch_bounds__(256) void lo_t_gather_q_kernel(const f16* __restrict__ raw, const float* __restrict__ ss,
+                                                            f16* __restrict__ qin, int B) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int chunk = gid & 15, row = gid >> 4;
   if (row >= B * 543) return;
   const int b = row / 543, p = row - b * 543;
   const int qtok = p < 512 ? 32 * p : 32 * 511 + (p - 511);
-  *reinterpret_cast<f16x8*>(qin + ((size_t)b * 1024 + p) * 128 + chunk * 8) =
-      *reinterpret_cast<const f16x8*>(bnA + ((size_t)b * T_HW + qtok) * 128 + chunk * 8);
+  f16x8 v = *reinterpret_cast<const f16x8*>(raw + ((size_t)b * T_HW + qtok) * 128 + chunk * 8), o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * ss[(chunk * 8 + j) * 2] + ss[(chunk * 8 + j) * 2 + 1]);
+  *reinterpret_cast<f16x8*>(qin + (size_t)row * 128 + chunk * 8) = o;
 }
 
-// the attention above on the split operands of the sparse path: q [B][1024][128] (row p = query of written position p),
-// kv [B][16384][256] (k | v), att [B][1024][128] (rows >= 543 stay zero)
-__global__ __launch_bounds__(256) void lo_t_attn_sparse_kernel(const f16* __restrict__ qc, const f16* __restrict__ kv,
-                                                               f16* __restrict__ att, int B) {
-  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int per_b = 512 + 31;
-  if (wave_g >= B * per_b) return;
-  const int b = wave_g / per_b, p = wave_g - b * per_b;
+// byte offset of 16-byte chunk ch (0..15) of row `row` in a [rows][128 x fp16] LDS image that serves row reads
+// (ds_read_b128) and transposed reads (ds_read_b64_tr_b16) alike
+__device__ __forceinline__ int t_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// one wave per written position p of sample b (chunk = min(p, 511)): x = BN(raw rows of the chunk) -> LDS (fp16),
+// S^T[key][head] = X U^T on MFMA (the key order of the M index is chosen so that the accumulators ARE the A operand of
+// the second product), softmax over the 32 keys (8 in-lane values x 4 lane groups), Z[head][c] = P X on MFMA with X
+// fragments by transposed LDS reads; Z row (8 x 128 fp16 + the constant-one column 1024) -> Z[b*1024 + p][1088].
+__global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __restrict__ raw, const float* __restrict__ ss,
+                                                               const f16* __restrict__ U, f16* __restrict__ Z, int B) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4][12288];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + wave;
+  if (wave_g >= B * 543) return;                        // wave-uniform: EXEC stays all ones for the transposed reads
+  const int b = wave_g / 543, p = wave_g - b * 543;
   const int chunk = p < 512 ? p : 511;
-  const int head = lane >> 3, part = lane & 7;
-  const f16* qp = qc + ((size_t)b * 1024 + p) * 128 + head * 16;
-  const f16* base = kv + (size_t)b * T_HW * 256;
-  f16x8 q0 = *reinterpret_cast<const f16x8*>(qp), q1 = *reinterpret_cast<const f16x8*>(qp + 8);
-  float sc[4];
+  unsigned char* sx = smem[wave];
+  unsigned char* su = sx + 8192;
+  unsigned char* sz = su + 2048;
+  {
+    const int c0 = (lane & 15) * 8;
+    float sc[8], sh[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const f16* kp = base + (size_t)(32 * chunk + part * 4 + k) * 256 + head * 16;
-    f16x8 k0 = *reinterpret_cast<const f16x8*>(kp), k1 = *reinterpret_cast<const f16x8*>(kp + 8);
-    float s = 0.f;
+    for (int j = 0; j < 8; ++j) { sc[j] = ss[(c0 + j) * 2]; sh[j] = ss[(c0 + j) * 2 + 1]; }
+    const f16* src = raw + ((size_t)b * T_HW + 32 * chunk) * 128;
+    f16x8 v[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) s += (float)q0[d] * (float)k0[d] + (float)q1[d] * (float)k1[d];
-    sc[k] = s * 0.25f;
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f16x8*>(src + (size_t)(i * 64 + lane) * 8);
+    const f16* usrc = U + (size_t)(b * 543 + p) * 1024;
+    f16x8 u0 = *reinterpret_cast<const f16x8*>(usrc + lane * 8), u1 = *reinterpret_cast<const f16x8*>(usrc + (64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[i][j] * sc[j] + sh[j]);
+      *reinterpret_cast<f16x8*>(sx + t_off(i * 4 + (lane >> 4), lane & 15)) = o;
+    }
+    *reinterpret_cast<f16x8*>(su + t_off(lane >> 4, lane & 15)) = u0;
+    *reinterpret_cast<f16x8*>(su + t_off(4 + (lane >> 4), lane & 15)) = u1;
   }
-  float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int m = lane & 15, g = lane >> 4;
+  // M index m = 4q + i  <->  key 8(q&1) + 4(q>>1) + i (+16 for the second tile): lane group g then owns keys
+  // r0..r0+3 and 16+r0..16+r0+3, r0 = 8(g&1) + 4(g>>1), which makes the transposed reads below conflict-free
+  const int keyrow = 8 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  float e[4], l = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { e[k] = __expf(sc[k] - m); l += e[k]; }
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) l += __shfl_xor(l, o, 64);
-  float acc[16];
-#pragma unroll
-  for (int d = 0; d < 16; ++d) acc[d] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const f16* vp = base + (size_t)(32 * chunk + part * 4 + k) * 256 + 128 + head * 16;
-    f16x8 v0 = *reinterpret_cast<const f16x8*>(vp), v1 = *reinterpret_cast<const f16x8*>(vp + 8);
-    float pw = e[k] / l;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) { acc[d] += pw * (float)v0[d]; acc[8 + d] += pw * (float)v1[d]; }
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ch = 4 * ks + g;
+    f16x8 bu = *reinterpret_cast<const f16x8*>(su + t_off(m & 7, ch));
+    if (m >= 8) bu = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 a0 = *reinterpret_cast<const f16x8*>(sx + t_off(keyrow, ch));
+    f16x8 a1 = *reinterpret_cast<const f16x8*>(sx + t_off(16 + keyrow, ch));
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bu, s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bu, s1, 0, 0, 0);
   }
+  // softmax over the 32 keys of head m: 8 values here, the rest in lanes m+16, m+32, m+48
+  float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float e[8], l = 0.f;
 #pragma unroll
-  for (int d = 0; d < 16; ++d)
+  for (int r = 0; r < 4; ++r) { e[r] = __expf(s0[r] - mx); e[4 + r] = __expf(s1[r] - mx); }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) acc[d] += __shfl_xor(acc[d], o, 64);
-  if (part == 0) {
-    f16x8 o0, o1;
+  for (int r = 0; r < 8; ++r) l += e[r];
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  f16x8 pf;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) { o0[d] = (f16)acc[d]; o1[d] = (f16)acc[8 + d]; }
-    f16* dst = att + ((size_t)b * 1024 + p) * 128 + head * 16;
-    *reinterpret_cast<f16x8*>(dst) = o0;
-    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+  for (int r = 0; r < 8; ++r) pf[r] = (f16)(e[r] * inv);
+  const int r0 = 8 * (g & 1) + 4 * (g >> 1), tq = m >> 2, tp = m & 3;
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) {
+    h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sx + t_off(r0 + tq, 2 * ct + (tp >> 1)) + 8 * (tp & 1)));
+    h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sx + t_off(16 + r0 + tq, 2 * ct + (tp >> 1)) + 8 * (tp & 1)));
+    f16x8 bf = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+    f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, bf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if (g < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f16*>(sz + ((4 * g + r) * 128 + ct * 16 + m) * 2) = (f16)z[r];
+    }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  f16* dst = Z + (size_t)(b * 1024 + p) * 1088;
+  *reinterpret_cast<f16x8*>(dst + lane * 8) = *reinterpret_cast<const f16x8*>(sz + lane * 16);
+  *reinterpret_cast<f16x8*>(dst + (64 + lane) * 8) = *reinterpret_cast<const f16x8*>(sz + (64 + lane) * 16);
+  if (lane == 0) *reinterpret_cast<f16x8*>(dst + 1024) = (f16x8){(f16)1.0f, 0, 0, 0, 0, 0, 0, 0};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -699,10 +778,12 @@ struct LoTeacher {
   size_t o_wp3[8][3][2];      // packed 3x3 weights (expert, layer, conv1/conv2)
   size_t o_wqkv[8][3], o_wproj[8][3], o_wpw[3], o_wfus;
   LoGeom g3, gq, gp, gpw, gfus;
-  // sparse expert path (default; LO_T_DENSE=1 selects the dense one): k|v projection, compact (8 image rows) q / proj / conv2
+  // sparse expert path (default; LO_T_DENSE=1 selects the dense one): folded attention (no k / v tensors), proj and
+  // conv2 on the 8 image rows per sample that are not a constant field
   bool sparse;
-  LoGeom gkv, gpc, g3c;
-  size_t o_qin, o_qc, o_attc, o_projc, o_rawBc, o_cvec[8][3];
+  LoGeom gU, gZ, g3c;
+  size_t o_qin, o_U, o_Z, o_projc, o_rawBc, o_cvec[8][3], o_wu[8][3], o_ub[8][3], o_wz[8][3];
+  int qrows;                  // query rows of the U GEMM: B * 543 rounded up to a multiple of 128
   size_t ws_bytes;
   bool att_zeroed;
   const void* att_zeroed_ws;
@@ -715,6 +796,8 @@ static size_t t_idx(const LoTeacher* h, const std::string& k) {
 #define TP(name) (P + h->off[t_idx(h, name)])
 #define TW(T, o) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (o))
 #define LO_TRYT(call) do { int _r = (call); if (_r != LO_OK) return _r; } while (0)
+// a teacher igemm launch reported under its own profiler name
+#define LO_TAGGED(tag, call) do { g_lo_prof_tag = (tag); int _r = (call); g_lo_prof_tag = nullptr; if (_r != LO_OK) return _r; } while (0)
 
 extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out) {
   LO_REQUIRE(out && B >= 1, "lo_teacher_create: bad argument");
@@ -797,14 +880,18 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
   h->o_wfus = take((size_t)128 * 192 * 2);
   const char* dense = getenv("LO_T_DENSE");
   h->sparse = !(dense && atoi(dense) != 0);
-  LO_TRYT(lo_make_geom(&h->gkv, LO_LINEAR, B, 128, 128, 128, 256));
-  LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, 128, 128));
+  h->qrows = ((B * 543 + 127) / 128) * 128;
+  LO_TRYT(lo_make_geom(&h->gU, LO_LINEAR, h->qrows / 128, 1, 128, 128, 1024));
+  LO_TRYT(lo_make_geom(&h->gZ, LO_LINEAR, B, 8, 128, 1088, 128));
   LO_TRYT(lo_make_geom(&h->g3c, LO_CONV3_S1, B, 8, 128, 128, 128));
   const size_t cpx = (size_t)B * 1024;
-  h->o_qin = take(cpx * 128 * 2); h->o_qc = take(cpx * 128 * 2); h->o_attc = take(cpx * 128 * 2);
+  h->o_qin = take((size_t)h->qrows * 128 * 2); h->o_U = take((size_t)h->qrows * 1024 * 2); h->o_Z = take(cpx * 1088 * 2);
   h->o_projc = take(cpx * 128 * 2); h->o_rawBc = take(cpx * 128 * 2);
   for (int e = 0; e < num_experts; ++e)
-    for (int l = 0; l < 3; ++l) h->o_cvec[e][l] = take(6 * 128 * 4);
+    for (int l = 0; l < 3; ++l) {
+      h->o_cvec[e][l] = take(6 * 128 * 4);
+      h->o_wu[e][l] = take((size_t)1024 * 128 * 2); h->o_ub[e][l] = take(1024 * 4); h->o_wz[e][l] = take((size_t)128 * 1088 * 2);
+    }
   h->ws_bytes = off;
   *out = h;
   return LO_OK;
@@ -833,6 +920,12 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
       hipLaunchKernelGGL(lo_t_cvec_kernel, dim3(6), dim3(128), 0, st, TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"),
                          TP(p + ".attention.proj.bias"), TW(float, h->o_cvec[e][l]));
       LO_LAUNCH_CHECK("t_cvec");
+      hipLaunchKernelGGL(lo_t_fold_qk_kernel, dim3(1024), dim3(128), 0, st, TP(p + ".attention.qkv.weight"), TP(p + ".attention.qkv.bias"),
+                         TW(f16, h->o_wu[e][l]), TW(float, h->o_ub[e][l]));
+      LO_LAUNCH_CHECK("t_fold_qk");
+      hipLaunchKernelGGL(lo_t_fold_pv_kernel, dim3(128), dim3(256), 0, st, TP(p + ".attention.qkv.weight"), TP(p + ".attention.qkv.bias"),
+                         TP(p + ".attention.proj.weight"), TW(f16, h->o_wz[e][l]));
+      LO_LAUNCH_CHECK("t_fold_pv");
     }
   const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
   for (int b = 0; b < 3; ++b)
@@ -861,7 +954,7 @@ static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, co
 static int t_bn_apply(LoTeacher* h, const f16* raw, const float* ls, const f16* identity, f16* y, int C, int dst_pitch, int dst_off,
                       int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr) {
   BnApplyArgs a{raw, TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode, T_HW / 64, cvec};
-  LoProfScope _p("lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode == 1 ? 3 : 2), st);
+  LoProfScope _p(mode ? "lo_bn_apply (block tail)" : "lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode == 1 ? 3 : 2), st);
   hipLaunchKernelGGL(lo_bn_apply_kernel, dim3(64, h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("bn_apply");
   return LO_OK;
@@ -883,8 +976,8 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   const size_t px = (size_t)B * T_HW;
   if (!h->att_zeroed || h->att_zeroed_ws != ws) {
     LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
-    LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * 128 * 2, st));
-    LO_HIP(hipMemsetAsync(TW(void, h->o_qin), 0, (size_t)B * 1024 * 128 * 2, st));
+    LO_HIP(hipMemsetAsync(TW(void, h->o_Z), 0, (size_t)B * 1024 * 1088 * 2, st));    // rows >= 543 of every sample stay zero
+    LO_HIP(hipMemsetAsync(TW(void, h->o_qin), 0, (size_t)h->qrows * 128 * 2, st));
     h->att_zeroed = true; h->att_zeroed_ws = ws;
   }
   float* bnp = TW(float, h->o_bnp);
@@ -927,26 +1020,23 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     for (int l = 0; l < 3; ++l) {
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
       f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
-      LO_TRYT(lo_conv_run(h->g3, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+      LO_TAGGED("t_conv1 (igemm)", lo_conv_run(h->g3, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
       LO_TRYT(t_bn_finalize(h, bnp, mt3, 128, p + ".conv1.2", P, ws, training, st));
-      LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_bnA), 128, 128, 0, 0, nullptr, ws, st));
       if (h->sparse) {
-        // k | v at every position (rows 128..383 of the qkv weight), q only for the 543 written positions
-        LO_TRYT(lo_conv_run(h->gkv, TW(f16, h->o_bnA), TW(f16, h->o_wqkv[e][l]) + 128 * 128, TP(p + ".attention.qkv.bias") + 128, nullptr,
-                            TW(f16, h->o_qkv), nullptr, nullptr, 1, st));
+        // folded attention: BN(conv1) is applied on the fly, k / v never exist (see lo_t_attn_folded_kernel)
         {
-          LoProfScope _p("lo_t_attn", 0, 0, st);
-          hipLaunchKernelGGL(lo_t_gather_q_kernel, dim3((B * 543 * 16 + 255) / 256), dim3(256), 0, st, TW(f16, h->o_bnA), TW(f16, h->o_qin), B);
+          LoProfScope _p("lo_t_gather_q", 0, 0, st);
+          hipLaunchKernelGGL(lo_t_gather_q_kernel, dim3((B * 543 * 16 + 255) / 256), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ss), TW(f16, h->o_qin), B);
         }
         LO_LAUNCH_CHECK("t_gather_q");
-        LO_TRYT(lo_conv_run(h->gpc, TW(f16, h->o_qin), TW(f16, h->o_wqkv[e][l]), TP(p + ".attention.qkv.bias"), nullptr, TW(f16, h->o_qc), nullptr, nullptr, 1, st));
+        LO_TAGGED("t_U (igemm)", lo_conv_run(h->gU, TW(f16, h->o_qin), TW(f16, h->o_wu[e][l]), TW(float, h->o_ub[e][l]), nullptr, TW(f16, h->o_U), nullptr, nullptr, 1, st));
         {
-          LoProfScope _p("lo_t_attn", 0, 0, st);
-          hipLaunchKernelGGL(lo_t_attn_sparse_kernel, dim3((B * 543 + 3) / 4), dim3(256), 0, st, TW(f16, h->o_qc), TW(f16, h->o_qkv), TW(f16, h->o_attc), B);
+          LoProfScope _p("lo_t_attn_folded", 2.0 * B * 543 * 2 * 8 * 32 * 128, 2.0 * px * 128 + 2.0 * B * 543 * 2112, st);
+          hipLaunchKernelGGL(lo_t_attn_folded_kernel, dim3((B * 543 + 3) / 4), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ss), TW(f16, h->o_U), TW(f16, h->o_Z), B);
         }
-        LO_LAUNCH_CHECK("t_attn_sparse");
-        LO_TRYT(lo_conv_run(h->gpc, TW(f16, h->o_attc), TW(f16, h->o_wproj[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_projc), nullptr, nullptr, 1, st));
-        LO_TRYT(lo_conv_run(h->g3c, TW(f16, h->o_projc), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), nullptr, TW(f16, h->o_rawBc), nullptr, nullptr, 1, st, nullptr, &ex));
+        LO_LAUNCH_CHECK("t_attn_folded");
+        LO_TAGGED("t_proj (igemm)", lo_conv_run(h->gZ, TW(f16, h->o_Z), TW(f16, h->o_wz[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_projc), nullptr, nullptr, 1, st));
+        LO_TAGGED("t_conv2c (igemm)", lo_conv_run(h->g3c, TW(f16, h->o_projc), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), nullptr, TW(f16, h->o_rawBc), nullptr, nullptr, 1, st, nullptr, &ex));
         const int tm = lo_conv_tile_m(h->g3c);
         LO_REQUIRE(tm == 64 || tm == 128, "teacher sparse path: unexpected conv tile height %d", tm);
         const float* cv = TW(float, h->o_cvec[e][l]);
@@ -955,6 +1045,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         xin = xout;
         continue;
       }
+      LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_bnA), 128, 128, 0, 0, nullptr, ws, st));
       LO_TRYT(lo_conv_run(h->gq, TW(f16, h->o_bnA), TW(f16, h->o_wqkv[e][l]), TP(p + ".attention.qkv.bias"), nullptr, TW(f16, h->o_qkv), nullptr, nullptr, 1, st));
       {
         LoProfScope _p("lo_t_attn", 0, 0, st);

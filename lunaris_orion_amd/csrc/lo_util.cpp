@@ -16,6 +16,7 @@ int lo_check_hip(hipError_t e, const char* what) {
 #include <string>
 #include <vector>
 bool g_lo_prof_on = false;
+const char* g_lo_prof_tag = nullptr;
 namespace {
 struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
 std::vector<Rec> g_recs;
