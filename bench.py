@@ -54,6 +54,30 @@ def collect_profile(lib):
     return rows
 
 
+def cpu_baseline_hybrid(latent: int, batch: int = 4):
+    """One full hybrid step of the CPU oracle (VAE step + two teacher forwards + head gradients), bounded sample."""
+    from oracle import teacher_ref as T
+    from oracle import vae_ref as R
+    cores = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    P = {k: torch.randn(shp) * (0.02 if len(shp) > 1 else 0.0) + (1.0 if k.endswith(".1.weight") else 0.0)
+         for k, shp in R.param_shapes(latent).items()}
+    tr = R.OracleTrainer(P)
+    S = T.closed_form_teacher_state(embedding_dim=256)
+    x = synth_sprites(batch, 321)
+    eps = torch.randn(batch, latent)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        T.teacher_forward(x, S, training=True)
+    recon = tr.step(x, eps, 0.0, True)["recon"]
+    with torch.no_grad():
+        T.teacher_forward(recon, S, training=True)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "sprites/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle, one hybrid step (VAE step + 2 teacher forwards, fp32, {cores} threads), batch {batch} latent {latent}, no warm-up"}
+
+
 def cpu_baseline(batch: int, latent: int, steps: int):
     """The oracle (CPU restatement, fp32, all host cores) on a bounded sample of the same workload."""
     from oracle import vae_ref as R
@@ -230,6 +254,8 @@ def main():
                                           "workload": f"full hybrid _process_batch: VAE step + 2 teacher forwards (feature_dim 128, 4 experts, "
                                                       f"embedding_dim 256) + reward/advantage + gate/quality-head update, batch {B}, latent {args.latent}",
                                           "quality_scores": hm["quality_scores"], "recon_loss": hm["recon_loss"]}
+            if not args.no_cpu_baseline:
+                out["config3_full_hybrid"]["cpu_baseline"] = cpu_baseline_hybrid(args.latent)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.latent, args.cpu_steps)
     if dist is not None:

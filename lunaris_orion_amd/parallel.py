@@ -68,6 +68,14 @@ class FlatGradSync:
                 g.div_(self.world)
         self._pending.clear()
 
+    def average_small(self, t: torch.Tensor) -> None:
+        """Average a few fp32 scalars in place (never compressed): the batch means behind the reward baseline."""
+        if self.world == 1 and not self.force:
+            return
+        dist.all_reduce(t, op=self._op(), group=self.group)
+        if self.backend != "nccl":
+            t.div_(self.world)
+
     def __call__(self, flat_grads: torch.Tensor) -> None:
         """Average `flat_grads` in place across ranks; the result is ordered on the current stream."""
         self.begin(flat_grads)

@@ -176,7 +176,16 @@ class HybridStepper(VAEStepper):
             t(images)                                   # train_hybrid.py:853-855 (side effects only)
         tout = t(recon)                                 # train_hybrid.py:865
         h, ws = self._teacher_setup(B)
-        _lib.check(_lib.lib.lo_hybrid_reward(tout["quality_scores"].data_ptr(), tout["semantic_score"].data_ptr(), B,
+        q_rows, s_rows, n_rows = tout["quality_scores"], tout["semantic_score"], B
+        if self.grad_sync is not None and (getattr(self.grad_sync, "world", 1) > 1 or getattr(self.grad_sync, "force", False)):
+            # data parallel: the baseline / advantage are functions of the batch means only (train_hybrid.py:870-883);
+            # one 5-float all-reduce keeps them identical on every rank
+            means = torch.cat([q_rows.mean(dim=0), s_rows.mean(dim=0)]).contiguous()
+            self.grad_sync.average_small(means)
+            self._reward_rows = (means[:4].reshape(1, 4).contiguous(), means[4:5].reshape(1, 1).contiguous())
+            q_rows, s_rows = self._reward_rows
+            n_rows = 1
+        _lib.check(_lib.lib.lo_hybrid_reward(q_rows.data_ptr(), s_rows.data_ptr(), n_rows,
                                              float(self.semantic_weight), float(self.reward_scale), float(self.baseline_momentum),
                                              float(self.quality_weight), float(self.accum), self.reward_state.data_ptr(),
                                              self.reward_out.data_ptr(), self.adv_dev.data_ptr(), st), "lo_hybrid_reward")

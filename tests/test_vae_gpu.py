@@ -221,6 +221,22 @@ for sync in (None, FlatGradSync(force=True), FlatGradSync(force=True, compress_f
 torch.cuda.synchronize()
 assert abs(out[0]["recon_loss"] - out[1]["recon_loss"]) == 0.0 and out[0]["grad_norm"] == out[1]["grad_norm"], out
 assert abs(out[0]["recon_loss"] - out[2]["recon_loss"]) < 1e-4, out
+# the hybrid step under data parallelism: gradient ranges of both models + the 5-float reward-mean exchange
+from oracle import teacher_ref as T
+from lunaris_orion_amd.teacher import LunarMoETeacher
+from lunaris_orion_amd.trainer import HybridStepper
+hy = []
+for sync in (None, FlatGradSync(force=True)):
+    m = LunarisCoreVAE(L); m.load_state_dict(P); m = m.to("cuda")
+    t = LunarMoETeacher(dropout_rate=0.0); t.load_state_dict(T.closed_form_teacher_state()); t = t.to("cuda").train()
+    hs = HybridStepper(m, t, grad_sync=sync)
+    for s in range(2):
+        hs.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
+    hy.append(hs.metrics())
+torch.cuda.synchronize()
+for k in ("recon_loss", "baseline", "quality_reward", "teacher_loss"):
+    assert abs(hy[0][k] - hy[1][k]) <= 1e-6, (k, hy)
+assert abs(hy[0]["advantage"] - hy[1]["advantage"]) <= 1e-7, hy
 dist.destroy_process_group()
 print("RCCL_PATH_OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
