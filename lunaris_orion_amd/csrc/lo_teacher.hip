@@ -1014,7 +1014,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_feat), 128, 128, 0, 0, TW(float, h->o_poolp), ws, st));
   LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
   // ---- experts (lunar_evaluator.py:260-275, 422-428)
-  const int mt3 = (int)(px / lo_conv_tile_m(h->g3));
+  const int mt3 = lo_conv_bn_rows(h->g3);   // BatchNorm partial rows of the conv1 epilogue (igemm: M tiles; fused-tap kernel: pixel tiles)
   for (int e = 0; e < h->E; ++e) {
     const f16* xin = TW(f16, h->o_feat);
     for (int l = 0; l < 3; ++l) {

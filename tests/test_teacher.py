@@ -191,3 +191,33 @@ def test_sparse_expert_path_equals_dense_path(training, monkeypatch):
     for k in stats[0]:
         ref = stats[1][k]
         assert (stats[0][k] - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), k
+
+
+@pytest.mark.gpu
+def test_teacher_forward_with_fused_tap_conv_kernel():
+    """The 8-wave fused-tap 3x3 kernel (lo_conv3x3_pp; selected by default only on long grids, e.g. batch 64) forced on for
+    the small parity batch: same tolerances as the default path.  LO_HALO is read once per process -> subprocess."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import teacher_ref as T, vae_ref as R
+from lunaris_orion_amd.teacher import LunarMoETeacher
+S = T.closed_form_teacher_state()
+m = LunarMoETeacher(dropout_rate=0.0); m.load_state_dict(S); m = m.to("cuda").train()
+x = R.normalise_sprites(R.closed_form_sprites(2))
+out = m(x.cuda()); torch.cuda.synchronize()
+with torch.no_grad():
+    ref, stats = T.teacher_forward(x, S, training=True)
+for k, t in {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}.items():
+    d = (out[k].cpu() - ref[k]).abs().max().item()
+    assert d <= t, (k, d)
+k = "experts.2.1.conv1.2.running_var"
+assert (m.state_dict()[k].cpu() - stats[k]).abs().max().item() <= 2e-3 * max(1.0, stats[k].abs().max().item())
+print("FUSED_TAP_OK")
+""" % root
+    env = dict(os.environ, LO_HALO="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert "FUSED_TAP_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -1,0 +1,10 @@
+#!/bin/bash
+# builds the diagnostic (stamped) binary of the fused-tap conv kernel into /tmp/conv3_stamp
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+F="--offload-arch=gfx950 -O3 -std=c++17 -DLO_STAMPS"
+hipcc $F -x hip -c $R/lunaris_orion_amd/csrc/lo_conv3.hip -o /tmp/s_conv3.o
+hipcc $F -x hip -c $R/lunaris_orion_amd/csrc/lo_conv.hip -o /tmp/s_conv.o
+hipcc $F -c $R/lunaris_orion_amd/csrc/lo_util.cpp -o /tmp/s_util.o
+hipcc $F -x hip -c $R/tools/conv3_stamp.cpp -o /tmp/s_main.o
+hipcc --offload-arch=gfx950 /tmp/s_conv3.o /tmp/s_conv.o /tmp/s_util.o /tmp/s_main.o -o /tmp/conv3_stamp
