@@ -17,7 +17,6 @@ loss is a real number, checkpoints are written.  Launch one process per GPU with
 from __future__ import annotations
 
 import argparse
-import glob
 import logging
 import os
 import signal
@@ -76,35 +75,7 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-class SpriteShards:
-    """sprites*.npy (uint8 [N,128,128,3], memory-mapped) + labels*.csv; only the images feed the step (train_hybrid.py:995)."""
-
-    def __init__(self, data_dir: str):
-        files = sorted(glob.glob(os.path.join(data_dir, "sprites*.npy")))
-        labels = sorted(glob.glob(os.path.join(data_dir, "labels*.csv")))
-        if not files or not labels:
-            raise ValueError(f"No sprites or labels files found in {data_dir}")
-        self.shards = [np.load(f, mmap_mode="r") for f in files]
-        for f, s in zip(files, self.shards):
-            if s.shape[1:] != (128, 128, 3):
-                raise ValueError(f"Expected 128x128x3 images in {f}, got {s.shape[1:]}")
-        self.cum = np.cumsum([0] + [len(s) for s in self.shards])
-        n_rows = 0
-        for lf in labels:
-            with open(lf, "rb") as fh:
-                n_rows += max(0, sum(1 for _ in fh) - 1)
-        if n_rows != len(self):
-            raise AssertionError(f"Mismatch between total sprites ({len(self)}) and labels ({n_rows})")
-
-    def __len__(self):
-        return int(self.cum[-1])
-
-    def batch_u8(self, idx: np.ndarray) -> torch.Tensor:
-        out = np.empty((len(idx), 128, 128, 3), dtype=np.uint8)
-        for j, i in enumerate(idx):
-            f = int(np.searchsorted(self.cum, i, side="right") - 1)
-            out[j] = self.shards[f][i - self.cum[f]]
-        return torch.from_numpy(out)
+from lunaris_orion_amd.data import SpriteFeeder, SpriteShards, epoch_batches   # noqa: E402
 
 
 def main(argv=None):
@@ -205,11 +176,10 @@ def main(argv=None):
     done = False
     for epoch in range(args.num_epochs):
         t0 = time.time()
-        order = np.random.permutation(train_idx)[rank::world]
         epoch_losses = []
-        for b in range(steps_per_epoch):
-            idx = np.sort(order[b * per_rank:(b + 1) * per_rank])
-            images = stepper.decode_sprites(data.batch_u8(idx).to("cuda", non_blocking=True))
+        feeder = SpriteFeeder(data, epoch_batches(train_idx, per_rank, rank, world), per_rank, device=f"cuda:{local}")
+        for b, batch_u8 in enumerate(feeder):
+            images = stepper.decode_sprites(batch_u8)
             stepper.step(images, batch_idx=b)
             global_step += 1
             if global_step % args.log_every == 0 or b == steps_per_epoch - 1:
@@ -225,6 +195,7 @@ def main(argv=None):
                          f"kl {metrics['kl_loss']:.4f} lr {m['lr']:.2e} grad_norm {m['grad_norm']:.3f}")
             if interrupted["flag"] or (args.max_steps and global_step >= args.max_steps):
                 done = True
+                feeder.close()
                 break
         avg = float(np.mean(epoch_losses)) if epoch_losses else float("nan")
         log.info(f"Epoch {epoch + 1} Summary: Time {(time.time() - t0) / 60:.2f} min, Average Loss {avg:.4f}, Best Loss {best_loss:.4f}")
