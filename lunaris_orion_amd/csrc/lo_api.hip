@@ -362,7 +362,7 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     auto add = [&](ConvLayer& c, const LoGeom& g, size_t o_dst) {
       LoPackJob j;
       j.src = PRM(c.p_w); j.dst = WSP(f16, o_dst); j.total = (int)lo_packed_weight_elems(g); j.block0 = blocks; j.g = g;
-      blocks += (j.total + 255) / 256;
+      blocks += lo_pack_blocks(g);
       jobs.push_back(j);
     };
     for (int s = 0; s < 4; ++s)
@@ -501,7 +501,14 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
     LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
     LO_HIP(hipEventRecord(h->ev_wg[k & 1], h->side));
   } else {
-    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st));
+    static char wtag[32][64];
+    if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
+      snprintf(wtag[k & 31], 64, "wgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
+      g_lo_prof_tag = wtag[k & 31];
+    }
+    int r_ = lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st);
+    g_lo_prof_tag = nullptr;
+    if (r_ != LO_OK) return r_;
   }
   if (din) {
     LoGnBwdFuse gb, *gbp = nullptr;
@@ -511,7 +518,14 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       prod->np1 = (c.gd.GH * c.gd.GW / lo_conv_tile_m(c.gd)) * c.gd.n_phase;
       gbp = &gb;
     }
-    LO_TRY(lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st, gbp));
+    static char dtag[32][64];
+    if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
+      snprintf(dtag[k & 31], 64, "dgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gd.Cin, c.gd.Cout);
+      g_lo_prof_tag = dtag[k & 31];
+    }
+    int r_ = lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st, gbp);
+    g_lo_prof_tag = nullptr;
+    if (r_ != LO_OK) return r_;
   }
   return LO_OK;
 }

@@ -128,23 +128,44 @@ __global__ void lo_pack_weight_kernel(const float* __restrict__ w, f16* __restri
   wp[i] = (f16)w[(size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t]];
 }
 
-// all packs of a model in ONE launch: jobs live in device memory (uploaded once per workspace by the executor)
+// all packs of a model in ONE launch: jobs live in device memory (uploaded once per workspace by the executor).
+// A block owns 16 output channels x 64 reduced channels x all taps: the canonical weight is read along its contiguous
+// axis (the 9 or 16 taps of one (n, c) pair are adjacent floats; the pairs themselves are adjacent along c for forward
+// convs / transposed-conv gradients and along n for the others), staged as fp16 in LDS, and written along c, the
+// contiguous axis of the packed operand.  lo_pack_blocks() gives the block count of one job.
+int lo_pack_blocks(const LoGeom& g) { return ((g.Cout + 15) / 16) * ((g.Cin + 63) / 64); }
 __global__ __launch_bounds__(256) void lo_pack_all_kernel(const LoPackJob* __restrict__ jobs, int njobs) {
-  // blockIdx.x -> job by linear search over the (<= 64) block prefix sums
+  __shared__ f16 tile[16][17][66];
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
   const LoPackJob& J = jobs[j];
-  int i = ((int)blockIdx.x - J.block0) * 256 + threadIdx.x;
-  if (i >= J.total) return;
   const LoGeom& g = J.g;
-  int p = 0;
-#pragma unroll
-  for (int q = 1; q < LO_MAX_PHASE; ++q) if (q < g.n_phase && i >= g.wofs[q]) p = q;
-  int jj = i - g.wofs[p];
-  int K = g.T[p] * g.Cin;
-  int n = jj / K, k = jj - n * K;
-  int t = k / g.Cin, c = k - t * g.Cin;
-  J.dst[i] = (f16)J.src[(size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t]];
+  const int tid = threadIdx.x;
+  const int tiles_c = (g.Cin + 63) / 64;
+  const int b = (int)blockIdx.x - J.block0;
+  const int n0 = (b / tiles_c) * 16, c0 = (b % tiles_c) * 64;
+  const bool n_fast = g.sn < g.sc;
+  const int t_all = n_fast ? g.sn : g.sc;     // taps of the canonical weight (9, 16; 1 for a Linear)
+  for (int q = tid; q < 1024; q += 256) {
+    int nl, cl;
+    if (n_fast) { nl = q & 15; cl = q >> 4; } else { cl = q & 63; nl = q >> 6; }
+    const int n = n0 + nl, c = c0 + cl;
+    if (n < g.Cout && c < g.Cin) {
+      const float* src = J.src + (size_t)n * g.sn + (size_t)c * g.sc;
+      for (int t = 0; t < t_all; ++t) tile[nl][t][cl] = (f16)src[t];
+    }
+  }
+  __syncthreads();
+  int sum_t = 0;
+  for (int p = 0; p < g.n_phase; ++p) sum_t += g.T[p];
+  const int cl = tid & 63, c = c0 + cl;
+  for (int r = tid >> 6; r < 16 * sum_t; r += 4) {
+    const int nl = r / sum_t;
+    int t = r - nl * sum_t, p = 0;
+    while (t >= g.T[p]) { t -= g.T[p]; ++p; }
+    const int n = n0 + nl;
+    if (n < g.Cout && c < g.Cin) J.dst[(size_t)g.wofs[p] + ((size_t)n * g.T[p] + t) * g.Cin + c] = tile[nl][g.rs[p][t]][cl];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ const char* lo_get_error();
 // lo_conv.hip
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
 int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st);
+int lo_pack_blocks(const LoGeom& g);   // blocks of one job in the fused pack launch
 struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
 struct LoConvExtra { int act; float* bn_partial; };   // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
