@@ -761,11 +761,32 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 }
 
 // sum the split slabs and scatter to the canonical fp32 gradient:  grad[n*sn + c*sc + rs] = scale * sum_s slab
-// one thread = 4 consecutive packed elements (same n and tap, consecutive c): 16-byte slab loads
+// block = 64 column threads x 4 split groups; a column = 4 consecutive packed elements (same n and tap, consecutive c:
+// 16-byte slab loads); group sg sums splits sg, sg+4, ... (4 loads in flight), the four partial sums are added in a fixed
+// order through LDS (bitwise reproducible).  Small weight tensors (36 k elements, up to 256 splits) get 4x the
+// workgroups and 4x the loads in flight of a one-thread-per-column loop.
 __global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
                                                               int total, int nsplit, float scale) {
-  int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= total) return;
+  __shared__ f32x4 part[4][64];
+  const int col = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int i = (blockIdx.x * 64 + col) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    const float* src = slab + i;
+    int s = sg;
+    for (; s + 12 < nsplit; s += 16) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (size_t)s * total);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 4) * total);
+      f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 8) * total);
+      f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 12) * total);
+      v += a0; v += a1; v += a2; v += a3;
+    }
+    for (; s < nsplit; s += 4) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * total);
+  }
+  part[sg][col] = v;
+  __syncthreads();
+  if (sg != 0 || i >= total) return;
+  v = part[0][col] + part[1][col] + part[2][col] + part[3][col];
   int p = 0;
 #pragma unroll
   for (int q = 1; q < LO_MAX_PHASE; ++q) if (q < g.n_phase && i >= g.wofs[q]) p = q;
@@ -773,8 +794,6 @@ __global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __res
   int K = g.T[p] * g.Cin;
   int n = j / K, k = j - n * K;
   int t = k / g.Cin, c = k - t * g.Cin;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < nsplit; ++s) v += *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + i);
   float* dst = grad + (size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t];
 #pragma unroll
   for (int e = 0; e < 4; ++e) dst[(size_t)e * g.sc] = v[e] * scale;
@@ -991,7 +1010,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   if (a.direct) return LO_OK;
   int total = a.packed_elems;
   LoProfScope _p2("lo_wgrad_reduce", 0, 4.0 * total * (a.nsplit + 1), st);
-  hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
+  hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
   LO_LAUNCH_CHECK("wgrad_reduce");
   return LO_OK;
 }
