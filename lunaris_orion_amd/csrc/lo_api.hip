@@ -163,7 +163,8 @@ struct LoVae {
   bool forward_done, loss_done;
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
-  hipEvent_t ev_dv[2], ev_wg[2], ev_join;
+  hipEvent_t ev_dv[2], ev_wg[2], ev_join, ev_pre, ev_cast;
+  bool cast_pending;          // the Linear-layer fp16 copies are being refreshed on the side stream (lo_vae_pack)
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
@@ -318,6 +319,7 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
   h->ws_bytes = ar.off;
   h->side = nullptr;
+  h->cast_pending = false;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
   h->fuse_gnb = getenv("LO_GNB_FUSE") != nullptr;   // measured neutral on MI355X (the heavier epilogue cancels the saved launches): off by default
   if (h->overlap) {
@@ -325,7 +327,9 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
     for (int i = 0; i < 2 && ok; ++i)
       ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h->ev_wg[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_cast, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); h->overlap = false; }   // no GPU in this process (CPU-side planning only)
   }
   *out = h;
@@ -337,7 +341,7 @@ extern "C" void lo_vae_destroy(LoVae* h) {
   if (h->overlap) {
     (void)hipStreamDestroy(h->side);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_dv[i]); (void)hipEventDestroy(h->ev_wg[i]); }
-    (void)hipEventDestroy(h->ev_join);
+    (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre); (void)hipEventDestroy(h->ev_cast);
   }
   delete h;
 }
@@ -382,14 +386,35 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     h->packjobs_for_ws = ws;
     h->packjobs_for_params = (const void*)P;
   }
+  // the four Linear-layer copies (0.15 ms at L=512) are not needed before the end of the encoder: refresh them on the side
+  // stream while the conv pack and the encoder forward run; the consumers wait on ev_cast (vae_wait_casts)
+  hipStream_t cs = st;
+  if (h->overlap && !g_lo_prof_on) {
+    LO_HIP(hipEventRecord(h->ev_pre, st));
+    LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
+    cs = h->side;
+  }
   LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, st));
   const int L = h->L;
   // encoder head: [fc_mu.weight ; fc_logvar.weight] is one contiguous [2L][32768] fp32 matrix in the flat buffer
   LO_REQUIRE(h->p_off[h->idx_fc_lv_w] == h->p_off[h->idx_fc_mu_w] + (size_t)L * 32768, "flat layout: head weights not adjacent");
-  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, st));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, st));
-  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, st));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, st));
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, cs));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, cs));
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, cs));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, cs));
+  if (cs != st) {
+    LO_HIP(hipEventRecord(h->ev_cast, cs));
+    h->cast_pending = true;
+  }
+  return LO_OK;
+}
+
+// first consumer of a Linear-layer fp16 copy after lo_vae_pack: order it after the side-stream refresh
+static int vae_wait_casts(LoVae* h, hipStream_t st) {
+  if (h->cast_pending) {
+    LO_HIP(hipStreamWaitEvent(st, h->ev_cast, 0));
+    h->cast_pending = false;
+  }
   return LO_OK;
 }
 
@@ -405,6 +430,7 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
 static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* ws, float* recon, const float* target,
                                hipStream_t st) {
   const int B = h->B;
+  LO_TRY(vae_wait_casts(h, st));
   LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
                      nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st));
@@ -444,6 +470,7 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
   }
   // ---- heads + reparameterisation (lunar_generate.py:150-152, 259-261)
   LO_TRY(lo_nhwc_to_nchw_f16(cur, WSP(f16, h->o_xflat), B, 64, 512, st));
+  LO_TRY(vae_wait_casts(h, st));
   LO_TRY(lo_conv_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_wp_head), nullptr, nullptr, nullptr, nullptr,
                      WSP(float, h->o_slab_head), h->head_split, st));
   LO_REQUIRE(h->p_off[h->idx_fc_lv_b] == h->p_off[h->idx_fc_mu_b] + (size_t)L, "flat layout: head biases not adjacent");
