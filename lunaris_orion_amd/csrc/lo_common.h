@@ -58,6 +58,15 @@ struct LoProfScope {
   }
 };
 
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at LDS offset lds_off, lane-linear) as inline asm.
+// Kernels whose fragments come from ds_read_b64_tr_b16 use this form instead of __builtin_amdgcn_global_load_lds: after
+// the builtin the compiler cannot tell the transposed reads from the DMA destinations and puts `s_waitcnt vmcnt(0)` in
+// front of them, which serialises every K step on the loads just issued (measured: lo_wgrad_tn, round 1).  With the asm
+// form the ordering is the kernel's own counted `s_waitcnt vmcnt(N)` + barrier, as written.  lds_off must be wave-uniform.
+__device__ __forceinline__ void lo_dma16(const void* gptr, unsigned int lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_off) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Geometry of one implicit-GEMM convolution-like op (forward conv, transposed conv as sub-pixel
 // phases, and every data-gradient of those).  All tensors are NHWC fp16.

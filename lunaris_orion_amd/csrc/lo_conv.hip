@@ -661,8 +661,7 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
       bool ok = live && m < a.M && a_col[i] < g.Cout;
       const int pix = (((n_img << sh_hout) + oy) << sh_wout) + ox;
       const f16* src = ok ? a.dy + (cout_pow2 ? ((size_t)pix << g.lg_cout) : (size_t)pix * g.Cout) + a_col[i] : zpage;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + (wave * IA + i) * 1024), 16, 0, 0);
+      lo_dma16(src, (unsigned int)(size_t)(sa + (wave * IA + i) * 1024));
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -671,8 +670,7 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
       int iy = gy * g.in_stride + dyo, ix = gx * g.in_stride + dxo;
       bool ok = live && m < a.M && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
       const f16* src = ok ? a.x + ((size_t)((((n_img << sh_hin) + iy) << sh_win) + ix) << sh_cin) + b_col[i] : zpage;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sb + (wave * IB + i) * 1024), 16, 0, 0);
+      lo_dma16(src, (unsigned int)(size_t)(sb + (wave * IB + i) * 1024));
     }
   };
 
@@ -954,6 +952,7 @@ static inline int wgrad_bkp(const LoGeom& g) { return ((long)g.B * g.GH * g.GW) 
 
 // number of pixel splits the wgrad launcher will use for this geometry (callers size the slab with it)
 int lo_wgrad_nsplit(const LoGeom& g) {
+  if (int n3 = lo_wgrad3_nsplit(g)) return n3;   // multi-tap kernel (3x3 stride 1)
   int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g), bkp = wgrad_bkp(g);
   int taps = 0;
   for (int p = 0; p < g.n_phase; ++p) taps += g.T[p];
@@ -976,6 +975,19 @@ int lo_wgrad_nsplit(const LoGeom& g) {
 }
 
 int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st) {
+  if (lo_wgrad3_nsplit(g) > 0) {
+    int nsplit = 0;
+    const int total = geom_packed_elems(g);
+    {
+      LoProfScope _p("lo_wgrad3x3_mt", geom_flops(g), geom_bytes(g), st);
+      int r = lo_wgrad3_run(g, x, dy, slab, st, &nsplit);
+      if (r != LO_OK) return r;
+    }
+    LoProfScope _p2("lo_wgrad_reduce", 0, 4.0 * total * (nsplit + 1), st);
+    hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
+    LO_LAUNCH_CHECK("wgrad_reduce");
+    return LO_OK;
+  }
   WgradArgs a;
   a.x = x; a.dy = dy; a.slab = slab; a.g = g; a.grad = grad; a.scale = scale;
   a.M = g.B * g.GH * g.GW;

@@ -92,6 +92,9 @@ WGRAD_CASES = [
     (KIND_S1, 2, 64, 64, 64),
     (KIND_S1, 4, 512, 512, 8),
     (KIND_S1, 2, 128, 128, 32),
+    (KIND_S1, 3, 256, 256, 16),          # multi-tap kernel: odd batch (uneven pixel splits)
+    (KIND_S1, 1, 64, 128, 16),           # ... Cin != Cout
+    (KIND_S1, 5, 128, 64, 8),            # ... 8-pixel-wide maps (4x8 chunks)
     (KIND_S2, 2, 64, 128, 64),
     (KIND_S2, 2, 256, 512, 16),
     (KIND_T4, 2, 512, 256, 8),
