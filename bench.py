@@ -179,7 +179,16 @@ def main():
         if not rows:
             rows = {"(not profiled)": [1.0, 1, 0.0, 0.0]}
         total_ms = sum(r[0] for r in rows.values())
-        dom_name, dom = max(rows.items(), key=lambda kv: kv[1][0])
+        # the tile instantiations of one template are one kernel: lo_igemm_nt<128,64,64>, <64,64,64>, ... -> lo_igemm_nt
+        fam = {}
+        for k, r in rows.items():
+            f = fam.setdefault(k.split("<")[0].split(" ")[0], [0.0, 0, 0.0, 0.0, 0])
+            for i in range(4):
+                f[i] += r[i]
+            f[4] += 1
+        dom_name, dom = max(fam.items(), key=lambda kv: kv[1][0])
+        n_inst = dom[4]
+        dom = dom[:4]
         d_ms, d_n, d_fl, d_by = dom
         if d_fl > 0:
             roof = {"bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s"}
@@ -197,7 +206,7 @@ def main():
                 roof["algorithmic_bytes_per_launch"] = d_by / max(d_n, 1)
         except Exception:
             pass
-        roof["kernel"] = dom_name
+        roof["kernel"] = dom_name + (f" ({n_inst} tile instantiations)" if n_inst > 1 else "")
         roof["launches_per_step"] = d_n / max(args.prof_steps, 1)
         roof["avg_launch_ms"] = d_ms / max(d_n, 1)
         roof["share_of_kernel_time"] = d_ms / total_ms

@@ -1005,11 +1005,13 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g);
   a.taps = taps;
   dim3 grid(((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps * a.nsplit);
+  static const int wg_stages = getenv("LO_WGRAD_STAGES") ? atoi(getenv("LO_WGRAD_STAGES")) : 2;   // 64-pixel steps: LDS stages
   {
     LoProfScope _p("lo_wgrad_tn", geom_flops(g), geom_bytes(g), st);
 #define LO_WG(BMW, BNW)                                                                            \
   do {                                                                                             \
-    if (bkp == 64) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 2, 64>), grid, dim3(256), 0, st, a);   \
+    if (bkp == 64 && wg_stages == 3 && (BMW + BNW) <= 192) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 3, 64>), grid, dim3(256), 0, st, a);   \
+    else if (bkp == 64) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 2, 64>), grid, dim3(256), 0, st, a);   \
     else hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 3, 32>), grid, dim3(256), 0, st, a);             \
   } while (0)
     if (bmw == 128 && bnw == 128) LO_WG(128, 128);

@@ -23,7 +23,7 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("lo_wgrad_tn", "lo_igemm_nt", "lo_gn_bwd_apply", "lo_gn_bwd_reduce", "lo_gn_fwd", "lo_adamw", "lo_wgrad_reduce"):
+    for key in ("lo_wgrad3x3_mt", "lo_wgrad_tn", "lo_igemm_nt", "lo_conv3x3_pp", "lo_t_attn_folded", "lo_bn_apply", "lo_gn_bwd_apply", "lo_gn_bwd_reduce", "lo_gn_fwd", "lo_adamw", "lo_wgrad_reduce"):
         if key in name:
             return key
     return name.split("(")[0][:40]
