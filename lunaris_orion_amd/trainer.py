@@ -161,6 +161,17 @@ class HybridStepper(VAEStepper):
             self.t_v = torch.zeros(n, dtype=torch.float32, device=t._flat.device)
             self.t_scratch = torch.zeros(1028, dtype=torch.float32, device=t._flat.device)
             self._t_ready = True
+            pending = getattr(self, "_pending_teacher_opt", None)
+            if pending is not None:                       # optimizer state of a checkpoint (hostside.restore_checkpoint)
+                from collections import OrderedDict
+                from .hostside import flat_offsets, load_adamw_state_dict
+                tp = OrderedDict(t.named_parameters())
+                offs = flat_offsets(tp, t._flat)
+                rel = {k: (o - b.value if b.value <= o < e.value else 0) for k, o in offs.items()}
+                names = list(tp.keys())
+                live = {"state": {i: st for i, st in pending.get("state", {}).items() if b.value <= offs[names[int(i)]] < e.value}}
+                load_adamw_state_dict(live, tp, self.t_m, self.t_v, rel)
+                self._pending_teacher_opt = None
         rows = getattr(self, "_t_rows", None)
         if rows is None or rows.numel() != batch * (e.value - b.value):
             self._t_rows = torch.empty(batch * (e.value - b.value), dtype=torch.float32, device=t._flat.device)
@@ -175,6 +186,7 @@ class HybridStepper(VAEStepper):
         if self.run_dead_teacher_call:
             t(images)                                   # train_hybrid.py:853-855 (side effects only)
         tout = t(recon)                                 # train_hybrid.py:865
+        self.last_teacher_out = tout
         h, ws = self._teacher_setup(B)
         q_rows, s_rows, n_rows = tout["quality_scores"], tout["semantic_score"], B
         if self.grad_sync is not None and (getattr(self.grad_sync, "world", 1) > 1 or getattr(self.grad_sync, "force", False)):

@@ -27,6 +27,7 @@ def test_cli_flags_and_defaults_match_reference():
     for k, v in REFERENCE_DEFAULTS.items():
         assert getattr(args, k) == v, k
     assert len(REFERENCE_DEFAULTS) + 1 == 35      # + data_dir
+    assert args.generate_samples == 0 and args.max_steps == 0 and not args.vae_only      # additions default to off
 
 
 def test_unsupported_feature_dim_is_refused_loudly(tmp_path):
@@ -64,6 +65,26 @@ def test_cli_end_to_end_on_gpu(tmp_path):
     assert set(ck.keys()) >= {"global_step", "vae_state_dict", "teacher_state_dict", "vae_optimizer", "teacher_optimizer",
                               "vae_scheduler", "teacher_scheduler", "best_loss", "args"}
     assert len(ck["vae_state_dict"]) == 72
+    # the optimizer / scheduler entries are torch.optim state_dicts: they load into the objects the reference builds
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    m = LunarisCoreVAE(256)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=1e-6)
+    opt.load_state_dict(ck["vae_optimizer"])
+    sch.load_state_dict(ck["vae_scheduler"])
+    steps = 2 * (int(0.9 * 24) // 4)
+    assert int(float(opt.state_dict()["state"][0]["step"])) == steps and sch.last_epoch == steps
+    assert float(opt.state_dict()["state"][5]["exp_avg_sq"].abs().sum()) > 0
+    # resume: two more epochs continue from the saved step count and write a comparison image + decoded samples
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
+                        "--vae_only", "--batch_size", "4", "--gradient_accumulation_steps", "1", "--num_epochs", "1", "--log_every", "1",
+                        "--latent_dim", "256", "--resume_from", str(out / "checkpoints" / "latest.pt"), "--eval_save_freq", "3",
+                        "--generate_samples", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck2 = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=True)
+    assert ck2["global_step"] == ck["global_step"] + steps // 2
+    assert int(float(ck2["vae_optimizer"]["state"][0]["step"])) == steps + steps // 2
+    assert list((out / "eval_samples").glob("comparison_*.png")) and len(list(out.glob("sample_*.png"))) == 2
 
 
 @pytest.mark.gpu
@@ -80,3 +101,6 @@ def test_cli_hybrid_end_to_end_on_gpu(tmp_path):
     import torch
     ck = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
     assert len(ck["teacher_state_dict"]) == 351
+    # teacher optimizer state exists exactly for the 28 tensors that receive gradients in the reference (gate, quality heads)
+    assert len(ck["teacher_optimizer"]["state"]) == 28 and len(ck["teacher_optimizer"]["param_groups"][0]["params"]) == 252
+    assert "reward_state" in ck["lunaris_amd_extra"]

@@ -72,6 +72,7 @@ def build_parser() -> argparse.ArgumentParser:
     # additions of this build (defaults keep the reference behaviour)
     p.add_argument("--vae_only", action="store_true", help="shorthand for --reward_scale 0 --quality_weight 0")
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many micro-batches (0 = no limit)")
+    p.add_argument("--generate_samples", type=int, default=0, help="decode this many prior samples to PNG when training ends (lunar_generate.py:278-291)")
     return p
 
 
@@ -139,29 +140,19 @@ def main(argv=None):
     log.info(f"VAE Parameters - Total: {sum(p.numel() for p in vae.parameters()):,}")
     global_step, best_loss = 0, float("inf")
 
+    from lunaris_orion_amd import hostside
+
     def save_checkpoint(tag="latest"):
         if rank != 0:
             return
         torch.cuda.synchronize()
-        ckpt = {"global_step": global_step, "vae_state_dict": {k: v.detach().cpu() for k, v in vae.state_dict().items()},
-                "teacher_state_dict": ({k: v.detach().cpu() for k, v in teacher.state_dict().items()} if teacher is not None else {}),
-                "vae_optimizer": {"exp_avg": stepper.exp_avg.cpu(), "exp_avg_sq": stepper.exp_avg_sq.cpu(),
-                                                            "opt_steps": stepper.opt_steps},
-                "teacher_optimizer": {}, "vae_scheduler": {"last_epoch": stepper.opt_steps}, "teacher_scheduler": {},
-                "best_loss": best_loss, "args": vars(args)}
-        torch.save(ckpt, out_dir / "checkpoints" / f"{tag}.pt")
+        torch.save(hostside.checkpoint_dict(stepper, vae, teacher, global_step, best_loss, vars(args)), out_dir / "checkpoints" / f"{tag}.pt")
+        log.info(f"Checkpoint saved at step {global_step}")
 
     if args.resume_from:
         ck = torch.load(args.resume_from, map_location="cpu", weights_only=True)
-        vae.load_state_dict(ck["vae_state_dict"], strict=False)
-        vae = vae.to("cuda")
-        global_step, best_loss = ck.get("global_step", 0), ck.get("best_loss", float("inf"))
-        opt = ck.get("vae_optimizer") or {}
-        if "exp_avg" in opt:
-            vae.flat_parameters()
-            stepper.exp_avg.copy_(opt["exp_avg"])
-            stepper.exp_avg_sq.copy_(opt["exp_avg_sq"])
-            stepper.opt_steps = int(opt.get("opt_steps", 0))
+        global_step, best_loss = hostside.restore_checkpoint(ck, stepper, vae, teacher)
+        log.info(f"Successfully loaded checkpoint from step {global_step}")
 
     data = SpriteShards(args.data_dir)
     n_train = int(0.9 * len(data))
@@ -171,6 +162,7 @@ def main(argv=None):
     steps_per_epoch = (n_train // world) // per_rank          # drop_last (:569)
     log.info(f"Dataset initialized with {len(data)} samples; {steps_per_epoch} batches/epoch/rank")
 
+    early = hostside.EarlyStopping(patience=args.early_stopping_patience)
     interrupted = {"flag": False}
     signal.signal(signal.SIGINT, lambda *_: interrupted.__setitem__("flag", True))
     done = False
@@ -193,18 +185,31 @@ def main(argv=None):
                         writer.add_scalar(k, v, global_step)
                 log.info(f"step {global_step} loss {metrics['total_loss']:.4f} recon {metrics['recon_loss']:.4f} "
                          f"kl {metrics['kl_loss']:.4f} lr {m['lr']:.2e} grad_norm {m['grad_norm']:.3f}")
+            if rank == 0 and global_step % args.eval_save_freq == 0:                       # train_hybrid.py:951-952
+                recon = stepper.last[0]
+                tout = getattr(stepper, "last_teacher_out", None)
+                pth = hostside.save_comparison(out_dir / "eval_samples" / f"comparison_{global_step}_{time.strftime('%Y%m%d_%H%M%S')}.png", images, recon,
+                                               tout["quality_scores"] if tout else None, tout["semantic_score"] if tout else None)
+                log.info(f"Saved comparison image {pth.name}")
             if interrupted["flag"] or (args.max_steps and global_step >= args.max_steps):
                 done = True
                 feeder.close()
                 break
         avg = float(np.mean(epoch_losses)) if epoch_losses else float("nan")
         log.info(f"Epoch {epoch + 1} Summary: Time {(time.time() - t0) / 60:.2f} min, Average Loss {avg:.4f}, Best Loss {best_loss:.4f}")
+        early(avg)                                                                         # train_hybrid.py:1049-1052
+        if early.early_stop:
+            log.info("Early stopping triggered")
+            done = True
         if avg < best_loss:
             best_loss = avg
             save_checkpoint("best")
         save_checkpoint("latest")
         if done:
             break
+    if rank == 0 and args.generate_samples > 0:
+        paths = hostside.save_samples(out_dir, vae.sample(args.generate_samples), global_step)
+        log.info(f"Generated and saved {len(list(paths))} samples")
     if writer is not None:
         writer.close()
     log.info("Training completed.")
