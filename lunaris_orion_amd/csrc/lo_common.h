@@ -126,16 +126,17 @@ __device__ __forceinline__ float lo_wave_sum(float v) {
 }
 
 // mish(u) = u * tanh(softplus(u)) = u * t/(t+2), t = w(w+2), w = e^u   (lunar_generate.py:24-26; nn.Mish)
+// mish(u) = u tanh(softplus(u)) = u t / (t + 2),  t = e^u (e^u + 2): one v_exp_f32 and one v_rcp_f32 (1 ulp; an IEEE
+// division costs ~10 more VALU instructions and the GroupNorm kernels are VALU-bound on exactly this arithmetic)
 __device__ __forceinline__ float lo_mish(float u) {
   float w = __expf(fminf(u, 20.0f));
   float t = w * (w + 2.0f);
-  return u * (t / (t + 2.0f));
+  return u * t * __builtin_amdgcn_rcpf(t + 2.0f);
 }
-// d mish / du = tau + u * (1 - tau^2) * sigmoid(u),  tau = tanh(softplus(u))
+// d mish / du = tau + u (1 - tau^2) sigmoid(u),  tau = t / (t + 2);  (1 - tau^2) sigmoid(u) = 4 w (w + 1) / (t + 2)^2
 __device__ __forceinline__ float lo_mish_grad(float u) {
   float w = __expf(fminf(u, 20.0f));
   float t = w * (w + 2.0f);
-  float tau = t / (t + 2.0f);
-  float sig = w / (1.0f + w);
-  return tau + u * (1.0f - tau * tau) * sig;
+  float r = __builtin_amdgcn_rcpf(t + 2.0f);
+  return t * r + u * (4.0f * w * (w + 1.0f)) * (r * r);
 }
