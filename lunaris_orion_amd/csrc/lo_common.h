@@ -126,6 +126,28 @@ __device__ __forceinline__ float lo_wave_sum(float v) {
 }
 
 // mish(u) = u * tanh(softplus(u)) = u * t/(t+2), t = w(w+2), w = e^u   (lunar_generate.py:24-26; nn.Mish)
+// Two-wide forms for the GroupNorm kernels (VALU-bound: v_pk_mul_f32 / v_pk_fma_f32 process two fp32 values per lane and
+// instruction).  With p = e^u + 1:  t = p^2 - 1,  t + 2 = p^2 + 1,  tau = t r,  r = 1 / (p^2 + 1),
+// mish = u tau,  mish' = tau + 4 u w p r^2.
+typedef float lo_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lo_mish_parts2(lo_f2 u, lo_f2& w, lo_f2& p, lo_f2& r, lo_f2& tau) {
+  const lo_f2 c = __builtin_elementwise_min(u, (lo_f2){20.0f, 20.0f});
+  w = (lo_f2){__expf(c[0]), __expf(c[1])};
+  p = w + 1.0f;
+  const lo_f2 s = p * p + 1.0f;
+  r = (lo_f2){__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};
+  tau = (p * p - 1.0f) * r;
+}
+__device__ __forceinline__ lo_f2 lo_mish2(lo_f2 u) {
+  lo_f2 w, p, r, tau;
+  lo_mish_parts2(u, w, p, r, tau);
+  return u * tau;
+}
+__device__ __forceinline__ lo_f2 lo_mish_grad2(lo_f2 u) {
+  lo_f2 w, p, r, tau;
+  lo_mish_parts2(u, w, p, r, tau);
+  return tau + (u * 4.0f) * (w * p) * (r * r);
+}
 // mish(u) = u tanh(softplus(u)) = u t / (t + 2),  t = e^u (e^u + 2): one v_exp_f32 and one v_rcp_f32 (1 ulp; an IEEE
 // division costs ~10 more VALU instructions and the GroupNorm kernels are VALU-bound on exactly this arithmetic)
 __device__ __forceinline__ float lo_mish(float u) {

@@ -107,12 +107,15 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
       if (rr < rows) {
         f16x8 y;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float uu = (float)h[u][j] * sc[j] + sh[j];
-          float m = lo_mish(uu);
-          if (a.mode == GN_MODE_SKIP) m += (float)o[u][j];
-          else if (a.mode == GN_MODE_RES) m = lo_mish(m + (float)o[u][j]);
-          y[j] = (f16)m;
+        for (int j = 0; j < 8; j += 2) {
+          const lo_f2 hv = {(float)h[u][j], (float)h[u][j + 1]};
+          lo_f2 m = lo_mish2(hv * (lo_f2){sc[j], sc[j + 1]} + (lo_f2){sh[j], sh[j + 1]});
+          if (a.mode != GN_MODE_PLAIN) {
+            const lo_f2 ov = {(float)o[u][j], (float)o[u][j + 1]};
+            m = a.mode == GN_MODE_SKIP ? m + ov : lo_mish2(m + ov);
+          }
+          y[j] = (f16)m[0];
+          y[j + 1] = (f16)m[1];
         }
         *reinterpret_cast<f16x8*>(a.y + base + (size_t)rr * C) = y;
       }
@@ -144,17 +147,20 @@ struct GnBwdArgs {
   int dbg_skip;         // timing experiments only: 1 = return after the prologue
 };
 
-__device__ __forceinline__ void gn_du(const GnBwdArgs& a, float hv, float dyv, float ov, float sc, float sh,
-                                      float mean, float rstd, float& du, float& xhat, float& dsv) {
-  xhat = (hv - mean) * rstd;
-  float u = hv * sc + sh;
-  if (a.mode == GN_MODE_RES) {
-    float s = lo_mish(u) + ov;
-    dsv = dyv * lo_mish_grad(s);
-    du = dsv * lo_mish_grad(u);
+// two elements at a time: xhat = hv*rstd + nmr (nmr = -mean*rstd), u = hv*sc + sh
+__device__ __forceinline__ void gn_du2(int mode, lo_f2 hv, lo_f2 dyv, lo_f2 ov, lo_f2 sc, lo_f2 sh, lo_f2 rstd, lo_f2 nmr,
+                                       lo_f2& du, lo_f2& xhat, lo_f2& dsv) {
+  xhat = hv * rstd + nmr;
+  const lo_f2 u = hv * sc + sh;
+  if (mode == GN_MODE_RES) {
+    lo_f2 w, p, r, tau;
+    lo_mish_parts2(u, w, p, r, tau);
+    const lo_f2 gu = tau + (u * 4.0f) * (w * p) * (r * r);
+    dsv = dyv * lo_mish_grad2(u * tau + ov);
+    du = dsv * gu;
   } else {
     dsv = dyv;
-    du = dyv * lo_mish_grad(u);
+    du = dyv * lo_mish_grad2(u);
   }
 }
 
@@ -164,18 +170,19 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
   const int C = a.C, G = C >> 3, CC = C >> 3;
   const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
   const int c0 = cc * 8;
-  float sc[8], sh[8], mean[8], rstd[8];
+  float sc[8], sh[8], nmr[8], rstd[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int grp = (c0 + j) / G;
-    mean[j] = a.stats[n * 16 + grp * 2];
+    const float mean = a.stats[n * 16 + grp * 2];
     rstd[j] = a.stats[n * 16 + grp * 2 + 1];
+    nmr[j] = -mean * rstd[j];
     sc[j] = a.gamma[c0 + j] * rstd[j];
-    sh[j] = a.beta[c0 + j] - mean[j] * sc[j];
+    sh[j] = a.beta[c0 + j] - mean * sc[j];
   }
-  float a1[8], a2[8];
+  lo_f2 a1[4], a2[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  for (int j = 0; j < 4; ++j) { a1[j] = (lo_f2){0.f, 0.f}; a2[j] = (lo_f2){0.f, 0.f}; }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;
@@ -197,12 +204,15 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
       if (rr < rows) {
         f16x8 dso;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float du, xh, dsv;
-          gn_du(a, (float)h[u][j], (float)d[u][j], a.mode == GN_MODE_RES ? (float)o[u][j] : 0.f, sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
-          a1[j] += du;
-          a2[j] += du * xh;
-          dso[j] = (f16)dsv;
+        for (int j = 0; j < 8; j += 2) {
+          lo_f2 du, xh, dsv;
+          const lo_f2 ov = a.mode == GN_MODE_RES ? (lo_f2){(float)o[u][j], (float)o[u][j + 1]} : (lo_f2){0.f, 0.f};
+          gn_du2(a.mode, (lo_f2){(float)h[u][j], (float)h[u][j + 1]}, (lo_f2){(float)d[u][j], (float)d[u][j + 1]}, ov,
+                 (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[j], rstd[j + 1]}, (lo_f2){nmr[j], nmr[j + 1]}, du, xh, dsv);
+          a1[j >> 1] += du;
+          a2[j >> 1] += du * xh;
+          dso[j] = (f16)dsv[0];
+          dso[j + 1] = (f16)dsv[1];
         }
         if (a.mode == GN_MODE_RES) *reinterpret_cast<f16x8*>(a.ds + base + (size_t)rr * C) = dso;
       }
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
   }
   // reduce over the row slots in a fixed order
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s_red[tid * 16 + j * 2] = a1[j]; s_red[tid * 16 + j * 2 + 1] = a2[j]; }
+  for (int j = 0; j < 8; ++j) { s_red[tid * 16 + j * 2] = a1[j >> 1][j & 1]; s_red[tid * 16 + j * 2 + 1] = a2[j >> 1][j & 1]; }
   __syncthreads();
   // C*2 outputs; thread t handles output (c = t>>1 ... ) looping
   for (int o = tid; o < C * 2; o += 256) {
@@ -256,23 +266,26 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
     s_c[tid] = tot / ((float)a.HW * (float)G);
   }
   __syncthreads();
-  float sc[8], sh[8], mean[8], rstd[8], gm[8], k1[8], k2[8];
+  // dv = rstd (gamma du - k1 - xhat k2) = du*ka - kb - xhat*kc
+  float sc[8], sh[8], nmr[8], rstd[8], ka[8], kb[8], kc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int grp = (c0 + j) / G;
     bool hi = grp != grp_lo;
-    mean[j] = hi ? st_hi[0] : st_lo[0];
+    const float mean = hi ? st_hi[0] : st_lo[0];
     rstd[j] = hi ? st_hi[1] : st_lo[1];
-    gm[j] = j < 4 ? gm0[j & 3] : gm1[j & 3];
-    sc[j] = gm[j] * rstd[j];
-    sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) - mean[j] * sc[j];
-    k1[j] = s_c[grp * 2];
-    k2[j] = s_c[grp * 2 + 1];
+    const float gm = j < 4 ? gm0[j & 3] : gm1[j & 3];
+    nmr[j] = -mean * rstd[j];
+    sc[j] = gm * rstd[j];
+    sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) - mean * sc[j];
+    ka[j] = rstd[j] * gm;
+    kb[j] = rstd[j] * s_c[grp * 2];
+    kc[j] = rstd[j] * s_c[grp * 2 + 1];
   }
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (a.dbg_skip) { if (k1[0] == 12345.f) a.dv[0] = (f16)k2[3]; return; }
+  if (a.dbg_skip) { if (kb[0] == 12345.f) a.dv[0] = (f16)kc[3]; return; }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;
@@ -294,13 +307,17 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
       if (rr < rows) {
         f16x8 out;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float du, xh, dsv;
-          gn_du(a, (float)h[u][j], (float)d[u][j], a.mode == GN_MODE_RES ? (float)o[u][j] : 0.f, sc[j], sh[j], mean[j], rstd[j], du, xh, dsv);
-          float dv = rstd[j] * (gm[j] * du - k1[j] - xh * k2[j]);
-          f16 dvh = (f16)dv;
-          out[j] = dvh;
-          acc[j] += (float)dvh;   // bias gradient = sum of the values the weight-gradient GEMM will also see
+        for (int j = 0; j < 8; j += 2) {
+          lo_f2 du, xh, dsv;
+          const lo_f2 ov = a.mode == GN_MODE_RES ? (lo_f2){(float)o[u][j], (float)o[u][j + 1]} : (lo_f2){0.f, 0.f};
+          gn_du2(a.mode, (lo_f2){(float)h[u][j], (float)h[u][j + 1]}, (lo_f2){(float)d[u][j], (float)d[u][j + 1]}, ov,
+                 (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[j], rstd[j + 1]}, (lo_f2){nmr[j], nmr[j + 1]}, du, xh, dsv);
+          const lo_f2 dv = du * (lo_f2){ka[j], ka[j + 1]} - (lo_f2){kb[j], kb[j + 1]} - xh * (lo_f2){kc[j], kc[j + 1]};
+          const f16 d0 = (f16)dv[0], d1 = (f16)dv[1];
+          out[j] = d0;
+          out[j + 1] = d1;
+          acc[j] += (float)d0;   // bias gradient = sum of the values the weight-gradient GEMM will also see
+          acc[j + 1] += (float)d1;
         }
         *reinterpret_cast<f16x8*>(a.dv + base + (size_t)rr * C) = out;
       }
