@@ -32,6 +32,12 @@ struct Conv3Args {
   float* gn_partial;   // [B][tiles per image][8][2] or null
   float* bn_partial;   // [B * tiles per image][Cout][2] or null (teacher epilogue)
   int act;             // 1: LeakyReLU(0.2) before the store (teacher epilogue)
+  // transform-on-load (lo_conv3x3_pp<..., XF=true>; the teacher's fused block tail): the logical input is
+  //   image rows 0..7 : xc [B][8][W][Cin] as stored        all other rows : T_nlev(...T_1(in)...),
+  //   T_l(x)[c] = lrelu(x[c] + kx[l][class][c]),  class = 0 interior, 1 left column, 2 right column, 3 bottom row, 4 / 5 its corners
+  const f16* xc;
+  const f16* kx;       // [nlev][6][Cin] fp16
+  int nlev;
   LoGeom g;
 #ifdef LO_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/conv3_stamp.cpp): [workgroup][wave][16] shader-clock stamps
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 //   A ring stage is overwritten (issue in M(s), interval >= 2s+1) after barrier 2s, which group 1 reaches only after the
 //   lgkmcnt(0) that retires its reads of step s-1 -- the last readers of that stage.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int TH, int TW>
+template <int BN, int TH, int TW, bool XF>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   constexpr int NW = 8, NTHR = 512, NSB = 4, D = 3;
   static_assert(TW == 16, "one 16-pixel fragment per tile row");
@@ -339,13 +345,16 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   constexpr int B_BYTES = BN * 128;
   constexpr int WGM = 4, WM = BM / WGM, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;
-  constexpr int MAIN_BYTES = 2 * PATCH_BYTES + NSB * B_BYTES;
+  constexpr int XF_LEV = 2, XF_C = 128;       // transform constants staged in LDS: [2 levels][6 classes][128 channels] fp16
+  constexpr int K_BYTES = XF ? XF_LEV * 6 * XF_C * 2 : 0;
+  constexpr int MAIN_BYTES = 2 * PATCH_BYTES + NSB * B_BYTES + K_BYTES;
   constexpr int EPI_BYTES = BM * OPITCH + NTHR * 64;
   constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
   unsigned char* const s_patch = smem;
   unsigned char* const s_b = smem + 2 * PATCH_BYTES;
+  unsigned char* const s_k = s_b + NSB * B_BYTES;
 
   const LoGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const uint32_t dyc = g.dyc[0], dxc = g.dxc[0];
 
   int p_src[PI];
+  unsigned p_xc = 0;   // XF: bit i = piece i of this lane comes from the compact rows buffer
 #pragma unroll
   for (int i = 0; i < PI; ++i) {
     int pp = (wave * PI + i) * 8 + (lane >> 3), pos = lane & 7;
@@ -374,6 +384,10 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int iy = y0 - 1 + py, ix = x0 - 1 + px;
     bool ok = pp < NPIX && px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     p_src[i] = ok ? ((n_img * H + iy) * W + ix) * Cin + ((pos ^ lo_swz3(pp)) * 8) : -1;
+    if (XF && ok && iy < 8) {
+      p_src[i] = ((n_img * 8 + iy) * W + ix) * Cin + ((pos ^ lo_swz3(pp)) * 8);
+      p_xc |= 1u << i;
+    }
   }
   int b_src[IB];
 #pragma unroll
@@ -389,7 +403,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       int off = -1;
 #pragma unroll
       for (int i = 0; i < PI; ++i) if (i == piece) off = p_src[i];
-      const f16* src = off >= 0 ? a.in + (off + cb * 64) : zpage;
+      const f16* base = (XF && ((p_xc >> piece) & 1u)) ? a.xc : a.in;
+      const f16* src = off >= 0 ? base + (off + cb * 64) : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_patch + buf * PATCH_BYTES + q * 1024), 16, 0, 0);
     }
@@ -421,13 +436,44 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const unsigned long long t_start = LO_T();
   unsigned long long acc_r = 0, acc_w1 = 0, acc_m = 0, acc_w2 = 0;
 #endif
+  // XF: in-place transform of a landed patch (all 8 waves, between two barriers): pixels of image rows >= 8 get
+  // T_nlev(..T_1(x)); rows 0..7 came from xc already transformed, pixels outside the image stay zero (the padding)
+  auto xform_patch = [&](int buf, int cb) __attribute__((always_inline)) {
+    unsigned char* pb = s_patch + buf * PATCH_BYTES;
+    for (int idx = tid; idx < NPIX * 8; idx += NTHR) {
+      const int pp = idx >> 3, pos = idx & 7;
+      const int py = pp / PW, px = pp - py * PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      if (px < TW + 2 && iy >= 8 && iy < H && (unsigned)ix < (unsigned)W) {
+        const int cls = (iy == H - 1 ? 3 : 0) + (ix == 0 ? 1 : (ix == W - 1 ? 2 : 0));
+        const int c = cb * 64 + ((pos ^ lo_swz3(pp)) * 8);
+        f16x8 v = *reinterpret_cast<const f16x8*>(pb + pp * 128 + pos * 16);
+        for (int lev = 0; lev < a.nlev; ++lev) {
+          const f16x8 k = *reinterpret_cast<const f16x8*>(s_k + ((lev * 6 + cls) * XF_C + c) * 2);
+          v = v + k;
+          v = __builtin_elementwise_max(v, v * (f16)0.2f);
+        }
+        *reinterpret_cast<f16x8*>(pb + pp * 128 + pos * 16) = v;
+      }
+    }
+  };
+  if (XF) {
+    for (int i = tid; i < a.nlev * 6 * XF_C / 8; i += NTHR)
+      *reinterpret_cast<f16x8*>(s_k + i * 16) = *reinterpret_cast<const f16x8*>(a.kx + i * 8);
+  }
   // ---- prologue: patch of channel block 0 and weight steps 0..2
 #pragma unroll
   for (int i = 0; i < PI; ++i) issue_patch_piece(0, 0, i);
 #pragma unroll
   for (int s = 0; s < D; ++s) issue_b(s, s);
   LO_VMCNT(IB * (D - 1));            // patch + step 0 landed (this wave's share)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // XF: the staged constants
   __builtin_amdgcn_s_barrier();
+  if (XF) {
+    xform_patch(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   if (grp == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one interval behind
 #ifdef LO_STAMPS
   const unsigned long long t_loop = LO_T();
@@ -488,7 +534,18 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #endif
     rs = (rs + 1 == NSB) ? 0 : rs + 1;
     ws = (ws + 1 == NSB) ? 0 : ws + 1;
-    if (++tap == 9) { tap = 0; ++cb; }
+    if (++tap == 9) {
+      tap = 0; ++cb;
+      if (XF && cb < KCB) {
+        // channel-block boundary: every wave waited for its own patch pieces (they are older than the two weight groups a
+        // wave may have in flight); re-join the groups, transform the new patch, restart the stagger
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        xform_patch(cb & 1, cb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+      }
+    }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
 #ifdef LO_STAMPS
@@ -645,7 +702,7 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
                  float* gn_partial, hipStream_t st, const LoConvExtra* ex) {
   int th, tw, bn, nw;
   LO_REQUIRE(conv3_tile(g, &th, &tw, &bn, &nw), "lo_conv3_run: geometry not supported by the fused-tap kernel");
-  Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, g};
+  Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, g};
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif
@@ -656,12 +713,36 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
   snprintf(name, sizeof(name), "lo_conv3x3_halo<%d,%dx%d>", bn, th, tw);
   LoProfScope _p(name, flops, bytes, st);
   static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;   // 0: lock-step 8-wave kernel (A/B knob)
-  if (nw == 8 && pp) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16>), dim3(tiles), dim3(512), 0, st, a);
+  if (nw == 8 && pp) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
   else if (nw == 8) hipLaunchKernelGGL((lo_conv3x3_halo<128, 16, 16, 8, 3>), dim3(tiles), dim3(512), 0, st, a);
   else if (tw == 16 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_halo<64, 8, 16, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
   else if (tw == 16 && bn == 128) hipLaunchKernelGGL((lo_conv3x3_halo<128, 8, 16, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
   else if (tw == 8 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_halo<64, 8, 8, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((lo_conv3x3_halo<128, 8, 8, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("conv3x3_halo");
+  return LO_OK;
+}
+
+// The 16x16-pixel fused-tap kernel with the transform-on-load (see Conv3Args): used by the teacher to fold the ExpertBlock
+// tail into the next block's conv1.  nlev = 0 is the plain kernel (any batch size: no grid-length heuristic here).
+bool lo_conv3_pp_applies(const LoGeom& g) {
+  return g.n_phase == 1 && g.T[0] == 9 && g.in_stride == 1 && g.out_stride == 1 && g.Cin % 64 == 0 && g.Cout % 128 == 0 &&
+         g.Hin % 16 == 0 && g.Win % 16 == 0 && g.Hin >= 16 && g.Cin <= 128;
+}
+int lo_conv3_run_pp_xf(const LoGeom& g, const f16* in, const f16* xc, const f16* kx, int nlev, const f16* wp, const float* bias,
+                       f16* out, hipStream_t st, const LoConvExtra* ex) {
+  LO_REQUIRE(lo_conv3_pp_applies(g), "lo_conv3_run_pp_xf: geometry not supported");
+  LO_REQUIRE(nlev >= 0 && nlev <= 2 && (nlev == 0 || (xc && kx)), "lo_conv3_run_pp_xf: bad transform arguments");
+  Conv3Args a{in, wp, bias, nullptr, out, nullptr, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, xc, kx, nlev, g};
+#ifdef LO_STAMPS
+  a.stamps = nullptr;
+#endif
+  const int tiles = g.B * (g.Hin / 16) * (g.Win / 16) * (g.Cout / 128);
+  double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
+  double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * (g.Cin + g.Cout) + 9.0 * g.Cin * g.Cout);
+  LoProfScope _p(nlev ? "lo_conv3x3_pp (transform on load)" : "lo_conv3x3_pp", flops, bytes, st);
+  if (nlev) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, true>), dim3(tiles), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
+  LO_LAUNCH_CHECK("conv3x3_pp_xf");
   return LO_OK;
 }

@@ -16,7 +16,10 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
 int lo_conv_tile_m(const LoGeom& g);
 int lo_conv_mt(const LoGeom& g);   // GroupNorm partial rows per sample the conv epilogue writes for this geometry
 int lo_conv3_tiles_per_image(const LoGeom& g, bool need_bn = false);
-int lo_conv_bn_rows(const LoGeom& g);   // BatchNorm partial rows written by lo_conv_run(..., ex) for this geometry
+int lo_conv_bn_rows(const LoGeom& g);
+bool lo_conv3_pp_applies(const LoGeom& g);
+int lo_conv3_run_pp_xf(const LoGeom& g, const f16* in, const f16* xc, const f16* kx, int nlev, const f16* wp, const float* bias,
+                       f16* out, hipStream_t st, const LoConvExtra* ex);   // BatchNorm partial rows written by lo_conv_run(..., ex) for this geometry
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                  float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr);
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);

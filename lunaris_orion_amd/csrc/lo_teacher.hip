@@ -537,6 +537,87 @@ __global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __rest
   if (lane == 0) *reinterpret_cast<f16x8*>(dst + 1024) = (f16x8){(f16)1.0f, 0, 0, 0, 0, 0, 0, 0};
 }
 
+// ---- fused block tail -------------------------------------------------------------------------------------------
+// ExpertBlock tail  x_l = lrelu(BN2(conv2) * layer_scale + x_{l-1})  (lunar_evaluator.py:273-275).  Outside image rows
+// 0..5 conv2 is one of six constant vectors, so there  x_l = lrelu(x_{l-1} + K_l[class]),  K_l[class][c] =
+// (cvec[class][c] * scale2[c] + shift2[c]) * layer_scale[c].  The full-resolution x_l is never written: the next block's
+// conv1 (lo_conv3x3_pp, transform on load) reads the expert's input `feat` and applies T_l .. T_1 to its LDS patch; only
+// image rows 0..7 exist as tensors (xc_l, [B][8][128][128]), and the global average pool of x_3 is one pass over feat.
+__global__ __launch_bounds__(256) void lo_t_kconst_kernel(const float* __restrict__ cvec, const float* __restrict__ ss,
+                                                          const float* __restrict__ ls, f16* __restrict__ kx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 6 * 128) return;
+  const int c = i & 127;
+  kx[i] = (f16)((cvec[i] * ss[c * 2] + ss[c * 2 + 1]) * ls[c]);
+}
+
+__device__ __forceinline__ int t_pos_class(int y, int x) { return (y == 127 ? 3 : 0) + (x == 0 ? 1 : (x == 127 ? 2 : 0)); }
+
+// rows 0..7 of x_l:  thread = (sample, row, column, 8-channel chunk).  idt: x_{l-1} rows (feat for l = 0, pitch 16384
+// pixels per sample; else the previous compact buffer, pitch 1024)
+__global__ __launch_bounds__(256) void lo_t_tail_compact_kernel(const f16* __restrict__ rawc, const float* __restrict__ ss,
+                                                                const float* __restrict__ ls, const float* __restrict__ cvec,
+                                                                const f16* __restrict__ idt, int idt_pitch, f16* __restrict__ xc, int B) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = gid & 15, p = (gid >> 4) & 1023, b = gid >> 14;
+  if (b >= B) return;
+  const int y = p >> 7, x = p & 127, c0 = chunk * 8;
+  f16x8 id = *reinterpret_cast<const f16x8*>(idt + ((size_t)b * idt_pitch + p) * 128 + c0), o, r;
+  if (y < 6) r = *reinterpret_cast<const f16x8*>(rawc + ((size_t)b * 1024 + p) * 128 + c0);
+  const int cls = t_pos_class(y, x);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float raw = y < 6 ? (float)r[j] : (float)(f16)cvec[cls * 128 + c0 + j];
+    float v = (raw * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1]) * ls[c0 + j] + (float)id[j];
+    o[j] = (f16)(v > 0.f ? v : 0.2f * v);
+  }
+  *reinterpret_cast<f16x8*>(xc + ((size_t)b * 1024 + p) * 128 + c0) = o;
+}
+
+// pooled partial sums of x_3 = T_3(T_2(T_1(feat))) (rows >= 8) / xc (rows 0..7): pool_partial[n][blk][c], 64 blocks of
+// 256 positions per sample (same layout as lo_bn_apply's pool output)
+__global__ __launch_bounds__(256) void lo_t_pool_xf_kernel(const f16* __restrict__ feat, const f16* __restrict__ xc,
+                                                           const f16* __restrict__ kx, float* __restrict__ pool_partial) {
+  __shared__ float s_red[256 * 8];
+  const int tid = threadIdx.x, n = blockIdx.y, blk = blockIdx.x;
+  const int cc = tid & 15, slot = tid >> 4, c0 = cc * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int r = slot; r < 256; r += 16) {
+    const int p = blk * 256 + r, y = p >> 7, x = p & 127;
+    float v[8];
+    if (y < 8) {
+      f16x8 h = *reinterpret_cast<const f16x8*>(xc + ((size_t)n * 1024 + p) * 128 + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    } else {
+      f16x8 h = *reinterpret_cast<const f16x8*>(feat + ((size_t)n * T_HW + p) * 128 + c0);
+      const int cls = t_pos_class(y, x);
+      // the levels are applied in fp16 exactly as the conv kernels do it
+#pragma unroll 1
+      for (int lev = 0; lev < 3; ++lev) {
+        const f16x8 k = *reinterpret_cast<const f16x8*>(kx + (lev * 6 + cls) * 128 + c0);
+        h = h + k;
+        h = __builtin_elementwise_max(h, h * (f16)0.2f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = tid; c < 128; c += 256) {
+    const int ccx = c >> 3, j = c & 7;
+    float tot = 0.f;
+    for (int s = 0; s < 16; ++s) tot += s_red[(s * 16 + ccx) * 8 + j];
+    pool_partial[((size_t)n * gridDim.x + blk) * 128 + c] = tot;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // heads: one workgroup (256 threads) per sample; everything fp32 in LDS
 //   gate: pooled_f[128] -> Linear(128,I) -> lrelu -> Linear(I,E) -> softmax
@@ -784,6 +865,8 @@ struct LoTeacher {
   LoGeom gU, gZ, g3c;
   size_t o_qin, o_U, o_Z, o_projc, o_rawBc, o_cvec[8][3], o_wu[8][3], o_ub[8][3], o_wz[8][3];
   int qrows;                  // query rows of the U GEMM: B * 543 rounded up to a multiple of 128
+  bool fuse_tail;             // block tail folded into the next conv1 (LO_T_FUSE_TAIL=0 turns it off)
+  size_t o_xc[2], o_kx[8];    // compact rows of x_l (ping-pong), transform constants [3][6][128] fp16 per expert
   size_t ws_bytes;
   bool att_zeroed;
   const void* att_zeroed_ws;
@@ -887,6 +970,12 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
   const size_t cpx = (size_t)B * 1024;
   h->o_qin = take((size_t)h->qrows * 128 * 2); h->o_U = take((size_t)h->qrows * 1024 * 2); h->o_Z = take(cpx * 1088 * 2);
   h->o_projc = take(cpx * 128 * 2); h->o_rawBc = take(cpx * 128 * 2);
+  {
+    const char* ft = getenv("LO_T_FUSE_TAIL");
+    h->fuse_tail = h->sparse && !(ft && atoi(ft) == 0) && lo_conv3_pp_applies(h->g3);
+  }
+  for (int k = 0; k < 2; ++k) h->o_xc[k] = take(cpx * 128 * 2);
+  for (int e = 0; e < num_experts; ++e) h->o_kx[e] = take(3 * 6 * 128 * 2);
   for (int e = 0; e < num_experts; ++e)
     for (int l = 0; l < 3; ++l) {
       h->o_cvec[e][l] = take(6 * 128 * 4);
@@ -1020,8 +1109,16 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     for (int l = 0; l < 3; ++l) {
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
       f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
-      LO_TAGGED("t_conv1 (igemm)", lo_conv_run(h->g3, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
-      LO_TRYT(t_bn_finalize(h, bnp, mt3, 128, p + ".conv1.2", P, ws, training, st));
+      if (h->fuse_tail) {
+        // conv1 reads the expert's input and applies the l previous block tails to its LDS patch (rows 0..7: xc)
+        LO_TAGGED(l ? "t_conv1 (fused tap, tail on load)" : "t_conv1 (fused tap)",
+                  lo_conv3_run_pp_xf(h->g3, TW(f16, h->o_feat), l ? TW(f16, h->o_xc[(l - 1) & 1]) : nullptr, TW(f16, h->o_kx[e]), l,
+                                     TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), TW(f16, h->o_rawA), st, &ex));
+        LO_TRYT(t_bn_finalize(h, bnp, B * 64, 128, p + ".conv1.2", P, ws, training, st));
+      } else {
+        LO_TAGGED("t_conv1 (igemm)", lo_conv_run(h->g3, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+        LO_TRYT(t_bn_finalize(h, bnp, mt3, 128, p + ".conv1.2", P, ws, training, st));
+      }
       if (h->sparse) {
         // folded attention: BN(conv1) is applied on the fly, k / v never exist (see lo_t_attn_folded_kernel)
         {
@@ -1041,6 +1138,22 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         LO_REQUIRE(tm == 64 || tm == 128, "teacher sparse path: unexpected conv tile height %d", tm);
         const float* cv = TW(float, h->o_cvec[e][l]);
         LO_TRYT(t_bn_finalize(h, bnp, B * 1024 / tm, 128, p + ".conv2.2", P, ws, training, st, 1024 / tm, 6 * 128 / tm, cv));
+        if (h->fuse_tail) {
+          f16* kx = TW(f16, h->o_kx[e]) + l * 6 * 128;
+          {
+            LoProfScope _p("lo_t_tail (rows 0..7 + constants)", 0, 0, st);
+            hipLaunchKernelGGL(lo_t_kconst_kernel, dim3(3), dim3(256), 0, st, cv, TW(float, h->o_ss), TP(p + ".layer_scale"), kx);
+            hipLaunchKernelGGL(lo_t_tail_compact_kernel, dim3(B * 64), dim3(256), 0, st, TW(f16, h->o_rawBc), TW(float, h->o_ss), TP(p + ".layer_scale"), cv,
+                               l ? TW(f16, h->o_xc[(l - 1) & 1]) : TW(f16, h->o_feat), l ? 1024 : T_HW, TW(f16, h->o_xc[l & 1]), B);
+          }
+          LO_LAUNCH_CHECK("t_tail_compact");
+          if (l == 2) {
+            LoProfScope _p("lo_t_pool (tail on load)", 0, 2.0 * px * 128, st);
+            hipLaunchKernelGGL(lo_t_pool_xf_kernel, dim3(64, B), dim3(256), 0, st, TW(f16, h->o_feat), TW(f16, h->o_xc[0]), TW(f16, h->o_kx[e]), TW(float, h->o_poolp));
+            LO_LAUNCH_CHECK("t_pool_xf");
+          }
+          continue;
+        }
         LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawBc), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 2, l == 2 ? TW(float, h->o_poolp) : nullptr, ws, st, cv));
         xin = xout;
         continue;
