@@ -543,78 +543,100 @@ __global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __rest
 // (cvec[class][c] * scale2[c] + shift2[c]) * layer_scale[c].  The full-resolution x_l is never written: the next block's
 // conv1 (lo_conv3x3_pp, transform on load) reads the expert's input `feat` and applies T_l .. T_1 to its LDS patch; only
 // image rows 0..7 exist as tensors (xc_l, [B][8][128][128]), and the global average pool of x_3 is one pass over feat.
-__global__ __launch_bounds__(256) void lo_t_kconst_kernel(const float* __restrict__ cvec, const float* __restrict__ ss,
-                                                          const float* __restrict__ ls, f16* __restrict__ kx) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 6 * 128) return;
-  const int c = i & 127;
-  kx[i] = (f16)((cvec[i] * ss[c * 2] + ss[c * 2 + 1]) * ls[c]);
-}
-
 __device__ __forceinline__ int t_pos_class(int y, int x) { return (y == 127 ? 3 : 0) + (x == 0 ? 1 : (x == 127 ? 2 : 0)); }
 
-// rows 0..7 of x_l:  thread = (sample, row, column, 8-channel chunk).  idt: x_{l-1} rows (feat for l = 0, pitch 16384
-// pixels per sample; else the previous compact buffer, pitch 1024)
+// rows 0..7 of x_l, and the level's transform constants kx[class][c] (written by workgroup 0).  Block = 16 positions x 16
+// chunks of 8 channels; the per-channel scale / shift / layer-scale live in registers.  idt: x_{l-1} rows (feat for l = 0,
+// pitch 16384 pixels per sample; else the previous compact buffer, pitch 1024)
 __global__ __launch_bounds__(256) void lo_t_tail_compact_kernel(const f16* __restrict__ rawc, const float* __restrict__ ss,
                                                                 const float* __restrict__ ls, const float* __restrict__ cvec,
-                                                                const f16* __restrict__ idt, int idt_pitch, f16* __restrict__ xc, int B) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int chunk = gid & 15, p = (gid >> 4) & 1023, b = gid >> 14;
-  if (b >= B) return;
-  const int y = p >> 7, x = p & 127, c0 = chunk * 8;
-  f16x8 id = *reinterpret_cast<const f16x8*>(idt + ((size_t)b * idt_pitch + p) * 128 + c0), o, r;
-  if (y < 6) r = *reinterpret_cast<const f16x8*>(rawc + ((size_t)b * 1024 + p) * 128 + c0);
-  const int cls = t_pos_class(y, x);
+                                                                const f16* __restrict__ idt, int idt_pitch, f16* __restrict__ xc,
+                                                                f16* __restrict__ kx, int B) {
+  const int tid = threadIdx.x, chunk = tid & 15, c0 = chunk * 8;
+  float sc[8], sh[8], lsv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float raw = y < 6 ? (float)r[j] : (float)(f16)cvec[cls * 128 + c0 + j];
-    float v = (raw * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1]) * ls[c0 + j] + (float)id[j];
-    o[j] = (f16)(v > 0.f ? v : 0.2f * v);
+  for (int j = 0; j < 8; ++j) { sc[j] = ss[(c0 + j) * 2]; sh[j] = ss[(c0 + j) * 2 + 1]; lsv[j] = ls[c0 + j]; }
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < 6 * 128; i += 256) {
+      const int c = i & 127;
+      kx[i] = (f16)((cvec[i] * ss[c * 2] + ss[c * 2 + 1]) * ls[c]);
+    }
   }
-  *reinterpret_cast<f16x8*>(xc + ((size_t)b * 1024 + p) * 128 + c0) = o;
+  // 16 positions per pass, 4 passes per block
+  for (int r = 0; r < 4; ++r) {
+    const int gp = (blockIdx.x * 4 + r) * 16 + (tid >> 4);
+    const int p = gp & 1023, b = gp >> 10;
+    if (b >= B) return;
+    const int y = p >> 7, x = p & 127;
+    f16x8 id = *reinterpret_cast<const f16x8*>(idt + ((size_t)b * idt_pitch + p) * 128 + c0), o, rw;
+    if (y < 6) rw = *reinterpret_cast<const f16x8*>(rawc + ((size_t)b * 1024 + p) * 128 + c0);
+    else {
+      const float* cv = cvec + t_pos_class(y, x) * 128 + c0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rw[j] = (f16)cv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = ((float)rw[j] * sc[j] + sh[j]) * lsv[j] + (float)id[j];
+      o[j] = (f16)(v > 0.f ? v : 0.2f * v);
+    }
+    *reinterpret_cast<f16x8*>(xc + ((size_t)b * 1024 + p) * 128 + c0) = o;
+  }
 }
 
-// pooled partial sums of x_3 = T_3(T_2(T_1(feat))) (rows >= 8) / xc (rows 0..7): pool_partial[n][blk][c], 64 blocks of
-// 256 positions per sample (same layout as lo_bn_apply's pool output)
+// pooled partial sums of x_3 = T_3(T_2(T_1(feat))) (rows >= 8) / xc (rows 0..7) for ALL experts in one pass over feat:
+// pool_partial[e][n][blk][c], 64 blocks of 256 positions per sample (the layout lo_pool_finalize_kernel reads).
+// kx: [E][3][6][128] fp16, xc: [E][B][1024][128] (compact x_3 rows of every expert).
+template <int E>
 __global__ __launch_bounds__(256) void lo_t_pool_xf_kernel(const f16* __restrict__ feat, const f16* __restrict__ xc,
-                                                           const f16* __restrict__ kx, float* __restrict__ pool_partial) {
+                                                           const f16* __restrict__ kx, float* __restrict__ pool_partial, int B) {
   __shared__ float s_red[256 * 8];
   const int tid = threadIdx.x, n = blockIdx.y, blk = blockIdx.x;
   const int cc = tid & 15, slot = tid >> 4, c0 = cc * 8;
-  float acc[8];
+  float acc[E][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
   for (int r = slot; r < 256; r += 16) {
     const int p = blk * 256 + r, y = p >> 7, x = p & 127;
-    float v[8];
     if (y < 8) {
-      f16x8 h = *reinterpret_cast<const f16x8*>(xc + ((size_t)n * 1024 + p) * 128 + c0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-    } else {
-      f16x8 h = *reinterpret_cast<const f16x8*>(feat + ((size_t)n * T_HW + p) * 128 + c0);
-      const int cls = t_pos_class(y, x);
-      // the levels are applied in fp16 exactly as the conv kernels do it
-#pragma unroll 1
-      for (int lev = 0; lev < 3; ++lev) {
-        const f16x8 k = *reinterpret_cast<const f16x8*>(kx + (lev * 6 + cls) * 128 + c0);
-        h = h + k;
-        h = __builtin_elementwise_max(h, h * (f16)0.2f);
+      for (int e = 0; e < E; ++e) {
+        f16x8 h = *reinterpret_cast<const f16x8*>(xc + (((size_t)e * B + n) * 1024 + p) * 128 + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[e][j] += (float)h[j];
       }
+    } else {
+      const f16x8 f = *reinterpret_cast<const f16x8*>(feat + ((size_t)n * T_HW + p) * 128 + c0);
+      const int cls = t_pos_class(y, x);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+      for (int e = 0; e < E; ++e) {
+        f16x8 h = f;
+        // the levels are applied in fp16 exactly as the conv kernels do it
+#pragma unroll
+        for (int lev = 0; lev < 3; ++lev) {
+          const f16x8 k = *reinterpret_cast<const f16x8*>(kx + ((e * 3 + lev) * 6 + cls) * 128 + c0);
+          h = h + k;
+          h = __builtin_elementwise_max(h, h * (f16)0.2f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[e][j] += (float)h[j];
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += v[j];
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[j];
-  __syncthreads();
-  for (int c = tid; c < 128; c += 256) {
-    const int ccx = c >> 3, j = c & 7;
-    float tot = 0.f;
-    for (int s = 0; s < 16; ++s) tot += s_red[(s * 16 + ccx) * 8 + j];
-    pool_partial[((size_t)n * gridDim.x + blk) * 128 + c] = tot;
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[e][j];
+    __syncthreads();
+    for (int c = tid; c < 128; c += 256) {
+      const int ccx = c >> 3, j = c & 7;
+      float tot = 0.f;
+      for (int s = 0; s < 16; ++s) tot += s_red[(s * 16 + ccx) * 8 + j];
+      pool_partial[(((size_t)e * B + n) * gridDim.x + blk) * 128 + c] = tot;
+    }
   }
 }
 
@@ -866,7 +888,8 @@ struct LoTeacher {
   size_t o_qin, o_U, o_Z, o_projc, o_rawBc, o_cvec[8][3], o_wu[8][3], o_ub[8][3], o_wz[8][3];
   int qrows;                  // query rows of the U GEMM: B * 543 rounded up to a multiple of 128
   bool fuse_tail;             // block tail folded into the next conv1 (LO_T_FUSE_TAIL=0 turns it off)
-  size_t o_xc[2], o_kx[8];    // compact rows of x_l (ping-pong), transform constants [3][6][128] fp16 per expert
+  size_t o_xc[2], o_kx[8];    // compact rows of x_l (ping-pong), transform constants [3][6][128] fp16 per expert (contiguous)
+  size_t o_xc3, o_poolpe;     // compact rows of x_3 of every expert [E][B][1024][128]; pool partials [E][B][64][128]
   size_t ws_bytes;
   bool att_zeroed;
   const void* att_zeroed_ws;
@@ -975,7 +998,12 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
     h->fuse_tail = h->sparse && !(ft && atoi(ft) == 0) && lo_conv3_pp_applies(h->g3);
   }
   for (int k = 0; k < 2; ++k) h->o_xc[k] = take(cpx * 128 * 2);
-  for (int e = 0; e < num_experts; ++e) h->o_kx[e] = take(3 * 6 * 128 * 2);
+  h->o_xc3 = take((size_t)num_experts * cpx * 128 * 2);
+  h->o_poolpe = take((size_t)num_experts * B * 64 * 128 * 4);
+  {
+    const size_t kx0 = take((size_t)num_experts * 3 * 6 * 128 * 2);
+    for (int e = 0; e < num_experts; ++e) h->o_kx[e] = kx0 + (size_t)e * 3 * 6 * 128 * 2;
+  }
   for (int e = 0; e < num_experts; ++e)
     for (int l = 0; l < 3; ++l) {
       h->o_cvec[e][l] = take(6 * 128 * 4);
@@ -1142,16 +1170,11 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           f16* kx = TW(f16, h->o_kx[e]) + l * 6 * 128;
           {
             LoProfScope _p("lo_t_tail (rows 0..7 + constants)", 0, 0, st);
-            hipLaunchKernelGGL(lo_t_kconst_kernel, dim3(3), dim3(256), 0, st, cv, TW(float, h->o_ss), TP(p + ".layer_scale"), kx);
-            hipLaunchKernelGGL(lo_t_tail_compact_kernel, dim3(B * 64), dim3(256), 0, st, TW(f16, h->o_rawBc), TW(float, h->o_ss), TP(p + ".layer_scale"), cv,
-                               l ? TW(f16, h->o_xc[(l - 1) & 1]) : TW(f16, h->o_feat), l ? 1024 : T_HW, TW(f16, h->o_xc[l & 1]), B);
+            hipLaunchKernelGGL(lo_t_tail_compact_kernel, dim3(B * 16), dim3(256), 0, st, TW(f16, h->o_rawBc), TW(float, h->o_ss), TP(p + ".layer_scale"), cv,
+                               l ? TW(f16, h->o_xc[(l - 1) & 1]) : TW(f16, h->o_feat), l ? 1024 : T_HW,
+                               l == 2 ? TW(f16, h->o_xc3) + (size_t)e * B * 1024 * 128 : TW(f16, h->o_xc[l & 1]), kx, B);
           }
           LO_LAUNCH_CHECK("t_tail_compact");
-          if (l == 2) {
-            LoProfScope _p("lo_t_pool (tail on load)", 0, 2.0 * px * 128, st);
-            hipLaunchKernelGGL(lo_t_pool_xf_kernel, dim3(64, B), dim3(256), 0, st, TW(f16, h->o_feat), TW(f16, h->o_xc[0]), TW(f16, h->o_kx[e]), TW(float, h->o_poolp));
-            LO_LAUNCH_CHECK("t_pool_xf");
-          }
           continue;
         }
         LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawBc), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 2, l == 2 ? TW(float, h->o_poolp) : nullptr, ws, st, cv));
@@ -1172,7 +1195,24 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
       LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 1, l == 2 ? TW(float, h->o_poolp) : nullptr, ws, st));
       xin = xout;
     }
-    LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
+    if (!h->fuse_tail) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
+  }
+  if (h->fuse_tail) {
+    // x_3 of every expert is pooled in ONE pass over feat (the full-resolution x_l were never written)
+    {
+      LoProfScope _p("lo_t_pool (tail on load)", 0, 2.0 * px * 128, st);
+#define LO_POOL(EE) hipLaunchKernelGGL((lo_t_pool_xf_kernel<EE>), dim3(64, B), dim3(256), 0, st, TW(f16, h->o_feat), TW(f16, h->o_xc3), \
+                                       TW(f16, h->o_kx[0]), TW(float, h->o_poolpe), B)
+      switch (h->E) {
+        case 1: LO_POOL(1); break; case 2: LO_POOL(2); break; case 3: LO_POOL(3); break; case 4: LO_POOL(4); break;
+        case 5: LO_POOL(5); break; case 6: LO_POOL(6); break; case 7: LO_POOL(7); break; default: LO_POOL(8); break;
+      }
+#undef LO_POOL
+    }
+    LO_LAUNCH_CHECK("t_pool_xf");
+    const int total = h->E * B * 128;
+    hipLaunchKernelGGL(lo_pool_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, TW(float, h->o_poolpe), TW(float, h->o_pool_e), 64, 128, total);
+    LO_LAUNCH_CHECK("pool_finalize");
   }
   // ---- heads (lunar_evaluator.py:417, 425, 431-449)
   HeadsArgs a;
