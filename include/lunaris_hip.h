@@ -168,6 +168,9 @@ int lo_vae_backward_phase(LoVae* h, int phase, const float* x, const float* flat
                           const float* target, int fused, const float* drecon, const float* gmu, const float* glv,
                           float loss_scale, float* flat_grads, void* stream);
 int lo_vae_linear_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_elem);
+/* [begin, end) of the flat gradient buffer that is complete after lo_vae_backward_phase(.., phase = 1): fc_mu.weight up to
+ * the end of the buffer (Linear layers, decoder convs, final conv).  The rest (encoder convs) is complete after phase 2. */
+int lo_vae_phase1_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_elem);
 
 #ifdef __cplusplus
 }

@@ -579,6 +579,35 @@ extern "C" int lo_vae_linear_grad_range(const LoVae* h, size_t* begin, size_t* e
   return LO_OK;
 }
 
+// everything from fc_mu.weight to the end of the flat buffer (the three Linear layers, the decoder convs and the final
+// conv: 90 % of the bytes) is final after phase 1
+extern "C" int lo_vae_phase1_grad_range(const LoVae* h, size_t* begin, size_t* end) {
+  LO_REQUIRE(h && begin && end, "lo_vae_phase1_grad_range: null argument");
+  *begin = h->p_off[h->idx_fc_mu_w];
+  *end = h->flat_elems;
+  return LO_OK;
+}
+
+// GroupNorm affine + conv bias gradients of a set of layers in one launch
+static int vae_gn_finalize(LoVae* h, bool enc, bool dec, float* G, void* ws, float inv, hipStream_t st) {
+  const int B = h->B;
+  LoGnFinJobs jobs;
+  jobs.n = 0;
+  int blocks = 0;
+  auto add = [&](ConvLayer& c) {
+    LoGnFinJob& j = jobs.j[jobs.n++];
+    j.P1 = WSP(float, c.o_P1); j.P2 = WSP(float, c.o_P2);
+    j.dgamma = GRD(c.p_gw); j.dbeta = GRD(c.p_gb); j.dbias = GRD(c.p_b);
+    j.nblk2 = B * lo_gn_nchunk(c.Ho * c.Wo, c.Cout);
+    j.nblk1 = c.np1 > 0 ? B * c.np1 : j.nblk2;
+    j.C = c.Cout; j.block0 = blocks;
+    blocks += (c.Cout + 3) / 4;
+  };
+  if (enc) for (int s = 0; s < 4; ++s) for (int k = 0; k < 3; ++k) add(h->enc[s][k]);
+  if (dec) for (int s = 0; s < 4; ++s) add(h->dec[s]);
+  return lo_gn_finalize_all(jobs, inv, st);
+}
+
 static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon, const float* target,
                              int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                              float* G, void* stream) {
@@ -637,7 +666,16 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
   }                   // ---------------- end of part A
-  if (phase == 1) return LO_OK;
+  if (phase == 1) {
+    // two-call form: every gradient from fc_mu.weight to the end of the buffer is complete now -> join the side
+    // stream (decoder weight gradients) and finish the decoder's GroupNorm / bias gradients, so that the caller can
+    // start exchanging that range while the encoder backward runs
+    if (h->overlap && !g_lo_prof_on) {
+      LO_HIP(hipEventRecord(h->ev_join, h->side));
+      LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+    return vae_gn_finalize(h, false, true, G, ws, inv, st);
+  }
   // ---- encoder stages 4..1
   for (int s = 3; s >= 0; --s) {
     ConvLayer& c0 = h->enc[s][0];
@@ -662,23 +700,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     LO_HIP(hipEventRecord(h->ev_join, h->side));
     LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   }
-  // ---- GroupNorm affine + conv bias gradients of all 16 layers in one launch
-  {
-    LoGnFinJobs jobs;
-    jobs.n = 0;
-    int blocks = 0;
-    auto add = [&](ConvLayer& c) {
-      LoGnFinJob& j = jobs.j[jobs.n++];
-      j.P1 = WSP(float, c.o_P1); j.P2 = WSP(float, c.o_P2);
-      j.dgamma = GRD(c.p_gw); j.dbeta = GRD(c.p_gb); j.dbias = GRD(c.p_b);
-      j.nblk2 = B * lo_gn_nchunk(c.Ho * c.Wo, c.Cout);
-      j.nblk1 = c.np1 > 0 ? B * c.np1 : j.nblk2;
-      j.C = c.Cout; j.block0 = blocks;
-      blocks += (c.Cout + 3) / 4;
-    };
-    for (int s = 0; s < 4; ++s) for (int k = 0; k < 3; ++k) add(h->enc[s][k]);
-    for (int s = 0; s < 4; ++s) add(h->dec[s]);
-    LO_TRY(lo_gn_finalize_all(jobs, inv, st));
-  }
+  // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or the encoder's after phase 2
+  LO_TRY(vae_gn_finalize(h, true, phase != 2, G, ws, inv, st));
   return LO_OK;
 }

@@ -75,16 +75,16 @@ class VAEStepper:
             bargs = (images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(), images.data_ptr(), 1, None, None, None,
                      float(vae.loss_scale), self.grads.data_ptr(), st)
             if self.grad_sync is not None and hasattr(self.grad_sync, "begin"):
-                # data parallel: the Linear-layer gradients (82 % of the bytes) are final after phase 1 and are exchanged
-                # while the encoder backward (phase 2) runs; the conv gradients follow after phase 2
+                # data parallel: everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final
+                # convs: 90 % of the bytes) is final after phase 1 and is exchanged while the encoder backward (phase 2)
+                # runs; the encoder conv gradients follow after phase 2
                 import ctypes as C
                 b, e = C.c_size_t(), C.c_size_t()
-                _lib.check(_lib.lib.lo_vae_linear_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_linear_grad_range")
+                _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
                 _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 1, *bargs), "lo_vae_backward_phase(1)")
                 self.grad_sync.begin(self.grads[b.value:e.value])
                 _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 2, *bargs), "lo_vae_backward_phase(2)")
                 self.grad_sync.begin(self.grads[:b.value])
-                self.grad_sync.begin(self.grads[e.value:])
                 self.grad_sync.finish()
             else:
                 _lib.check(_lib.lib.lo_vae_backward(eng.handle, *bargs), "lo_vae_backward")

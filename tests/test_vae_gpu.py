@@ -171,9 +171,11 @@ def test_two_phase_backward_equals_single_call():
     class Recorder:
         def __init__(self):
             self.slices = []
+            self.snaps = []
 
         def begin(self, g):
             self.slices.append((g.data_ptr(), g.numel()))
+            self.snaps.append((g, g.clone()))          # what an exchange started now would read
 
         def finish(self):
             pass
@@ -189,9 +191,11 @@ def test_two_phase_backward_equals_single_call():
     st2.step(x, 0, eps)
     torch.cuda.synchronize()
     assert torch.equal(st2.grads, ref)
-    assert sum(n for _, n in rec.slices) == st2.grads.numel() and len(rec.slices) == 3
+    assert sum(n for _, n in rec.slices) == st2.grads.numel() and len(rec.slices) == 2
     big = max(n for _, n in rec.slices)
-    assert big >= 0.65 * st2.grads.numel()         # the Linear-layer range: 70 % of the bytes at latent 256, 82 % at 512
+    assert big >= 0.75 * st2.grads.numel()         # Linear layers + decoder convs: 78 % of the bytes at latent 256, 90 % at 512
+    for view, snap in rec.snaps:                   # a range is handed over only once it is final (nothing writes it later)
+        assert torch.equal(view, snap)
 
 
 def test_rccl_single_rank_group_path():
