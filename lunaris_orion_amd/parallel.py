@@ -8,9 +8,10 @@ All 72 gradients live in ONE flat fp32 buffer (lunaris_orion_amd.vae), so the ex
 contiguous buffer — no bucketing logic, no per-tensor launches.  `FlatGradSync`:
   * backend "nccl" (= RCCL on ROCm): asynchronous `all_reduce(AVG)` (RCCL's own stream, ordered after the producing
     kernels), joined before clip+AdamW.  VAEStepper splits the backward in two native calls so that the exchange of
-    the three Linear weight gradients (82 % of the bytes, contiguous in the flat buffer, final after phase 1)
-    overlaps the encoder backward; the conv gradients (42 MB) follow.  Optional fp16 wire format (halves the xGMI
-    bytes; the sum is then taken in fp16, so it is off by default to keep DP == single-process to fp32 rounding);
+    everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final convs: 90 % of the
+    bytes, final after phase 1) overlaps the encoder backward; the encoder conv gradients (25 MB) follow.  Optional
+    fp16 wire format (halves the xGMI bytes; g * 1024 on the wire so that small gradients stay in the normal fp16
+    range; the sum is then taken in fp16, so it is off by default to keep DP == single-process to fp32 rounding);
   * backend "gloo" (CPU tests): SUM then divide (gloo has no AVG).
 The module is pure host logic on top of torch.distributed and is exercised by world-size-2 gloo tests on CPU.
 """
@@ -31,13 +32,17 @@ class FlatGradSync:
     VAEStepper to overlap the exchange of the Linear-layer gradients with the encoder backward.
     """
 
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None, compress_fp16: bool = False, force: bool = False):
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, compress_fp16: bool = False, force: bool = False,
+                 wire_scale: float = 1024.0):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.compress = compress_fp16
+        # fp16 wire: typical gradient elements (1e-5 .. 1e-3) sit at the bottom of the fp16 range; the wire carries
+        # g * wire_scale (overflow needs an element > 64) and the result is divided again
+        self.wire_scale = float(wire_scale)
         self.force = force              # tests: issue the collectives even in a one-rank group
         self._pending = []          # (work, wire_or_None, destination)
         self._wire = {}
@@ -55,7 +60,7 @@ class FlatGradSync:
             wire = self._wire.get(key)
             if wire is None:
                 wire = self._wire[key] = torch.empty(g.numel(), dtype=torch.float16, device=g.device)
-            wire.copy_(g)
+            torch.mul(g, self.wire_scale, out=wire)
         work = dist.all_reduce(wire if wire is not None else g, op=self._op(), group=self.group, async_op=True)
         self._pending.append((work, wire, g))
 
@@ -64,6 +69,7 @@ class FlatGradSync:
             work.wait()                      # NCCL: the current stream waits; gloo: the host waits
             if wire is not None:
                 g.copy_(wire)
+                g.div_(self.wire_scale)
             if self.backend != "nccl":
                 g.div_(self.world)
         self._pending.clear()
