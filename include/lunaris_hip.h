@@ -93,6 +93,14 @@ int lo_decode_sprites_u8(const void* u8_hwc, float* out_chw, int B, void* stream
 int lo_selfattn2d_forward(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                           const float* bv, const float* gamma, float* q, float* k, float* v, float* out, int B, int C,
                           int N, void* stream);
+/* Backward of the same module (autograd of lunar_generate.py:68-78): q, k, v are the forward's outputs; scratch:
+ * lo_selfattn2d_backward_scratch_elems(B, C, N) floats.  Writes dx [B,C,N] and the gradients of the three 1x1 convs and of
+ * gamma (not accumulated: overwritten).  No N x N tensor is materialised; all sums are in a fixed order. */
+size_t lo_selfattn2d_backward_scratch_elems(int B, int C, int N);
+int lo_selfattn2d_backward(const float* x, const float* wq, const float* wk, const float* wv, const float* gamma,
+                           const float* q, const float* k, const float* v, const float* dy, float* scratch, float* dx,
+                           float* dwq, float* dbq, float* dwk, float* dbk, float* dwv, float* dbv, float* dgamma, int B,
+                           int C, int N, void* stream);
 
 /* clip_grad_norm_ + AdamW over one flat fp32 buffer (train_hybrid.py:913,921; :504-509).  scratch: 1024+4 floats;
  * scratch[1024..1026] = (grad norm, clip coef, finite flag) afterwards. */

@@ -47,6 +47,8 @@ SIGNATURES = {
     "lo_final_conv_backward": (i32, [vp, f32p, f32p, f32p, f32p, f32p, flt, vp, f32p, f32p, f32p, i32, flt, vp]),
     "lo_decode_sprites_u8": (i32, [vp, f32p, i32, vp]),
     "lo_selfattn2d_forward": (i32, [f32p] * 12 + [i32, i32, i32, vp]),
+    "lo_selfattn2d_backward_scratch_elems": (C.c_size_t, [i32, i32, i32]),
+    "lo_selfattn2d_backward": (i32, [f32p] * 18 + [i32, i32, i32, vp]),
     "lo_clip_adamw_step": (i32, [f32p, f32p, f32p, f32p, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),
     "lo_teacher_create": (i32, [i32, i32, i32, i32, C.POINTER(C.c_void_p)]),
     "lo_teacher_destroy": (None, [vp]),

@@ -105,6 +105,16 @@ extern "C" int lo_selfattn2d_forward(const float* x, const float* wq, const floa
   return lo_selfattn2d_fwd(x, wq, bq, wk, bk, wv, bv, gamma, q, k, v, out, B, C, N, S(stream));
 }
 
+extern "C" size_t lo_selfattn2d_backward_scratch_elems(int B, int C, int N) { return lo_selfattn2d_bwd_scratch(B, C, N); }
+extern "C" int lo_selfattn2d_backward(const float* x, const float* wq, const float* wk, const float* wv, const float* gamma,
+                                      const float* q, const float* k, const float* v, const float* dy, float* scratch, float* dx,
+                                      float* dwq, float* dbq, float* dwk, float* dbk, float* dwv, float* dbv, float* dgamma, int B,
+                                      int C, int N, void* stream) {
+  LO_REQUIRE(x && wq && wk && wv && gamma && q && k && v && dy && scratch && dx && dwq && dbq && dwk && dbk && dwv && dbv && dgamma,
+             "lo_selfattn2d_backward: null argument");
+  return lo_selfattn2d_bwd(x, wq, wk, wv, gamma, q, k, v, dy, scratch, dx, dwq, dbq, dwk, dbk, dwv, dbv, dgamma, B, C, N, S(stream));
+}
+
 // =============================================================================================
 // VAE executor
 // =============================================================================================

@@ -103,8 +103,298 @@ int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const fl
   hipLaunchKernelGGL(lo_attn_project_kernel, gv, blk, 0, st, x, wv, bv, v, C, C, N);
   LO_LAUNCH_CHECK("attn_project");
   size_t lds = (size_t)(2 * D * 64 + 64 * 65 + 64 * 65 + 256) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { LO_HIP(hipFuncSetAttribute((const void*)lo_attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096)); attr = true; }
   LoProfScope _p("lo_attn_fused", 2.0 * B * N * (double)N * (2.0 * D + C), 4.0 * B * N * (2.0 * D + 3.0 * C), st);
   hipLaunchKernelGGL(lo_attn_fused_kernel, dim3(N / 64, C / 64, B), dim3(256), lds, st, q, k, v, x, gamma, out, C, D, N);
   LO_LAUNCH_CHECK("attn_fused");
+  return LO_OK;
+}
+
+// =============================================================================================
+// backward (fp32; off the VAE's hot path, built so that the module is trainable)
+//   y = gamma * O + x,  O[c][i] = sum_j V[c][j] att[i][j],  att = softmax_j(S),  S[i][j] = sum_d Q[d][i] K[d][j]
+//   dO = gamma dy;  t_i = sum_c dy[c][i] O[c][i]  (dgamma = sum t_i, delta_i = gamma t_i)
+//   dP[i][j] = sum_c dO[c][i] V[c][j];  dS = att (dP - delta_i)
+//   dQ[d][i] = sum_j dS[i][j] K[d][j];  dK[d][j] = sum_i dS[i][j] Q[d][i];  dV[c][j] = sum_i dO[c][i] att[i][j]
+// dP is a sum over channels, and dS is linear in it: every 64-channel group contributes partial dQ / dK (group 0 also
+// carries the -delta term), summed afterwards in a fixed order.  Nothing of size N x N is written to memory.
+//   lo_attn_bwd_stats : row max / 1/sum of the softmax and t_part[b][cg][i]      grid (N/64, C/64, B)
+//   lo_attn_bwd_dq    : dQ_part[b][cg][d][i]                                      grid (N/64 query blocks, C/64, B)
+//   lo_attn_bwd_dkv   : dK_part[b][cg][d][j], dV[b][c][j]                         grid (N/64 key blocks,   C/64, B)
+//   lo_attn_bwd_proj_* : 1x1-conv weight / bias gradients and dx
+// =============================================================================================
+__global__ __launch_bounds__(256) void lo_attn_bwd_stats_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ dy,
+                                                                float* __restrict__ ml, float* __restrict__ t_part,
+                                                                int C, int D, int N) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_q = sm;
+  float* s_k = s_q + D * AT_Q;
+  float* s_p = s_k + D * AT_K;
+  float* s_v = s_p + AT_Q * 65;
+  float* s_red = s_v + AT_C * 65;
+  const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
+  const int q0 = blockIdx.x * AT_Q, c0 = blockIdx.y * AT_C, bi = blockIdx.z;
+  const float* qb = q + (size_t)bi * D * N;
+  const float* kb = k + (size_t)bi * D * N;
+  const float* vb = v + (size_t)bi * C * N;
+  for (int e = tid; e < D * AT_Q; e += 256) s_q[e] = qb[(size_t)(e / AT_Q) * N + q0 + (e % AT_Q)];
+  float m = -INFINITY, l = 0.f;
+  for (int j0 = 0; j0 < N; j0 += AT_K) {
+    __syncthreads();
+    for (int e = tid; e < D * AT_K; e += 256) s_k[e] = kb[(size_t)(e / AT_K) * N + j0 + (e % AT_K)];
+    __syncthreads();
+    for (int jj = part * 16; jj < part * 16 + 16; ++jj) {
+      float s = 0.f;
+      for (int c = 0; c < D; ++c) s += s_q[c * AT_Q + i] * s_k[c * AT_K + jj];
+      float mn = fmaxf(m, s);
+      l = l * __expf(m - mn) + __expf(s - mn);
+      m = mn;
+    }
+  }
+  s_red[part * 64 + i] = m;
+  __syncthreads();
+  const float mt = fmaxf(fmaxf(s_red[i], s_red[64 + i]), fmaxf(s_red[128 + i], s_red[192 + i]));
+  __syncthreads();
+  s_red[part * 64 + i] = l * __expf(m - mt);
+  __syncthreads();
+  const float inv_l = 1.f / (s_red[i] + s_red[64 + i] + s_red[128 + i] + s_red[192 + i]);
+  if (blockIdx.y == 0 && part == 0) {
+    ml[((size_t)bi * N + q0 + i) * 2] = mt;
+    ml[((size_t)bi * N + q0 + i) * 2 + 1] = inv_l;
+  }
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (int j0 = 0; j0 < N; j0 += AT_K) {
+    __syncthreads();
+    for (int e = tid; e < D * AT_K; e += 256) s_k[e] = kb[(size_t)(e / AT_K) * N + j0 + (e % AT_K)];
+    for (int e = tid; e < AT_C * AT_K; e += 256) s_v[(e / AT_K) * 65 + (e % AT_K)] = vb[(size_t)(c0 + e / AT_K) * N + j0 + (e % AT_K)];
+    __syncthreads();
+    for (int jj = part * 16; jj < part * 16 + 16; ++jj) {
+      float s = 0.f;
+      for (int c = 0; c < D; ++c) s += s_q[c * AT_Q + i] * s_k[c * AT_K + jj];
+      s_p[i * 65 + jj] = __expf(s - mt) * inv_l;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < AT_K; ++jj) {
+      float p = s_p[i * 65 + jj];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] += s_v[(part * 16 + c) * 65 + jj] * p;
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t += acc[c] * dy[((size_t)bi * C + c0 + part * 16 + c) * N + q0 + i];
+  __syncthreads();
+  s_red[part * 64 + i] = t;
+  __syncthreads();
+  if (part == 0) t_part[((size_t)bi * gridDim.y + blockIdx.y) * N + q0 + i] = s_red[i] + s_red[64 + i] + s_red[128 + i] + s_red[192 + i];
+}
+
+// MODE 0: workgroup = 64 queries (i), loops key blocks, writes dQ_part.  MODE 1: workgroup = 64 keys (j), loops query
+// blocks, writes dK_part and dV.  thread = (row r = tid & 63 of the block the workgroup owns, part = tid >> 6)
+template <int MODE>
+__global__ __launch_bounds__(256) void lo_attn_bwd_main_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ dy,
+                                                               const float* __restrict__ gamma, const float* __restrict__ ml,
+                                                               const float* __restrict__ t_part, float* __restrict__ dqk_part,
+                                                               float* __restrict__ dv, int C, int D, int N) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_own = sm;                       // [D][64]  q (MODE 0) or k (MODE 1) of the owned block
+  float* s_oth = s_own + D * 64;           // [D][64]  the other operand of the current pair
+  float* s_ds = s_oth + D * 64;            // [64 own][65]  dS of the current pair
+  float* s_att = s_ds + 64 * 65;           // [64 own][65]  att of the current pair (MODE 1: for dV)
+  float* s_a = s_att + 64 * 65;            // [64 c][65]    dO chunk: columns = queries of the pair
+  float* s_b = s_a + 64 * 65;              // [64 c][65]    V chunk: columns = keys of the pair
+  float* s_st = s_b + 64 * 65;             // [3][64]       m, 1/l, delta of the queries of the pair
+  const int tid = threadIdx.x, r = tid & 63, part = tid >> 6;
+  const int o0 = blockIdx.x * 64, c0 = blockIdx.y * 64, bi = blockIdx.z, ncg = gridDim.y;
+  const float gm = gamma[0];
+  const float* qb = q + (size_t)bi * D * N;
+  const float* kb = k + (size_t)bi * D * N;
+  const float* vb = v + (size_t)bi * C * N;
+  const float* dyb = dy + (size_t)bi * C * N;
+  const float* own = MODE == 0 ? qb : kb;
+  const float* oth = MODE == 0 ? kb : qb;
+  for (int e = tid; e < D * 64; e += 256) s_own[e] = own[(size_t)(e / 64) * N + o0 + (e % 64)];
+  float accq[16], accv[16];                // dQ / dK rows d = part*16 + dd (D <= 64); dV channels part*16 + c
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { accq[c] = 0.f; accv[c] = 0.f; }
+  for (int p0 = 0; p0 < N; p0 += 64) {
+    const int i0 = MODE == 0 ? o0 : p0, j0 = MODE == 0 ? p0 : o0;   // queries i0.., keys j0.. of this pair
+    __syncthreads();
+    for (int e = tid; e < D * 64; e += 256) s_oth[e] = oth[(size_t)(e / 64) * N + p0 + (e % 64)];
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int c = e / 64, x = e % 64;
+      s_a[c * 65 + x] = gm * dyb[(size_t)(c0 + c) * N + i0 + x];
+      s_b[c * 65 + x] = vb[(size_t)(c0 + c) * N + j0 + x];
+    }
+    if (tid < 64) {
+      s_st[tid] = ml[((size_t)bi * N + i0 + tid) * 2];
+      s_st[64 + tid] = ml[((size_t)bi * N + i0 + tid) * 2 + 1];
+      float t = 0.f;
+      for (int g = 0; g < ncg; ++g) t += t_part[((size_t)bi * ncg + g) * N + i0 + tid];
+      s_st[128 + tid] = gm * t;
+    }
+    __syncthreads();
+    // att and dS for (own row r, 16 columns xx of the other block)
+    const float* qv = MODE == 0 ? s_own : s_oth;
+    const float* kv = MODE == 0 ? s_oth : s_own;
+    for (int xx = part * 16; xx < part * 16 + 16; ++xx) {
+      const int qi = MODE == 0 ? r : xx, kj = MODE == 0 ? xx : r;
+      float s = 0.f;
+      for (int d = 0; d < D; ++d) s += qv[d * 64 + qi] * kv[d * 64 + kj];
+      const float att = __expf(s - s_st[qi]) * s_st[64 + qi];
+      float dp = 0.f;
+      for (int c = 0; c < 64; ++c) dp += s_a[c * 65 + qi] * s_b[c * 65 + kj];
+      s_ds[r * 65 + xx] = att * (dp - (blockIdx.y == 0 ? s_st[128 + qi] : 0.f));
+      if (MODE == 1) s_att[r * 65 + xx] = att;
+    }
+    __syncthreads();
+    // dQ[d][i=r] += sum_x dS[r][x] K[d][x]  (MODE 0)     dK[d][j=r] += sum_x dS[r][x] Q[d][x]  (MODE 1)
+    for (int xx = 0; xx < 64; ++xx) {
+      const float ds = s_ds[r * 65 + xx];
+#pragma unroll
+      for (int dd = 0; dd < 16; ++dd) {
+        const int d = part * 16 + dd;
+        if (d < D) accq[dd] += ds * s_oth[d * 64 + xx];
+      }
+      if (MODE == 1) {
+        // dV[c][j=r] += dO[c][i=xx] att[i=xx][j=r]
+        const float at = s_att[r * 65 + xx];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) accv[c] += s_a[(part * 16 + c) * 65 + xx] * at;
+      }
+    }
+  }
+#pragma unroll
+  for (int dd = 0; dd < 16; ++dd) {
+    const int d = part * 16 + dd;
+    if (d < D) dqk_part[(((size_t)bi * ncg + blockIdx.y) * D + d) * N + o0 + r] = accq[dd];
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dv[((size_t)bi * C + c0 + part * 16 + c) * N + o0 + r] = accv[c];
+  }
+}
+
+// g[b][d][n] = sum_cg part[b][cg][d][n]  (fixed order)
+__global__ void lo_attn_sum_parts_kernel(const float* __restrict__ part, float* __restrict__ g, int ncg, int DN, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = i / DN, r = i - b * DN;
+  float t = 0.f;
+  for (int c = 0; c < ncg; ++c) t += part[((size_t)b * ncg + c) * DN + r];
+  g[i] = t;
+}
+
+// 1x1-conv parameter gradients: dw[co][ci] = sum_{b,n} g[b][co][n] x[b][ci][n], db[co] = sum_{b,n} g[b][co][n]
+// block = 16 (co) x 16 (ci) threads, tiles of 64 positions through LDS
+__global__ __launch_bounds__(256) void lo_attn_proj_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int Co,
+                                                                 int C, int N) {
+  __shared__ float s_g[16][65], s_x[16][65];
+  const int tid = threadIdx.x, tci = tid & 15, tco = tid >> 4;
+  const int co0 = blockIdx.x * 16, ci0 = blockIdx.y * 16;
+  float acc = 0.f, accb = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      __syncthreads();
+      for (int e = tid; e < 16 * 64; e += 256) {
+        const int rr = e / 64, nn = e % 64;
+        s_g[rr][nn] = co0 + rr < Co ? g[((size_t)b * Co + co0 + rr) * N + n0 + nn] : 0.f;
+        s_x[rr][nn] = x[((size_t)b * C + ci0 + rr) * N + n0 + nn];
+      }
+      __syncthreads();
+      for (int nn = 0; nn < 64; ++nn) {
+        acc += s_g[tco][nn] * s_x[tci][nn];
+        if (tci == 0) accb += s_g[tco][nn];
+      }
+    }
+  if (co0 + tco < Co) {
+    dw[(size_t)(co0 + tco) * C + ci0 + tci] = acc;
+    if (tci == 0 && blockIdx.y == 0) db[co0 + tco] = accb;
+  }
+}
+
+// dx[b][c][n] = dy + sum_d wq[d][c] dq[b][d][n] + sum_d wk[d][c] dk[b][d][n] + sum_c' wv[c'][c] dv[b][c'][n]
+__global__ void lo_attn_proj_dx_kernel(const float* __restrict__ dy, const float* __restrict__ wq, const float* __restrict__ wk,
+                                       const float* __restrict__ wv, const float* __restrict__ dq, const float* __restrict__ dk,
+                                       const float* __restrict__ dvv, float* __restrict__ dx, int C, int D, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (n >= N) return;
+  float acc = dy[((size_t)b * C + c) * N + n];
+  for (int d = 0; d < D; ++d) {
+    acc += wq[(size_t)d * C + c] * dq[((size_t)b * D + d) * N + n];
+    acc += wk[(size_t)d * C + c] * dk[((size_t)b * D + d) * N + n];
+  }
+  for (int cp = 0; cp < C; ++cp) acc += wv[(size_t)cp * C + c] * dvv[((size_t)b * C + cp) * N + n];
+  dx[((size_t)b * C + c) * N + n] = acc;
+}
+
+// dgamma = sum of t_part (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void lo_attn_dgamma_kernel(const float* __restrict__ t_part, float* __restrict__ dgamma, int total) {
+  __shared__ double red[256];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < total; i += 256) t += (double)t_part[i];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 256; ++i) s += red[i];
+    dgamma[0] = (float)s;
+  }
+}
+
+// scratch (floats): ml 2BN | t_part B*ncg*N | dq_part B*ncg*D*N | dk_part B*ncg*D*N | dq B*D*N | dk B*D*N | dv B*C*N
+size_t lo_selfattn2d_bwd_scratch(int B, int C, int N) {
+  const size_t ncg = C / 64, D = C / 8;
+  return (size_t)2 * B * N + (size_t)B * ncg * N + 2 * (size_t)B * ncg * D * N + 2 * (size_t)B * D * N + (size_t)B * C * N;
+}
+
+int lo_selfattn2d_bwd(const float* x, const float* wq, const float* wk, const float* wv, const float* gamma, const float* q,
+                      const float* k, const float* v, const float* dy, float* scratch, float* dx, float* dwq, float* dbq,
+                      float* dwk, float* dbk, float* dwv, float* dbv, float* dgamma, int B, int C, int N, hipStream_t st) {
+  LO_REQUIRE(C % 64 == 0 && N % 64 == 0, "lo_selfattn2d_bwd: C=%d and H*W=%d must be multiples of 64", C, N);
+  const int D = C / 8, ncg = C / 64;
+  LO_REQUIRE(D <= 64, "lo_selfattn2d_bwd: C/8 = %d > 64 is not supported", D);
+  float* ml = scratch;
+  float* t_part = ml + (size_t)2 * B * N;
+  float* dq_part = t_part + (size_t)B * ncg * N;
+  float* dk_part = dq_part + (size_t)B * ncg * D * N;
+  float* dq = dk_part + (size_t)B * ncg * D * N;
+  float* dk = dq + (size_t)B * D * N;
+  float* dvv = dk + (size_t)B * D * N;
+  const dim3 grid(N / 64, ncg, B);
+  {
+    size_t lds = (size_t)(2 * D * 64 + 64 * 65 + 64 * 65 + 256) * sizeof(float);
+    static bool attr1 = false;
+    if (!attr1) { LO_HIP(hipFuncSetAttribute((const void*)lo_attn_bwd_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096)); attr1 = true; }
+    hipLaunchKernelGGL(lo_attn_bwd_stats_kernel, grid, dim3(256), lds, st, q, k, v, dy, ml, t_part, C, D, N);
+    LO_LAUNCH_CHECK("attn_bwd_stats");
+  }
+  {
+    size_t lds = (size_t)(2 * D * 64 + 4 * 64 * 65 + 192) * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      LO_HIP(hipFuncSetAttribute((const void*)lo_attn_bwd_main_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+      LO_HIP(hipFuncSetAttribute((const void*)lo_attn_bwd_main_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((lo_attn_bwd_main_kernel<0>), grid, dim3(256), lds, st, q, k, v, dy, gamma, ml, t_part, dq_part, nullptr, C, D, N);
+    hipLaunchKernelGGL((lo_attn_bwd_main_kernel<1>), grid, dim3(256), lds, st, q, k, v, dy, gamma, ml, t_part, dk_part, dvv, C, D, N);
+    LO_LAUNCH_CHECK("attn_bwd_main");
+  }
+  const int tot = B * D * N;
+  hipLaunchKernelGGL(lo_attn_sum_parts_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, dq_part, dq, ncg, D * N, tot);
+  hipLaunchKernelGGL(lo_attn_sum_parts_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, dk_part, dk, ncg, D * N, tot);
+  hipLaunchKernelGGL(lo_attn_proj_wgrad_kernel, dim3((D + 15) / 16, C / 16), dim3(256), 0, st, dq, x, dwq, dbq, B, D, C, N);
+  hipLaunchKernelGGL(lo_attn_proj_wgrad_kernel, dim3((D + 15) / 16, C / 16), dim3(256), 0, st, dk, x, dwk, dbk, B, D, C, N);
+  hipLaunchKernelGGL(lo_attn_proj_wgrad_kernel, dim3(C / 16, C / 16), dim3(256), 0, st, dvv, x, dwv, dbv, B, C, C, N);
+  hipLaunchKernelGGL(lo_attn_proj_dx_kernel, dim3(N / 64, C, B), dim3(64), 0, st, dy, wq, wk, wv, dq, dk, dvv, dx, C, D, N);
+  hipLaunchKernelGGL(lo_attn_dgamma_kernel, dim3(1), dim3(256), 0, st, t_part, dgamma, B * ncg * N);
+  LO_LAUNCH_CHECK("attn_bwd_proj");
   return LO_OK;
 }

@@ -77,4 +77,8 @@ int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float
 int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                       const float* bv, const float* gamma, float* q, float* k, float* v, float* out, int B, int C, int N,
                       hipStream_t st);
+size_t lo_selfattn2d_bwd_scratch(int B, int C, int N);
+int lo_selfattn2d_bwd(const float* x, const float* wq, const float* wk, const float* wv, const float* gamma, const float* q,
+                      const float* k, const float* v, const float* dy, float* scratch, float* dx, float* dwq, float* dbq,
+                      float* dwk, float* dbk, float* dwv, float* dbv, float* dgamma, int B, int C, int N, hipStream_t st);
 int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st);

@@ -49,8 +49,7 @@ class ResBlock(nn.Module):
 class SelfAttention2d(nn.Module):
     """Spatial self-attention block of the reference (lunar_generate.py:56-78), which defines it but never instantiates
     it.  Same parameters (`query_conv`, `key_conv`, `value_conv`, `gamma`); forward is one fused HIP pass
-    (`lo_selfattn2d_forward`: no N x N tensor is materialised).  Forward only in this round: calling it with
-    autograd enabled on its parameters raises."""
+    (`lo_selfattn2d_forward` / `lo_selfattn2d_backward`: no N x N tensor is materialised in either direction)."""
 
     def __init__(self, in_channels: int):
         super().__init__()
@@ -61,22 +60,51 @@ class SelfAttention2d(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _lib.require_gpu()
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("SelfAttention2d backward is not built yet: call under torch.no_grad()")
         if not x.is_cuda:
             raise _lib.LunarisHipError("SelfAttention2d needs CUDA (ROCm) tensors; there is no CPU path")
+        return _SelfAttnFunction.apply(x, self.query_conv.weight, self.query_conv.bias, self.key_conv.weight, self.key_conv.bias,
+                                       self.value_conv.weight, self.value_conv.bias, self.gamma)
+
+
+class _SelfAttnFunction(torch.autograd.Function):
+    """Forward / backward of SelfAttention2d as two native calls (`lo_selfattn2d_forward` / `_backward`)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
         B, Cc, H, W = x.shape
         N = H * W
-        x = x.detach().contiguous().float()
+        xd = x.detach().contiguous().float()
+        P = [t.detach().contiguous().float() for t in (wq, bq, wk, bk, wv, bv, gamma)]
         q = torch.empty(B, Cc // 8, N, dtype=torch.float32, device=x.device)
         k = torch.empty_like(q)
         v = torch.empty(B, Cc, N, dtype=torch.float32, device=x.device)
-        out = torch.empty_like(x)
-        P = [t.detach().contiguous().float() for t in (self.query_conv.weight, self.query_conv.bias, self.key_conv.weight,
-                                                       self.key_conv.bias, self.value_conv.weight, self.value_conv.bias, self.gamma)]
-        _lib.check(_lib.lib.lo_selfattn2d_forward(x.data_ptr(), *[t.data_ptr() for t in P], q.data_ptr(), k.data_ptr(), v.data_ptr(),
+        out = torch.empty_like(xd)
+        _lib.check(_lib.lib.lo_selfattn2d_forward(xd.data_ptr(), *[t.data_ptr() for t in P], q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                                   out.data_ptr(), B, Cc, N, _lib.stream_ptr()), "lo_selfattn2d_forward")
+        ctx.save_for_backward(xd, P[0], P[2], P[4], P[6], q, k, v)
+        ctx.shapes = (wq.shape, bq.shape, wk.shape, bk.shape, wv.shape, bv.shape)
         return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, wq, wk, wv, gamma, q, k, v = ctx.saved_tensors
+        B, Cc, H, W = xd.shape
+        N = H * W
+        dy = dy.detach().contiguous().float()
+        dev = xd.device
+        scratch = torch.empty(_lib.lib.lo_selfattn2d_backward_scratch_elems(B, Cc, N), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(xd)
+        dwq, dwk, dwv = torch.empty_like(wq), torch.empty_like(wk), torch.empty_like(wv)
+        dbq = torch.empty(Cc // 8, dtype=torch.float32, device=dev)
+        dbk = torch.empty_like(dbq)
+        dbv = torch.empty(Cc, dtype=torch.float32, device=dev)
+        dg = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib.lo_selfattn2d_backward(xd.data_ptr(), wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), gamma.data_ptr(), q.data_ptr(),
+                                                   k.data_ptr(), v.data_ptr(), dy.data_ptr(), scratch.data_ptr(), dx.data_ptr(),
+                                                   dwq.data_ptr(), dbq.data_ptr(), dwk.data_ptr(), dbk.data_ptr(), dwv.data_ptr(),
+                                                   dbv.data_ptr(), dg.data_ptr(), B, Cc, N, _lib.stream_ptr()), "lo_selfattn2d_backward")
+        s = ctx.shapes
+        return dx, dwq.view(s[0]), dbq.view(s[1]), dwk.view(s[2]), dbk.view(s[3]), dwv.view(s[4]), dbv.view(s[5]), dg
 
 
 class Encoder(nn.Module):

@@ -293,8 +293,9 @@ def test_clip_adamw_matches_torch():
 
 
 @pytest.mark.parametrize("B,C,H", [(2, 64, 8), (2, 128, 16), (1, 512, 8)])
-def test_selfattention2d_forward(B, C, H):
-    """Fused attention vs the oracle restatement (and vs the golden fixture generated from the reference module)."""
+def test_selfattention2d_forward_backward(B, C, H):
+    """Fused attention vs the oracle restatement (and vs the golden fixture generated from the reference module); the
+    backward vs autograd of the oracle."""
     import os
 
     import numpy as np
@@ -317,5 +318,18 @@ def test_selfattention2d_forward(B, C, H):
     if (B, C, H) == (2, 64, 8):
         g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfattn2d.npz"))
         assert np.abs(got.numpy() - g["y"]).max() <= 2e-5 * max(1.0, np.abs(g["y"]).max())
-    with pytest.raises(NotImplementedError):
-        m(x.cuda().requires_grad_(True))
+    # backward: every gradient against autograd of the oracle restatement (fp32 both sides)
+    xr = x.clone().requires_grad_(True)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = R.self_attention_2d(xr, Pr["query_conv.weight"], Pr["query_conv.bias"], Pr["key_conv.weight"], Pr["key_conv.bias"],
+                             Pr["value_conv.weight"], Pr["value_conv.bias"], Pr["gamma"])
+    dy = R.closed_form_tensor("attn.dy", tuple(yr.shape))
+    yr.backward(dy)
+    xg = x.cuda().requires_grad_(True)
+    m.zero_grad()
+    m(xg).backward(dy.cuda())
+    got_g = {"x": xg.grad.cpu(), **{k: p.grad.cpu() for k, p in m.named_parameters()}}
+    ref_g = {"x": xr.grad, **{k: Pr[k].grad for k in Pr}}
+    for k in ref_g:
+        scale = max(1e-3, ref_g[k].abs().max().item())
+        assert (got_g[k] - ref_g[k]).abs().max().item() <= 2e-4 * scale + 1e-6, (k, (got_g[k] - ref_g[k]).abs().max().item(), scale)
