@@ -224,22 +224,37 @@ struct LcBwdArgs {
   float* partial;        // [nwg][867]
 };
 
+// MFMA form (the direct form was LDS-bound on broadcast weight reads: 216 ds_read_b128 per pixel):
+//   dpre (fp16, [18x18][4]) and the staged a4 tile live in LDS;
+//   data gradient   D[px][ci] = sum_k A[px][k] Wd[k][ci],  k = tap*3 + co (27 of 32): per tile row two
+//                   v_mfma_f32_16x16x32_f16 (ci 0..15, 16..31); A gathered from dpre with per-lane byte offsets
+//   weight gradient D[co][ci] += sum_px dpre[px][co] a4[px + tap][ci] per tap: K = 32 pixels (two tile rows), A = dpre^T
+//                   (3 of 16 rows used), B by transposed LDS reads of the a4 tile; 18 accumulators kept across the 8 tiles
 __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
+  constexpr int SP = 80;                                          // staging pitch of the output tile (bytes per pixel)
   __shared__ __attribute__((aligned(16))) unsigned char tile[LC_TP * LC_TP * LC_PITCH];  // reused as reduction buffer
-  __shared__ __attribute__((aligned(16))) float dp[LC_TP * LC_TP][4];
-  __shared__ __attribute__((aligned(16))) float w2[9][3][LC_CI];
-  __shared__ float bred[8][3];
-  const int tid = threadIdx.x, ty = blockIdx.x, n = blockIdx.y;   // one workgroup = one row of 8 tiles
+  __shared__ __attribute__((aligned(16))) f16 dp[LC_TP * LC_TP][8];   // dpre as fp16 hi [0..2] + lo [4..6] (hi + lo ~ 22 bits)
+  __shared__ __attribute__((aligned(16))) unsigned char so[256 * SP];
+  __shared__ float bred[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, ty = blockIdx.x, n = blockIdx.y;   // one workgroup = one row of 8 tiles
+  const int wave = tid >> 6, m = lane & 15, g = lane >> 4;
   const float cf = a.drecon ? a.gscale : *a.coef;
-  for (int i = tid; i < 9 * 3 * LC_CI; i += 256) {
-    int ci = i % LC_CI, co = (i / LC_CI) % 3, t = i / (3 * LC_CI);
-    w2[t][co][ci] = a.w[(co * LC_CI + ci) * 9 + t];
-  }
-  const int ci = tid & 31, q = tid >> 5;
-  float wacc[27];
+  // ---- data-gradient constants: k = 8g + jj -> (tap, co); A byte offset relative to pixel (py, m) of the tile; B = weights
+  int aoff[8];
+  f16x8 wd[2];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) wacc[k] = 0.f;
+  for (int jj = 0; jj < 8; ++jj) {
+    const int kidx = 8 * g + jj;
+    const int tap = kidx / 3, co = kidx - tap * 3, r = tap / 3, sx = tap - r * 3;
+    aoff[jj] = kidx < 27 ? (((2 - r) * LC_TP + (2 - sx)) * 8 + co) * 2 : -1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wd[t][jj] = kidx < 27 ? (f16)a.w[(co * LC_CI + t * 16 + m) * 9 + tap] : (f16)0.f;
+  }
+  f32x4 wacc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { wacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wacc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float bacc0 = 0.f, bacc1 = 0.f, bacc2 = 0.f;
+  const int tq = m >> 2, tsub = (m & 3) * 8;                      // transposed-read lane roles
   for (int tx = 0; tx < 8; ++tx) {
     __syncthreads();                     // previous tile fully consumed
     lc_stage_a4(a.a4, tile, n, ty, tx, tid);
@@ -257,83 +272,88 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
         d1 = cf * g1 * (1.f - r1 * r1);
         d2 = cf * g2 * (1.f - r2 * r2);
       }
-      dp[p][0] = d0; dp[p][1] = d1; dp[p][2] = d2; dp[p][3] = 0.f;
+      if (y >= 1 && y <= LC_T && xx >= 1 && xx <= LC_T) { bacc0 += d0; bacc1 += d1; bacc2 += d2; }   // bias: the tile's own pixels
+      const f16 h0 = (f16)d0, h1 = (f16)d1, h2 = (f16)d2;
+      dp[p][0] = h0; dp[p][1] = h1; dp[p][2] = h2; dp[p][3] = (f16)0.f;
+      dp[p][4] = (f16)(d0 - (float)h0); dp[p][5] = (f16)(d1 - (float)h1); dp[p][6] = (f16)(d2 - (float)h2); dp[p][7] = (f16)0.f;
     }
     __syncthreads();
-    // ---- data gradient: thread = pixel, 32 input channels
-    {
-      const int px = tid & 15, py = tid >> 4;
-      float acc[LC_CI];
+    const unsigned char* dpb = reinterpret_cast<const unsigned char*>(&dp[0][0]);
+    // ---- data gradient: wave w owns tile rows 4w .. 4w+3
 #pragma unroll
-      for (int j = 0; j < LC_CI; ++j) acc[j] = 0.f;
-#pragma unroll 1
-      for (int r = 0; r < 3; ++r)
+    for (int rr = 0; rr < 4; ++rr) {
+      const int py = wave * 4 + rr;
+      const int base = (py * LC_TP + m) * 16;
+      f16x8 af;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          // output pixel (py,px) of da4 receives dpre at (py + 1 - r, px + 1 - s); tile coords are +1
-          f32x4 d = *reinterpret_cast<const f32x4*>(&dp[(py + 2 - r) * LC_TP + (px + 2 - s)][0]);
+      for (int jj = 0; jj < 8; ++jj) af[jj] = aoff[jj] >= 0 ? *reinterpret_cast<const f16*>(dpb + base + aoff[jj]) : (f16)0.f;
 #pragma unroll
-          for (int co = 0; co < 3; ++co) {
-            float dv = d[co];
+      for (int t = 0; t < 2; ++t) {
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, wd[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // D: column = ci (lane & 15), rows = pixels 4g + reg of this tile row
 #pragma unroll
-            for (int j = 0; j < LC_CI; j += 4) {
-              f32x4 wv = *reinterpret_cast<const f32x4*>(&w2[r * 3 + s][co][j]);
-              acc[j] += dv * wv[0]; acc[j + 1] += dv * wv[1]; acc[j + 2] += dv * wv[2]; acc[j + 3] += dv * wv[3];
-            }
-          }
-        }
-      const int oy = ty * LC_T + py, ox = tx * LC_T + px;
-      f16* dst = a.da4 + (((size_t)n * 128 + oy) * 128 + ox) * LC_CI;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        f16x8 h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (f16)acc[ch * 8 + j];
-        *reinterpret_cast<f16x8*>(dst + ch * 8) = h;
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<f16*>(so + (py * 16 + 4 * g + e) * SP + (t * 16 + m) * 2) = (f16)d[e];
       }
     }
-    // ---- weight gradient: thread = (ci, pixel subset q of 32 pixels); 27 accumulators (tap, co) kept across tiles
-    for (int pp = q * 32; pp < q * 32 + 32; ++pp) {
-      int py = pp >> 4, px = pp & 15;
-      f32x4 d = *reinterpret_cast<const f32x4*>(&dp[(py + 1) * LC_TP + px + 1][0]);
-      if (ci == 0) { bacc0 += d[0]; bacc1 += d[1]; bacc2 += d[2]; }
+    // ---- weight gradient: wave w owns the 32-pixel chunks 2w, 2w+1 (tile rows 2c, 2c+1)
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = wave * 2 + cc;
+      // A = dpre^T: row = co (m < 3), k = pixels {row 2c: 4g..4g+3, row 2c+1: 4g..4g+3}; hi and lo halves: the weight
+      // gradient keeps the precision of an fp32 dpre (the MFMAs are not what this kernel waits for)
+      f16x8 af, al;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          float xv = (float)*reinterpret_cast<const f16*>(tile + ((py + r) * LC_TP + px + s) * LC_PITCH + ci * 2);
-          wacc[(r * 3 + s) * 3 + 0] += d[0] * xv;
-          wacc[(r * 3 + s) * 3 + 1] += d[1] * xv;
-          wacc[(r * 3 + s) * 3 + 2] += d[2] * xv;
+      for (int e = 0; e < 8; ++e) {
+        const int prow = 2 * c + (e >> 2) + 1, pcol = 4 * g + (e & 3) + 1;
+        af[e] = m < 3 ? dp[prow * LC_TP + pcol][m] : (f16)0.f;
+        al[e] = m < 3 ? dp[prow * LC_TP + pcol][4 + m] : (f16)0.f;
+      }
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int r = t9 / 3, sx = t9 - r * 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned char* p0 = tile + ((2 * c + r) * LC_TP + 4 * g + tq + sx) * LC_PITCH + t * 32 + tsub;
+          h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)p0);
+          h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(p0 + LC_TP * LC_PITCH));
+          f16x8 bf = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+          wacc[t9][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, wacc[t9][t], 0, 0, 0);
+          wacc[t9][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bf, wacc[t9][t], 0, 0, 0);
         }
+      }
+    }
+    __syncthreads();
+    // ---- staged data gradient -> global (16-byte chunks; a tile row is 1 KiB contiguous in NHWC)
+    for (int i = tid; i < 256 * 4; i += 256) {
+      const int px = i >> 2, ch = i & 3;
+      const int oy = ty * LC_T + (px >> 4), ox = tx * LC_T + (px & 15);
+      *reinterpret_cast<u32x4*>(a.da4 + (((size_t)n * 128 + oy) * 128 + ox) * LC_CI + ch * 8) =
+          *reinterpret_cast<const u32x4*>(so + px * SP + ch * 16);
     }
   }
-  __syncthreads();                       // everyone is done reading the a4 tile: reuse it for the reduction
-  float* red = reinterpret_cast<float*>(tile);   // [4 subsets][27][32] floats = 13824 B
+  __syncthreads();                       // everyone is done with the a4 tile: reuse it for the reduction
+  float* red = reinterpret_cast<float*>(tile);   // [4 waves][27][32] floats = 13824 B
   static_assert(LC_TP * LC_TP * LC_PITCH >= 4 * 27 * 32 * 4, "reduction buffer");
-  float* outp = a.partial + ((size_t)n * gridDim.x + ty) * 867;
-  if (ci == 0) { bred[q][0] = bacc0; bred[q][1] = bacc1; bred[q][2] = bacc2; }
-  // two rounds of 4 pixel subsets each (fixed order)
-  for (int round = 0; round < 2; ++round) {
-    if ((q >> 2) == round) {
+  // D of the weight gradient: column = ci (lane & 15), rows = co 4g + reg: lanes 0..15 (g = 0), reg 0..2
+  if (g == 0) {
 #pragma unroll
-      for (int k = 0; k < 27; ++k) red[((q & 3) * 27 + k) * 32 + ci] = wacc[k];
-    }
-    __syncthreads();
-    for (int i = tid; i < 27 * 32; i += 256) {
-      float t = red[i] + red[27 * 32 + i] + red[2 * 27 * 32 + i] + red[3 * 27 * 32 + i];
-      int k = i / 32, c = i % 32;       // k = (r*3+s)*3 + co
-      int rs = k / 3, co = k % 3;
-      size_t oidx = (size_t)co * 288 + c * 9 + rs;
-      if (round == 0) outp[oidx] = t; else outp[oidx] += t;   // same thread owns oidx in both rounds
-    }
-    __syncthreads();
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int co = 0; co < 3; ++co) red[(wave * 27 + t9 * 3 + co) * 32 + t * 16 + m] = wacc[t9][t][co];
   }
-  if (tid < 3) {
-    float t = 0.f;
-    for (int k = 0; k < 8; ++k) t += bred[k][tid];
-    outp[864 + tid] = t;
+  bacc0 = lo_wave_sum(bacc0); bacc1 = lo_wave_sum(bacc1); bacc2 = lo_wave_sum(bacc2);
+  if (lane == 0) { bred[wave][0] = bacc0; bred[wave][1] = bacc1; bred[wave][2] = bacc2; }
+  __syncthreads();
+  float* outp = a.partial + ((size_t)n * gridDim.x + ty) * 867;
+  for (int i = tid; i < 27 * 32; i += 256) {
+    const float t = red[i] + red[27 * 32 + i] + red[2 * 27 * 32 + i] + red[3 * 27 * 32 + i];
+    const int k = i / 32, ci = i % 32;       // k = tap*3 + co
+    const int rs = k / 3, co = k % 3;
+    outp[(size_t)co * 288 + ci * 9 + rs] = t;
   }
+  if (tid < 3) outp[864 + tid] = bred[0][tid] + bred[1][tid] + bred[2][tid] + bred[3][tid];
 }
 
 // =============================================================================================
