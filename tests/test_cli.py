@@ -104,3 +104,26 @@ def test_cli_hybrid_end_to_end_on_gpu(tmp_path):
     # teacher optimizer state exists exactly for the 28 tensors that receive gradients in the reference (gate, quality heads)
     assert len(ck["teacher_optimizer"]["state"]) == 28 and len(ck["teacher_optimizer"]["param_groups"][0]["params"]) == 252
     assert "reward_state" in ck["lunaris_amd_extra"]
+
+
+@pytest.mark.gpu
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and (when asked) `cpu_baseline`."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--latent", "256",
+                        "--hybrid-steps", "1", "--cpu-batch", "2", "--cpu-steps", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["config3_full_hybrid"]["value"] > 0
