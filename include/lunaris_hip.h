@@ -151,7 +151,9 @@ long long lo_teacher_tensor_offset(const LoTeacher* h, int index);
 size_t lo_teacher_flat_elems(const LoTeacher* h);
 size_t lo_teacher_workspace_bytes(const LoTeacher* h);
 int lo_teacher_pack(LoTeacher* h, const float* flat_state, void* ws, void* stream);
-/* training != 0: BatchNorm uses batch statistics and updates running_mean / running_var inside flat_state */
+/* training != 0: BatchNorm uses batch statistics and updates running_mean / running_var inside flat_state  Passing NULL for all five output
+ * pointers makes it a statistics-only call (BatchNorm running statistics updated, pooling of the last block and heads
+ * skipped): the first teacher call of _process_batch, train_hybrid.py:853-855, whose outputs are dead in the reference. */
 int lo_teacher_forward(LoTeacher* h, const float* x, float* flat_state, void* ws, int training, float* quality_scores,
                        float* expert_weights, float* style_embedding, float* prompt_embedding, float* semantic_score,
                        void* stream);

@@ -1087,7 +1087,11 @@ static int t_pool(LoTeacher* h, float* pooled, int C, void* ws, hipStream_t st) 
 // training != 0).  outputs: quality_scores [B,4], expert_weights [B,E], style/prompt embeddings [B,emb], semantic [B,1].
 extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* ws, int training, float* quality, float* weights,
                                   float* style, float* prompt, float* semantic, void* stream) {
-  LO_REQUIRE(h && x && P && ws && quality && weights && style && prompt && semantic, "lo_teacher_forward: null argument");
+  // all five output pointers null = statistics-only call: everything that feeds a BatchNorm layer runs (the running
+  // statistics are the call's side effect), the pooling of the last block and the heads do not.  This is the first
+  // teacher call of _process_batch (train_hybrid.py:853-855), whose outputs the reference overwrites before use.
+  const bool stats_only = !quality && !weights && !style && !prompt && !semantic;
+  LO_REQUIRE(h && x && P && ws && (stats_only || (quality && weights && style && prompt && semantic)), "lo_teacher_forward: null argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int B = h->B;
   const size_t px = (size_t)B * T_HW;
@@ -1197,6 +1201,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     }
     if (!h->fuse_tail) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
   }
+  if (stats_only) return LO_OK;
   if (h->fuse_tail) {
     // x_3 of every expert is pooled in ONE pass over feat (the full-resolution x_l were never written)
     {

@@ -177,6 +177,23 @@ class LunarMoETeacher(nn.Module):
             eng[2] = self._weights_version
         return eng
 
+    def update_statistics_only(self, x: torch.Tensor) -> None:
+        """The side effects of `forward(x)` in train mode without its outputs: every BatchNorm layer sees the batch
+        (running statistics, `num_batches_tracked`), the pooling of the last ExpertBlocks and the heads are skipped.
+        `_process_batch` calls the teacher once this way (train_hybrid.py:853-855: the result is overwritten unused)."""
+        if not self.training:
+            return
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
+            raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        h, ws, _ = self._engine(x.shape[0])
+        _lib.check(_lib.lib.lo_teacher_forward(h, x.data_ptr(), self._flat.data_ptr(), ws.data_ptr(), 1, None, None, None, None, None,
+                                               _lib.stream_ptr()), "lo_teacher_forward(statistics only)")
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += 1
+
     def forward(self, x: torch.Tensor, prompt_embedding=None):
         """lunar_evaluator.py:408-462.  ``prompt_embedding`` is accepted and ignored exactly like the reference does
         (it is overwritten at :438 before any use)."""

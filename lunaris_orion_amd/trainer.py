@@ -184,7 +184,7 @@ class HybridStepper(VAEStepper):
         st = _lib.stream_ptr()
         recon, mu, logvar, eng = vae._native_forward(images, eps, target=images)
         if self.run_dead_teacher_call:
-            t(images)                                   # train_hybrid.py:853-855 (side effects only)
+            t.update_statistics_only(images)            # train_hybrid.py:853-855 (side effects only)
         tout = t(recon)                                 # train_hybrid.py:865
         self.last_teacher_out = tout
         h, ws = self._teacher_setup(B)

@@ -221,3 +221,21 @@ print("FUSED_TAP_OK")
     env = dict(os.environ, LO_HALO="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "FUSED_TAP_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_statistics_only_call_has_the_side_effects_of_forward():
+    """`_process_batch`'s first teacher call (train_hybrid.py:853-855) only matters through the BatchNorm running
+    statistics: `update_statistics_only` must leave the same state as a full train-mode forward."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(2)).cuda()
+    states = []
+    for stats_only in (False, True):
+        t = LunarMoETeacher(dropout_rate=0.0); t.load_state_dict(S); t = t.to("cuda").train()
+        t.update_statistics_only(x) if stats_only else t(x)
+        torch.cuda.synchronize()
+        states.append({k: v.detach().cpu().clone() for k, v in t.state_dict().items()})
+    assert int(states[1]["experts.0.0.conv1.2.num_batches_tracked"]) == 1
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
