@@ -430,7 +430,16 @@ static int vae_wait_casts(LoVae* h, hipStream_t st) {
 
 static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16* y, int mode, const float* P, void* ws,
                    hipStream_t st) {
-  LO_TRY(lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st));
+  static char ftag[64][64];
+  static int fcount = 0;
+  if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
+    char* tg = ftag[fcount++ & 63];
+    snprintf(tg, 64, "fwd kind%d %dx%d %d->%d", c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
+    g_lo_prof_tag = tg;
+  }
+  int r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st);
+  g_lo_prof_tag = nullptr;
+  if (r_ != LO_OK) return r_;
   return lo_gn_fwd(WSP(f16, c.o_v), WSP(float, c.o_part), c.MT, PRM(c.p_gw), PRM(c.p_gb), other, y, WSP(float, c.o_stats), h->B,
                    c.Ho * c.Wo, c.Cout, mode, st);
 }
