@@ -1,0 +1,172 @@
+"""Parity at BASELINE.json's full sizes (batch 64, latent 512) through size-independent properties.
+
+The oracle needs minutes per step at this size, so the full-size runs are tied to it indirectly:
+  * GroupNorm is per-sample and the losses are means, so sample i of a batch-64 forward must equal the same sample in a
+    batch-2 forward (which tests/test_vae_gpu.py checks against the oracle and the golden fixtures);
+  * the losses must equal the plain means over the returned tensors;
+  * the batch-64 gradient must be the average of the gradients of its two batch-32 halves;
+  * the same step twice gives the same bits;
+  * the teacher in eval mode (running statistics) is per-sample too: batch 64 vs batch 2; in train mode the sparse
+    expert path must reproduce the dense path (every convolution in full) at batch 64.
+Tolerances: mu / logvar / recon 5e-3 abs (different tile shapes are picked at different batch sizes, so
+the fp32 accumulation order differs), losses 1e-4 abs, gradients 2e-3 relative L2 (fp16 activations).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import teacher_ref as T
+from oracle import vae_ref as R
+
+pytestmark = pytest.mark.gpu
+B_FULL, L_FULL = 64, 512
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _vae(L=L_FULL):
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    m = LunarisCoreVAE(latent_dim=L)
+    m.load_state_dict(R.closed_form_params(L, 0))
+    return m.to("cuda")
+
+
+def _inputs(B, L=L_FULL):
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    return x, eps
+
+
+def test_batch64_forward_is_per_sample_and_losses_are_means():
+    m = _vae()
+    x, eps = _inputs(B_FULL)
+    with torch.no_grad():
+        recon, mu, logvar = m(x, eps)
+        # the pair (4, 37) as its own batch of two
+        idx = torch.tensor([4, 37], device="cuda")
+        r2, mu2, lv2 = m(x[idx].contiguous(), eps[idx].contiguous())
+    torch.cuda.synchronize()
+    assert (mu[idx] - mu2).abs().max().item() <= 5e-3
+    assert (logvar[idx] - lv2).abs().max().item() <= 5e-3
+    assert (recon[idx] - r2).abs().max().item() <= 5e-3
+    # tie the small batch to the oracle here as well (seconds on the CPU)
+    P = R.closed_form_params(L_FULL, 0)
+    r_ref, mu_ref, lv_ref = R.vae_forward(x[idx].cpu(), eps[idx].cpu(), P)
+    assert (mu2.cpu() - mu_ref).abs().max().item() <= 5e-3
+    assert (lv2.cpu() - lv_ref).abs().max().item() <= 5e-3
+    assert (r2.cpu() - r_ref).abs().max().item() <= 5e-3
+
+    from lunaris_orion_amd.trainer import VAEStepper
+    st = VAEStepper(m, lr=0.0, weight_decay=0.0)
+    st.step(x, 0, eps)
+    met = st.metrics()
+    rl = torch.mean((recon.double() - x.double()) ** 2).item()
+    kl = (-0.5 * torch.mean(1 + logvar.double() - mu.double() ** 2 - logvar.double().exp())).item()
+    assert abs(met["recon_loss"] - rl) <= 1e-4
+    assert abs(met["kl_loss"] - kl) <= 1e-4
+
+
+def test_batch64_gradient_is_the_mean_of_its_halves_and_is_deterministic():
+    from lunaris_orion_amd.trainer import VAEStepper
+    x, eps = _inputs(B_FULL)
+
+    def grads(xs, es):
+        m = _vae()
+        st = VAEStepper(m, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
+        st.step(xs, 0, es)
+        torch.cuda.synchronize()
+        return [g.detach().double().clone() for g in st.parameter_grads()], [k for k, _ in m.named_parameters()]
+
+    full, names = grads(x, eps)
+    again, _ = grads(x, eps)
+    for a, b, k in zip(full, again, names):
+        assert torch.equal(a, b), k                       # bitwise run-to-run
+    h0, _ = grads(x[:32].contiguous(), eps[:32].contiguous())
+    h1, _ = grads(x[32:].contiguous(), eps[32:].contiguous())
+    num = den = 0.0
+    for g, a, b, k in zip(full, h0, h1, names):
+        ref = 0.5 * (a + b)
+        e, n = (g - ref).norm().item(), ref.norm().item()
+        num += e * e
+        den += n * n
+        assert e <= 2e-3 * n + 1e-9, (k, e / (n + 1e-30))
+    assert (num / den) ** 0.5 <= 1e-3
+
+
+def test_full_size_clip_adamw_matches_torch():
+    """clip_grad_norm_ + AdamW on the whole latent-512 flat buffer (61 M elements) against torch.optim.AdamW."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    m = _vae()
+    x, eps = _inputs(4)
+    st = VAEStepper(m, lr=1e-3, min_lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    before = [p.detach().clone() for p in m.parameters()]
+    st.step(x, 0, eps)
+    torch.cuda.synchronize()
+    g = [t.detach().clone() for t in st.parameter_grads()]
+    ref = [torch.nn.Parameter(b.clone()) for b in before]
+    for p, gg in zip(ref, g):
+        p.grad = gg.clone()
+    opt = torch.optim.AdamW(ref, lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    torch.nn.utils.clip_grad_norm_(ref, 1.0)
+    opt.step()
+    for (k, p), r in zip(m.named_parameters(), ref):
+        assert (p.detach() - r.detach()).abs().max().item() <= 2e-6, k
+
+
+def _teacher(B):
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    m = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256, dropout_rate=0.0)
+    m.load_state_dict(T.closed_form_teacher_state(embedding_dim=256))
+    return m.to("cuda")
+
+
+def test_teacher_eval_batch64_is_per_sample():
+    m = _teacher(B_FULL)
+    m.eval()
+    x, _ = _inputs(B_FULL)
+    idx = torch.tensor([9, 50], device="cuda")
+    with torch.no_grad():
+        full = m(x)
+        two = m(x[idx].contiguous())
+    torch.cuda.synchronize()
+    tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}
+    for k, t in tol.items():
+        assert (full[k][idx] - two[k]).abs().max().item() <= t, k
+
+
+_DENSE_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from oracle import vae_ref as R
+from lunaris_orion_amd.teacher import LunarMoETeacher
+from oracle import teacher_ref as T
+m = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256, dropout_rate=0.0)
+m.load_state_dict(T.closed_form_teacher_state(embedding_dim=256))
+m = m.to("cuda")
+m.train(True)
+x = R.normalise_sprites(R.closed_form_sprites(64)).cuda()
+out = m(x)
+torch.cuda.synchronize()
+torch.save({{k: v.cpu() for k, v in out.items() if v is not None}} | {{"rm": m.state_dict()["experts.3.2.conv2.2.running_mean"].cpu(),
+            "rv": m.state_dict()["experts.1.1.conv1.2.running_var"].cpu()}}, sys.argv[1])
+"""
+
+
+def test_teacher_train_batch64_sparse_equals_dense(tmp_path):
+    """The path that skips the constant fields (default) against every convolution in full (LO_T_DENSE=1), batch 64,
+    train-mode BatchNorm: outputs and the running statistics it leaves behind.  One process each: the switch is read
+    when the library creates the teacher."""
+    outs = {}
+    for dense in ("0", "1"):
+        f = tmp_path / f"t{dense}.pt"
+        env = dict(os.environ, LO_T_DENSE=dense)
+        r = subprocess.run([sys.executable, "-c", _DENSE_SNIPPET.format(root=ROOT), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[dense] = torch.load(f)
+    tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3,
+           "rm": 2e-3, "rv": 2e-3}
+    for k, t in tol.items():
+        d = (outs["0"][k] - outs["1"][k]).abs().max().item()
+        assert d <= t * max(1.0, outs["1"][k].abs().max().item()), (k, d)
