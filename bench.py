@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-fp16", action="store_true", help="fp16 wire format for the gradient all-reduce (off: fp32)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--precision", choices=["fp16", "fp8"], default="fp16",
+                    help="operand format of the forward convs in the timed leg (fp8 = BASELINE config 5 mode; the headline number is fp16)")
+    ap.add_argument("--fp8-steps", type=int, default=20, help="extra leg (N=1): VAE-only steps in the fp8 operand mode, BASELINE config 5 (0 = skip)")
     ap.add_argument("--hybrid-steps", type=int, default=8, help="extra leg (N=1): full hybrid VAE+teacher steps, BASELINE config 3 (0 = skip)")
     args = ap.parse_args()
 
@@ -135,7 +138,7 @@ def main():
     from lunaris_orion_amd.vae import LunarisCoreVAE
 
     torch.manual_seed(42)                      # identical initial weights on every rank (train_hybrid.py:1088,1138)
-    model = LunarisCoreVAE(latent_dim=args.latent).to("cuda")
+    model = LunarisCoreVAE(latent_dim=args.latent, mfma_precision=args.precision).to("cuda")
     grad_sync = None
     if world > 1:
         from lunaris_orion_amd.parallel import FlatGradSync
@@ -231,16 +234,49 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "f16" if args.precision == "fp16" else "fp8 (e4m3 forward operands) / f16 backward",
             "data": "synthetic",
             "config": {"workload": f"VAE-only training step (fwd+MSE/KL+bwd+clip+AdamW), per-GPU batch {B}, latent_dim {args.latent}, "
                                    "teacher scalar 0 (--reward_scale 0 --quality_weight 0; the full hybrid step of BASELINE config 3 is the config3_full_hybrid object at N=1), "
-                                   "gradient_accumulation_steps 1, fp16 MFMA operands / fp32 accumulate, fp32 master weights",
+                                   "gradient_accumulation_steps 1, " + ("fp16 MFMA operands" if args.precision == "fp16" else
+                                   "e4m3 MFMA operands in the forward convs with Cin % 128 == 0, fp16 elsewhere") + " / fp32 accumulate, fp32 master weights",
                        "global_batch": world * B, "latent_dim": args.latent,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof,
             "final_metrics": {k: met[k] for k in ("recon_loss", "kl_loss", "grad_norm")},
         }
+        if world == 1 and args.fp8_steps > 0 and args.precision == "fp16":
+            # BASELINE config 5: the same VAE-only step with e4m3 operands in the forward convs; loss parity against the fp16 mode
+            # from identical weights, inputs and noise (first step), then throughput
+            def fresh(prec):
+                torch.manual_seed(42)
+                m = LunarisCoreVAE(latent_dim=args.latent, mfma_precision=prec).to("cuda")
+                return m, VAEStepper(m, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
+                                     kl_weight=0.1, gradient_accumulation_steps=1)
+            first = {}
+            for prec in ("fp16", "fp8"):
+                m8, s8 = fresh(prec)
+                s8.step(pool[0], batch_idx=0)
+                first[prec] = s8.metrics()
+                if prec == "fp16":
+                    del m8, s8
+            for i in range(1, 6):
+                s8.step(pool[i % len(pool)], batch_idx=i)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            for i in range(args.fp8_steps):
+                s8.step(pool[i % len(pool)], batch_idx=i)
+            torch.cuda.synchronize()
+            dt8 = (time.perf_counter() - t8) / args.fp8_steps
+            out["config5_fp8_forward"] = {
+                "value": B / dt8, "unit": "sprites/s", "ms_per_step": 1e3 * dt8, "steps": args.fp8_steps,
+                "workload": f"VAE-only step, batch {B}, latent {args.latent}: OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4) in the "
+                            "forward convs with Cin % 128 == 0, fp16 backward",
+                "loss_parity_vs_f16_first_step": {k: abs(first["fp8"][k] - first["fp16"][k]) for k in ("recon_loss", "kl_loss")},
+                "f16_first_step": {k: first["fp16"][k] for k in ("recon_loss", "kl_loss", "grad_norm")},
+                "fp8_first_step": {k: first["fp8"][k] for k in ("recon_loss", "kl_loss", "grad_norm")}}
+            del m8, s8
+            torch.cuda.empty_cache()
         if world == 1 and args.hybrid_steps > 0:
             # BASELINE config 3: batch 64, latent 512, embedding_dim 256, feature_dim 128, teacher on (both teacher forwards of
             # _process_batch, reward/advantage, gate + quality-head update); teacher dropout not applied

@@ -54,6 +54,13 @@ int lo_pack_weight_for(int kind, int B, int H, int W, int Cin, int Cout, const f
  * in/out/add_src: fp16 NHWC.  Replaces aten::convolution / aten::addmm. */
 int lo_conv_forward(int kind, int B, int H, int W, int Cin, int Cout, const void* in, const void* wp, const float* bias,
                     const void* add_src, void* out, float* gn_partial, int* mt_out, void* stream);
+/* e4m3 operand forms (see LO_VAE_FP8_FWD below; Cin % 128 == 0, Cout % 64 == 0): x8 = fp8(8 * x16) saturating at 448;
+ * wp8 / wscale[n_phase][Cout] from the packed fp16 weight (one scale per output channel: amax / 448, folded with 1/8);
+ * the conv itself, same outputs as lo_conv_forward. */
+int lo_quantize_act_f8(const void* x16, void* x8, size_t n, void* stream);
+int lo_pack_weight_f8_for(int kind, int B, int H, int W, int Cin, int Cout, const void* wp16, void* wp8, float* wscale, void* stream);
+int lo_conv_forward_f8(int kind, int B, int H, int W, int Cin, int Cout, const void* in8, const void* wp8, const float* wscale,
+                       const float* bias, const void* add_src, void* out, float* gn_partial, int* mt_out, void* stream);
 /* Linear with split-K: y[M,N] (fp32 and/or fp16) = x[M,K] Wp[N,K]^T + bias.  slab: nsplit*M*N floats. */
 int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab, int nsplit,
                      float* out32, void* out16, void* stream);
@@ -110,6 +117,14 @@ int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, size_t n, f
 /* ---- the VAE step executor (LunarisCoreVAE.forward / backward, lunar_generate.py:263-276) -------------------- */
 typedef struct LoVae LoVae;
 int lo_vae_create(int batch, int latent_dim, LoVae** out);
+/* The same with mode flags.  LO_VAE_FP8_FWD (BASELINE config 5): the forward convolutions whose input channel count is a
+ * multiple of 128 (ResBlock / stride-2 convs at 128-512 channels, transposed convs at 512 / 256 / 128) run on OCP e4m3
+ * operands (v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation): activations as fp8(8 * value) written next to the fp16
+ * copy by the producing GroupNorm kernel, weights with one scale per output channel.  The backward is unchanged (fp16
+ * operands).  No reference counterpart: the reference's low-precision mode is torch.cuda.amp fp16 autocast
+ * (train_hybrid.py:850).  Unknown flag bits are an error. */
+#define LO_VAE_FP8_FWD 1u
+int lo_vae_create_ex(int batch, int latent_dim, unsigned flags, LoVae** out);
 void lo_vae_destroy(LoVae* h);
 /* parameters live in ONE flat fp32 buffer; tensor i (state_dict order, 72 tensors) starts at this element offset */
 int lo_vae_num_params(const LoVae* h);

@@ -35,6 +35,9 @@ SIGNATURES = {
     "lo_packed_weight_elems_for": (sz, [i32] * 6),
     "lo_pack_weight_for": (i32, [i32] * 6 + [f32p, vp, vp]),
     "lo_conv_forward": (i32, [i32] * 6 + [vp, vp, f32p, vp, vp, f32p, C.POINTER(C.c_int), vp]),
+    "lo_quantize_act_f8": (i32, [vp, vp, sz, vp]),
+    "lo_pack_weight_f8_for": (i32, [i32] * 6 + [vp, vp, f32p, vp]),
+    "lo_conv_forward_f8": (i32, [i32] * 6 + [vp, vp, f32p, f32p, vp, vp, f32p, C.POINTER(C.c_int), vp]),
     "lo_linear_splitk": (i32, [i32, i32, i32, vp, vp, f32p, f32p, i32, f32p, vp, vp]),
     "lo_wgrad_slab_bytes_for": (sz, [i32] * 6),
     "lo_conv_wgrad": (i32, [i32] * 6 + [vp, vp, f32p, f32p, flt, vp]),
@@ -64,6 +67,7 @@ SIGNATURES = {
     "lo_teacher_heads_backward": (i32, [vp, f32p, vp, f32p, flt, f32p, f32p, vp]),
     "lo_hybrid_reward": (i32, [f32p, f32p, i32, flt, flt, flt, flt, flt, f32p, f32p, f32p, vp]),
     "lo_vae_create": (i32, [i32, i32, C.POINTER(C.c_void_p)]),
+    "lo_vae_create_ex": (i32, [i32, i32, C.c_uint, C.POINTER(C.c_void_p)]),
     "lo_vae_destroy": (None, [vp]),
     "lo_vae_num_params": (i32, [vp]),
     "lo_vae_param_offset": (sz, [vp, i32]),

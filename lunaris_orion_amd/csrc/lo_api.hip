@@ -38,6 +38,27 @@ extern "C" int lo_conv_forward(int kind, int B, int H, int W, int Cin, int Cout,
   if (mt_out) *mt_out = lo_conv_mt(g);
   return lo_conv_run(g, (const f16*)in, (const f16*)wp, bias, (const f16*)add_src, (f16*)out, gn_partial, nullptr, 1, S(stream));
 }
+// fp8 (e4m3) operand forms of the same op: see LO_VAE_FP8_FWD in the header
+extern "C" int lo_quantize_act_f8(const void* x16, void* x8, size_t n, void* stream) {
+  LO_REQUIRE(x16 && x8, "lo_quantize_act_f8: null argument");
+  return lo_quantize_f8((const f16*)x16, (uint8_t*)x8, n, S(stream));
+}
+extern "C" int lo_pack_weight_f8_for(int kind, int B, int H, int W, int Cin, int Cout, const void* wp16, void* wp8, float* wscale,
+                                     void* stream) {
+  LO_REQUIRE(wp16 && wp8 && wscale, "lo_pack_weight_f8_for: null argument");
+  LoGeom g;
+  LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
+  return lo_pack_f8_one(g, (const f16*)wp16, (uint8_t*)wp8, wscale, S(stream));
+}
+extern "C" int lo_conv_forward_f8(int kind, int B, int H, int W, int Cin, int Cout, const void* in8, const void* wp8,
+                                  const float* wscale, const float* bias, const void* add_src, void* out, float* gn_partial,
+                                  int* mt_out, void* stream) {
+  LO_REQUIRE(in8 && wp8 && wscale && out, "lo_conv_forward_f8: null argument");
+  LoGeom g;
+  LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
+  if (mt_out) *mt_out = lo_conv_mt(g);
+  return lo_conv_run_f8(g, (const uint8_t*)in8, (const uint8_t*)wp8, wscale, bias, (const f16*)add_src, (f16*)out, gn_partial, S(stream));
+}
 extern "C" int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab,
                                 int nsplit, float* out32, void* out16, void* stream) {
   LoGeom g;
@@ -132,6 +153,9 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_P1, o_P2;         // GN backward partial sums (kept until the fused finalize at the end of backward)
   int np1;                   // >0: P1 rows per sample written by the consumer's fused data-gradient epilogue
   int MT;
+  // fp8 operand mode (LO_VAE_FP8_FWD): e4m3 weights + per-row scales of the forward op, e4m3 copy of the activation o_a
+  bool f8;                   // this layer's forward conv runs on e4m3 operands
+  size_t o_wp8, o_wscale, o_a8;   // o_a8 = 0: no consumer needs the copy
 };
 
 struct Arena {
@@ -178,6 +202,11 @@ struct LoVae {
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
+  // fp8 operand mode of the forward convs (lo_vae_create_ex flag LO_VAE_FP8_FWD)
+  bool fp8_fwd;
+  size_t o_eout8[4], o_h08, o_packjobs8;
+  std::vector<LoPackF8Job> packjobs8_host;
+  int n_packjobs8, pack_blocks8;
 };
 
 static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin, int Cout, int p_w, Arena& ar, bool first) {
@@ -207,11 +236,16 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   c.np1 = 0;
   c.o_P1 = ar.take((size_t)B * p1rows * Cout * 2 * 4);
   c.o_P2 = ar.take((size_t)B * nchunk * Cout * 4);
+  c.f8 = false;
+  c.o_wp8 = c.o_wscale = c.o_a8 = 0;
   return LO_OK;
 }
 
-extern "C" int lo_vae_create(int B, int L, LoVae** out) {
+extern "C" int lo_vae_create(int B, int L, LoVae** out) { return lo_vae_create_ex(B, L, 0u, out); }
+
+extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   LO_REQUIRE(out, "lo_vae_create: null out");
+  LO_REQUIRE((flags & ~(unsigned)LO_VAE_FP8_FWD) == 0, "lo_vae_create_ex: unknown flag bits 0x%x", flags);
   LO_REQUIRE(B >= 1 && B <= 4096, "lo_vae_create: batch %d out of range", B);
   LO_REQUIRE(L >= 64 && L % 64 == 0 && L <= 4096, "lo_vae_create: latent_dim %d must be a multiple of 64", L);
   LoVae* h = new LoVae();
@@ -327,6 +361,29 @@ extern "C" int lo_vae_create(int B, int L, LoVae** out) {
   h->o_slab_dz = ar.take((size_t)h->dfcd_split * B * L * 4);
   h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
+  // ---- fp8 operand mode: every forward conv whose geometry the e4m3 igemm covers (Cin % 128 == 0: the 128 / 256 / 512
+  // channel ResBlock and stride-2 convs, the 512 / 256 / 128 channel transposed convs) reads an e4m3 copy of its input,
+  // written by the kernel that produces the fp16 activation (which the backward still uses)
+  h->fp8_fwd = (flags & LO_VAE_FP8_FWD) != 0;
+  for (int s = 0; s < 4; ++s) h->o_eout8[s] = 0;
+  h->o_h08 = 0; h->o_packjobs8 = 0; h->n_packjobs8 = h->pack_blocks8 = 0;
+  if (h->fp8_fwd) {
+    auto enable = [&](ConvLayer& c, size_t* producer_copy) {
+      if (!lo_conv_f8_applies(c.gf)) return;
+      c.f8 = true;
+      c.o_wp8 = ar.take(lo_packed_weight_elems(c.gf));
+      c.o_wscale = ar.take((size_t)c.gf.n_phase * c.Cout * 4);
+      if (!*producer_copy) *producer_copy = ar.take((size_t)B * c.H * c.W * c.Cin);
+    };
+    for (int s = 0; s < 4; ++s) {
+      if (s > 0) enable(h->enc[s][0], &h->o_eout8[s - 1]);
+      enable(h->enc[s][1], &h->enc[s][0].o_a8);
+      enable(h->enc[s][2], &h->enc[s][1].o_a8);
+    }
+    enable(h->dec[0], &h->o_h08);
+    for (int s = 1; s < 4; ++s) enable(h->dec[s], &h->dec[s - 1].o_a8);
+    h->o_packjobs8 = ar.take(sizeof(LoPackF8Job) * 32);
+  }
   h->ws_bytes = ar.off;
   h->side = nullptr;
   h->cast_pending = false;
@@ -393,6 +450,26 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     LO_HIP(hipMemcpyAsync(WSP(void, h->o_packjobs), jobs.data(), jobs.size() * sizeof(LoPackJob), hipMemcpyHostToDevice, st));
     h->n_packjobs = (int)jobs.size();
     h->pack_blocks = blocks;
+    if (h->fp8_fwd) {
+      std::vector<LoPackF8Job>& j8 = h->packjobs8_host;
+      j8.clear();
+      int blocks8 = 0;
+      auto add8 = [&](ConvLayer& c) {
+        if (!c.f8) return;
+        LoPackF8Job j;
+        lo_pack_f8_job(&j, c.gf, WSP(f16, c.o_wp_f), WSP(uint8_t, c.o_wp8), WSP(float, c.o_wscale), blocks8);
+        blocks8 += c.gf.n_phase * c.Cout;
+        j8.push_back(j);
+      };
+      for (int s = 0; s < 4; ++s)
+        for (int k = 0; k < 3; ++k) add8(h->enc[s][k]);
+      for (int s = 0; s < 4; ++s) add8(h->dec[s]);
+      LO_REQUIRE(j8.size() <= 32, "too many fp8 pack jobs");
+      if (!j8.empty())
+        LO_HIP(hipMemcpyAsync(WSP(void, h->o_packjobs8), j8.data(), j8.size() * sizeof(LoPackF8Job), hipMemcpyHostToDevice, st));
+      h->n_packjobs8 = (int)j8.size();
+      h->pack_blocks8 = blocks8;
+    }
     h->packjobs_for_ws = ws;
     h->packjobs_for_params = (const void*)P;
   }
@@ -405,6 +482,7 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     cs = h->side;
   }
   LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, st));
+  if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(WSP(LoPackF8Job, h->o_packjobs8), h->n_packjobs8, h->pack_blocks8, st));
   const int L = h->L;
   // encoder head: [fc_mu.weight ; fc_logvar.weight] is one contiguous [2L][32768] fp32 matrix in the flat buffer
   LO_REQUIRE(h->p_off[h->idx_fc_lv_w] == h->p_off[h->idx_fc_mu_w] + (size_t)L * 32768, "flat layout: head weights not adjacent");
@@ -428,8 +506,9 @@ static int vae_wait_casts(LoVae* h, hipStream_t st) {
   return LO_OK;
 }
 
+// in8: e4m3 copy of `in` (fp8 mode, layers with c.f8); y8: where to leave the e4m3 copy of y (0 = nobody reads it)
 static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16* y, int mode, const float* P, void* ws,
-                   hipStream_t st) {
+                   hipStream_t st, size_t o_in8 = 0, size_t o_y8 = 0) {
   static char ftag[64][64];
   static int fcount = 0;
   if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
@@ -437,11 +516,18 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
     snprintf(tg, 64, "fwd kind%d %dx%d %d->%d", c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
     g_lo_prof_tag = tg;
   }
-  int r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st);
+  int r_;
+  if (c.f8) {
+    LO_REQUIRE(o_in8, "fp8 mode: no e4m3 copy of the input of a conv %d->%d", c.Cin, c.Cout);
+    r_ = lo_conv_run_f8(c.gf, WSP(uint8_t, o_in8), WSP(uint8_t, c.o_wp8), WSP(float, c.o_wscale), PRM(c.p_b), nullptr, WSP(f16, c.o_v),
+                        WSP(float, c.o_part), st);
+  } else {
+    r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st);
+  }
   g_lo_prof_tag = nullptr;
   if (r_ != LO_OK) return r_;
   return lo_gn_fwd(WSP(f16, c.o_v), WSP(float, c.o_part), c.MT, PRM(c.p_gw), PRM(c.p_gb), other, y, WSP(float, c.o_stats), h->B,
-                   c.Ho * c.Wo, c.Cout, mode, st);
+                   c.Ho * c.Wo, c.Cout, mode, st, o_y8 ? WSP(uint8_t, o_y8) : nullptr);
 }
 
 // decoder (lunar_generate.py:194-229) from the latent z (fp16, in the workspace); use_skips=false is the `skips=[]`
@@ -452,13 +538,15 @@ static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* w
   LO_TRY(vae_wait_casts(h, st));
   LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
                      nullptr, 1, st));
-  LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st));
+  LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st, h->o_h08 ? WSP(uint8_t, h->o_h08) : nullptr));
   const f16* cur = WSP(f16, h->o_h0);
+  size_t cur8 = h->o_h08;
   for (int s = 0; s < 4; ++s) {
     ConvLayer& c = h->dec[s];
     const f16* skip = (use_skips && s < 3) ? WSP(f16, h->o_eout[2 - s]) : nullptr;
-    LO_TRY(conv_gn(h, c, cur, skip, WSP(f16, c.o_a), skip ? 1 : 0, P, ws, st));
+    LO_TRY(conv_gn(h, c, cur, skip, WSP(f16, c.o_a), skip ? 1 : 0, P, ws, st, cur8, c.o_a8));
     cur = WSP(f16, c.o_a);
+    cur8 = c.o_a8;
   }
   return lo_final_conv_fwd(cur, PRM(h->idx_final_w), PRM(h->idx_final_b), target, recon, target ? WSP(float, h->o_msep) : nullptr,
                            B, st);
@@ -471,6 +559,7 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
   const int B = h->B, L = h->L;
   // ---- encoder (lunar_generate.py:127-153)
   const f16* cur = nullptr;
+  size_t cur8 = 0;
   for (int s = 0; s < 4; ++s) {
     ConvLayer& c0 = h->enc[s][0];
     ConvLayer& c1 = h->enc[s][1];
@@ -478,14 +567,15 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
     if (s == 0) {
       LO_TRY(lo_first_conv_fwd(x, PRM(c0.p_w), PRM(c0.p_b), WSP(f16, c0.o_v), WSP(float, c0.o_part), B, st));
       LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
-                       WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st));
+                       WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
     } else {
-      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st));
+      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8));
     }
-    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st));
+    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8));
     // ResBlock tail: out = mish(mish(GN(conv2)) + identity); c2.o_a is unused, the result is the stage output
-    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st));
+    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st, c1.o_a8, h->o_eout8[s]));
     cur = WSP(f16, h->o_eout[s]);
+    cur8 = h->o_eout8[s];
   }
   // ---- heads + reparameterisation (lunar_generate.py:150-152, 259-261)
   LO_TRY(lo_nhwc_to_nchw_f16(cur, WSP(f16, h->o_xflat), B, 64, 512, st));

@@ -13,6 +13,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define LO_WAVE 64
 
@@ -161,4 +163,17 @@ __device__ __forceinline__ float lo_mish_grad(float u) {
   float t = w * (w + 2.0f);
   float r = __builtin_amdgcn_rcpf(t + 2.0f);
   return t * r + u * (4.0f * w * (w + 1.0f)) * (r * r);
+}
+
+// ---- fp8 operand path (OCP e4m3, gfx950): activations are stored as fp8(value * LO_F8_ACT_SCALE) with saturation at the
+// e4m3 maximum (448): 8 covers |value| <= 56 with 3 mantissa bits down to 2^-9 (subnormal step 2.4e-4); the GroupNorm +
+// Mish outputs these buffers hold are O(1).  Weights carry one scale per output channel (lo_pack_f8_kernel).
+#define LO_F8_ACT_SCALE 8.0f
+#define LO_F8_MAX 448.0f
+__device__ __forceinline__ uint32_t lo_pack4_fp8(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -LO_F8_MAX), LO_F8_MAX); b = fminf(fmaxf(b, -LO_F8_MAX), LO_F8_MAX);
+  c = fminf(fmaxf(c, -LO_F8_MAX), LO_F8_MAX); d = fminf(fmaxf(d, -LO_F8_MAX), LO_F8_MAX);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
 }

@@ -189,6 +189,7 @@ struct IgemmArgs {
   const float* gb_gamma;
   const float* gb_beta;
   float* gb_P1;
+  const float* f8_scale;   // fp8 operand path: [n_phase][Cout] dequantisation factor (weight row scale / activation scale)
   int M;               // rows per phase = B*GH*GW
   int nsplit;          // >= 1
   int ksteps_per_split;
@@ -215,11 +216,18 @@ __device__ __forceinline__ int lo_xcd_remap(int bid, int total) {
 // wave-instruction fills 1 KiB of LDS linearly, so tiles are unpadded [rows][BK] and bank conflicts are removed by an
 // XOR swizzle applied on the per-lane SOURCE chunk and again on the fragment read: chunk' = chunk ^ ((row >> 1) & (CPR-1)).
 // NSTAGE LDS stages, NSTAGE-1 K steps in flight behind a counted s_waitcnt vmcnt + one raw s_barrier per K step.
-template <int BM, int BN, int BK, int NSTAGE, bool SPLITK>
+// F8: both operands are OCP e4m3 bytes (in / w point at bytes, every element offset below is scaled by ES), BK = 128 elements
+// so a tile row is the same 128 bytes as the fp16 BK = 64 row, and one K step is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per
+// 16x16 block (lane holds row lane&15, k = 32*(lane>>4) .. +31: two adjacent 16-byte chunks; unit block scales) - twice the
+// K per byte moved and per MFMA cycle.  The epilogue multiplies by f8_scale[phase][n] before the bias.
+template <int BM, int BN, int BK, int NSTAGE, bool SPLITK, bool F8 = false>
 __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
-  constexpr int CPR = BK / 8;             // 16-byte chunks per tile row
+  constexpr int ES = F8 ? 1 : 2;          // bytes per operand element
+  constexpr int CE = 16 / ES;             // elements per 16-byte chunk
+  constexpr int CPR = BK / CE;            // 16-byte chunks per tile row
   constexpr int RPI = 64 / CPR;           // tile rows filled by one wave-instruction
-  constexpr int ROWB = BK * 2;            // bytes per tile row
+  constexpr int ROWB = BK * ES;           // bytes per tile row
+  static_assert(!(F8 && SPLITK) && (!F8 || BK == 128), "fp8 path: BK = 128, no split-K");
   constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;   // LDS-DMA instructions per wave and K step (A, B)
   static_assert(IA >= 1 && IB >= 1 && IA * RPI * 4 == BM && IB * RPI * 4 == BN, "tile / wave-instruction mismatch");
   constexpr int LPT = IA + IB;
@@ -254,8 +262,9 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   }
   const int nk = ks_end - ks_begin;
   const int Ktot = T * g.Cin;
-  const f16* wbase = a.w + g.wofs[phase];
-  const f16* zpage = reinterpret_cast<const f16*>(lo_zero_page);
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w) + (size_t)g.wofs[phase] * ES;
+  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page);
   const uint32_t dyc = g.dyc[phase], dxc = g.dxc[phase];   // tap offsets in registers: no memory load inside the K loop
 
   // per-lane source coordinates of the LDS-DMA instructions this wave issues.  Everything that depends only on the
@@ -272,13 +281,13 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     a_iy0[i] = ok ? gy * g.in_stride : -100000;       // makes every tap invalid for an out-of-range row
     a_ix0[i] = gx * g.in_stride;
     a_base[i] = ((n_img * g.Hin + gy * g.in_stride) * g.Win + gx * g.in_stride) * g.Cin +
-                (lpos ^ ((row >> 1) & (CPR - 1))) * 8;   // logical chunk stored at this lane's LDS slot
+                (lpos ^ ((row >> 1) & (CPR - 1))) * CE;  // logical chunk stored at this lane's LDS slot
   }
   int b_base[IB];
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
     int row = (wave * IB + i) * RPI + lrow;
-    b_base[i] = (n0 + row) * Ktot + (lpos ^ ((row >> 1) & (CPR - 1))) * 8;
+    b_base[i] = (n0 + row) * Ktot + (lpos ^ ((row >> 1) & (CPR - 1))) * CE;
   }
   // issue-side K position (tap, channel block) and the per-tap source offsets
   int i_t = ks_begin / KCB, i_cb = ks_begin - i_t * KCB, i_ks = ks_begin;
@@ -301,13 +310,13 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     const int coff = i_cb * BK;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const f16* src = (live && a_tap[i] >= 0) ? a.in + (a_tap[i] + coff) : zpage;
+      const unsigned char* src = (live && a_tap[i] >= 0) ? inb + (size_t)(a_tap[i] + coff) * ES : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sa + (wave * IA + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const f16* src = live ? wbase + (b_base[i] + i_ks * BK) : zpage;
+      const unsigned char* src = live ? wbase + (size_t)(b_base[i] + i_ks * BK) * ES : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + (wave * IB + i) * 1024), 16, 0, 0);
     }
@@ -327,20 +336,24 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
 
   const int fr = lane & 15, fq = lane >> 4;
   // fragment read offsets (bytes inside a stage), swizzled like the DMA sources
-  int xoff[MI][BK / 32], woff[NI][BK / 32];
+  constexpr int NKK = F8 ? BK / 128 : BK / 32;   // MFMA k sub-steps per K step
+  constexpr int CPF = F8 ? 2 : 1;                // 16-byte chunks per lane fragment
+  int xoff[MI][NKK][CPF], woff[NI][NKK][CPF];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      int R = wm * WM + mi * 16 + fr;
-      xoff[mi][kk] = R * ROWB + (((kk * 4 + fq) ^ ((R >> 1) & (CPR - 1))) * 16);
-    }
+    for (int cf = 0; cf < CPF; ++cf) {
+      const int chunk = F8 ? kk * 8 + fq * 2 + cf : kk * 4 + fq;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+      for (int mi = 0; mi < MI; ++mi) {
+        int R = wm * WM + mi * 16 + fr;
+        xoff[mi][kk][cf] = R * ROWB + ((chunk ^ ((R >> 1) & (CPR - 1))) * 16);
+      }
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      int R = wn * WN + ni * 16 + fr;
-      woff[ni][kk] = A_BYTES + R * ROWB + (((kk * 4 + fq) ^ ((R >> 1) & (CPR - 1))) * 16);
+      for (int ni = 0; ni < NI; ++ni) {
+        int R = wn * WN + ni * 16 + fr;
+        woff[ni][kk][cf] = A_BYTES + R * ROWB + ((chunk ^ ((R >> 1) & (CPR - 1))) * 16);
+      }
     }
 
   if (nk > 0) {
@@ -354,17 +367,36 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
       issue(ws);
       const unsigned char* sbase = smem + rs * STAGE;
 #pragma unroll
-      for (int kk = 0; kk < BK / 32; ++kk) {
-        f16x8 wf[NI], xf[MI];
+      for (int kk = 0; kk < NKK; ++kk) {
+        if constexpr (F8) {
+          i32x8 wf[NI], xf[MI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const f16x8*>(sbase + woff[ni][kk]);
+          for (int ni = 0; ni < NI; ++ni) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(sbase + woff[ni][kk][0]), hi = *reinterpret_cast<const i32x4*>(sbase + woff[ni][kk][1]);
+            wf[ni] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const f16x8*>(sbase + xoff[mi][kk]);
+          for (int mi = 0; mi < MI; ++mi) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(sbase + xoff[mi][kk][0]), hi = *reinterpret_cast<const i32x4*>(sbase + xoff[mi][kk][1]);
+            xf[mi] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            for (int mi = 0; mi < MI; ++mi)   // formats 0 / 0 = e4m3 x e4m3; block scales 0x7f = 2^0
+              acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else {
+          f16x8 wf[NI], xf[MI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const f16x8*>(sbase + woff[ni][kk][0]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const f16x8*>(sbase + xoff[mi][kk][0]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
       }
       rs = (rs + 1 == NSTAGE) ? 0 : rs + 1;
       ws = (ws + 1 == NSTAGE) ? 0 : ws + 1;
@@ -397,10 +429,12 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     int nl = wn * WN + ni * 16 + fq * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + nl);
+    f32x4 sv = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (F8) sv = *reinterpret_cast<const f32x4*>(a.f8_scale + (size_t)phase * g.Cout + n0 + nl);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       int ml = wm * WM + mi * 16 + fr;
-      f32x4 v = acc[ni][mi] + bv;
+      f32x4 v = F8 ? acc[ni][mi] * sv + bv : acc[ni][mi] + bv;
       f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       *reinterpret_cast<f16x4*>(so + ml * OPITCH + nl * 2) = h;
     }
@@ -855,6 +889,125 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
 
 void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out);
 
+// ---- fp8 operand path -------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+static int launch_igemm_f8(const IgemmArgs& a, hipStream_t st) {
+  const LoGeom& g = a.g;
+  static char name[64];
+  snprintf(name, sizeof(name), "lo_igemm_nt<%d,%d,128>/fp8", BM, BN);
+  LoProfScope _p(name, geom_flops(g), 0.5 * geom_bytes(g) + (double)g.B * g.Hout * g.Wout * g.Cout, st);
+  dim3 grid(((a.M + BM - 1) / BM) * (g.Cout / BN) * g.n_phase);
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);
+  hipLaunchKernelGGL((lo_igemm_nt<BM, BN, 128, NSTAGE, false, true>), grid, dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("igemm_f8");
+  return LO_OK;
+}
+bool lo_conv_f8_applies(const LoGeom& g) {
+  return g.Cin % 128 == 0 && g.Cout % 64 == 0 && lo_conv3_tiles_per_image(g, false) == 0;
+}
+// Same op as lo_conv_run with both operands in e4m3: in8 = fp8(activation * LO_F8_ACT_SCALE) in the fp16 tensor's layout,
+// w8 / wscale from lo_pack_f8_all.  Output, bias, residual add and GroupNorm partials as in the fp16 path (same tiles, so
+// lo_conv_mt(g) rows of partials).
+int lo_conv_run_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, const f16* add_src,
+                   f16* out, float* gn_partial, hipStream_t st) {
+  LO_REQUIRE(lo_conv_f8_applies(g), "lo_conv_run_f8: geometry not supported (Cin %% 128, Cout %% 64)");
+  IgemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = reinterpret_cast<const f16*>(in8); a.w = reinterpret_cast<const f16*>(w8); a.f8_scale = wscale;
+  a.bias = bias; a.add_src = add_src; a.out = out; a.gn_partial = gn_partial;
+  a.g = g;
+  a.M = g.B * g.GH * g.GW;
+  a.nsplit = 1;
+  int ksteps = 0;
+  for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / 128) > ksteps ? g.T[p] * (g.Cin / 128) : ksteps;
+  a.ksteps_per_split = ksteps;
+  int bm, bn;
+  lo_conv_pick_tile(g, &bm, &bn);
+  if (gn_partial) {
+    LO_REQUIRE((g.GH * g.GW) % bm == 0 && a.M % bm == 0, "lo_conv_run_f8: GN partials need whole tiles per sample");
+    LO_REQUIRE((g.Cout >> 3) <= bn, "lo_conv_run_f8: GroupNorm group wider than the N tile");
+  }
+  if (bm == 128 && bn == 128) return launch_igemm_f8<128, 128>(a, st);
+  if (bm == 128 && bn == 64) return launch_igemm_f8<128, 64>(a, st);
+  if (bm == 64 && bn == 128) return launch_igemm_f8<64, 128>(a, st);
+  if (bm == 64 && bn == 64) return launch_igemm_f8<64, 64>(a, st);
+  lo_set_error("lo_conv_run_f8: no kernel for tile %dx%d", bm, bn);
+  return LO_ERR_ARG;
+}
+
+// fp16 packed weights -> e4m3 with one scale per (phase, output channel) row: scale = amax / 448 (1 for an all-zero row);
+// wscale = scale / LO_F8_ACT_SCALE is what the conv epilogue multiplies by.  One workgroup per row; all layers of a model in
+// one launch (job table in device memory, like lo_pack_all).
+__device__ __forceinline__ void lo_pack_f8_row(const LoPackF8Job& J, int row) {   // row = phase * Cout + n
+  __shared__ float s_red[4];
+  const int p = row / J.Cout, n = row - p * J.Cout;
+  const int K = J.K[p];
+  const size_t o = (size_t)J.wofs[p] + (size_t)n * K;
+  const f16* src = J.src + o;
+  const int tid = threadIdx.x;
+  float amax = 0.f;
+  for (int k = tid * 8; k < K; k += 256 * 8) {
+    f16x8 v = *reinterpret_cast<const f16x8*>(src + k);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf((float)v[q]));
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
+  if ((tid & 63) == 0) s_red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const float scale = amax > 0.f ? amax * (1.0f / LO_F8_MAX) : 1.0f;
+  const float inv = 1.0f / scale;
+  for (int k = tid * 8; k < K; k += 256 * 8) {
+    f16x8 v = *reinterpret_cast<const f16x8*>(src + k);
+    u32x2 q = {lo_pack4_fp8((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
+               lo_pack4_fp8((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv)};
+    *reinterpret_cast<u32x2*>(J.dst + o + k) = q;
+  }
+  if (tid == 0) J.scale[row] = scale * (1.0f / LO_F8_ACT_SCALE);
+}
+__global__ __launch_bounds__(256) void lo_pack_f8_kernel(const LoPackF8Job* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
+  lo_pack_f8_row(jobs[j], (int)blockIdx.x - jobs[j].block0);
+}
+__global__ __launch_bounds__(256) void lo_pack_f8_one_kernel(LoPackF8Job J) { lo_pack_f8_row(J, (int)blockIdx.x); }
+int lo_pack_f8_one(const LoGeom& g, const f16* wp, uint8_t* w8, float* wscale, hipStream_t st) {
+  LoPackF8Job j;
+  lo_pack_f8_job(&j, g, wp, w8, wscale, 0);
+  hipLaunchKernelGGL(lo_pack_f8_one_kernel, dim3(g.n_phase * g.Cout), dim3(256), 0, st, j);
+  LO_LAUNCH_CHECK("pack_f8_one");
+  return LO_OK;
+}
+// x8 = e4m3(x * LO_F8_ACT_SCALE), saturating (stand-alone form of what the GroupNorm forward emits in fp8 mode)
+__global__ __launch_bounds__(256) void lo_quantize_f8_kernel(const f16* __restrict__ x, uint8_t* __restrict__ x8, size_t n) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    f16x4 v = *reinterpret_cast<const f16x4*>(x + i);
+    *reinterpret_cast<uint32_t*>(x8 + i) = lo_pack4_fp8((float)v[0] * LO_F8_ACT_SCALE, (float)v[1] * LO_F8_ACT_SCALE,
+                                                       (float)v[2] * LO_F8_ACT_SCALE, (float)v[3] * LO_F8_ACT_SCALE);
+  }
+}
+int lo_quantize_f8(const f16* x, uint8_t* x8, size_t n, hipStream_t st) {
+  LO_REQUIRE(n % 4 == 0, "lo_quantize_f8: element count must be a multiple of 4");
+  hipLaunchKernelGGL(lo_quantize_f8_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, x8, n);
+  LO_LAUNCH_CHECK("quantize_f8");
+  return LO_OK;
+}
+void lo_pack_f8_job(LoPackF8Job* j, const LoGeom& g, const f16* src, uint8_t* dst, float* scale, int block0) {
+  memset(j, 0, sizeof(*j));
+  j->src = src; j->dst = dst; j->scale = scale; j->Cout = g.Cout; j->n_phase = g.n_phase; j->block0 = block0;
+  for (int p = 0; p < g.n_phase; ++p) { j->K[p] = g.T[p] * g.Cin; j->wofs[p] = g.wofs[p]; }
+}
+int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStream_t st) {
+  if (njobs <= 0) return LO_OK;
+  LoProfScope _p("lo_pack_f8", 0, 0, st);
+  hipLaunchKernelGGL(lo_pack_f8_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  LO_LAUNCH_CHECK("pack_f8");
+  return LO_OK;
+}
+
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb, const LoConvExtra* ex) {
@@ -863,6 +1016,7 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
   a.gb_beta = gb ? gb->beta : nullptr; a.gb_P1 = gb ? gb->P1 : nullptr;
   a.act = ex ? ex->act : 0; a.bn_partial = ex ? ex->bn_partial : nullptr;
+  a.f8_scale = nullptr;
   a.g = g;
   a.M = g.B * g.GH * g.GW;
   a.nsplit = nsplit < 1 ? 1 : nsplit;

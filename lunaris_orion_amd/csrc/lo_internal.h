@@ -13,6 +13,15 @@ struct LoConvExtra { int act; float* bn_partial; };   // teacher epilogue: Leaky
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr,
                 const LoConvExtra* ex = nullptr);
+// fp8 (e4m3) operand path of the forward convs
+struct LoPackF8Job { const f16* src; uint8_t* dst; float* scale; int K[LO_MAX_PHASE]; int wofs[LO_MAX_PHASE]; int Cout, n_phase, block0; };
+bool lo_conv_f8_applies(const LoGeom& g);
+int lo_conv_run_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, const f16* add_src,
+                   f16* out, float* gn_partial, hipStream_t st);
+void lo_pack_f8_job(LoPackF8Job* j, const LoGeom& g, const f16* src, uint8_t* dst, float* scale, int block0);   // blocks: n_phase * Cout
+int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStream_t st);
+int lo_pack_f8_one(const LoGeom& g, const f16* wp, uint8_t* w8, float* wscale, hipStream_t st);
+int lo_quantize_f8(const f16* x, uint8_t* x8, size_t n, hipStream_t st);
 int lo_conv_tile_m(const LoGeom& g);
 int lo_conv_mt(const LoGeom& g);   // GroupNorm partial rows per sample the conv epilogue writes for this geometry
 int lo_conv3_tiles_per_image(const LoGeom& g, bool need_bn = false);
@@ -33,7 +42,7 @@ size_t lo_packed_weight_elems(const LoGeom& g);
 // lo_norm.hip
 int lo_gn_nchunk(int HW, int C);
 int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, const float* beta, const f16* other, f16* y,
-              float* stats, int B, int HW, int C, int mode, hipStream_t st);
+              float* stats, int B, int HW, int C, int mode, hipStream_t st, uint8_t* y8 = nullptr);   // y8: e4m3 copy of y * LO_F8_ACT_SCALE
 int lo_gn_bwd(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
               f16* ds, f16* dv, float* P1, float* P2, float* dgamma, float* dbeta, float* dbias, int B, int HW, int C,
               int mode, float scale, hipStream_t st);
@@ -46,7 +55,7 @@ int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float
                       f16* ds, f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st, int np1 = 0);
 int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st);
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
-int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
+int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st, uint8_t* dst8 = nullptr);
 
 // lo_edge.hip
 int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v, float* gn_partial, int B, hipStream_t st);

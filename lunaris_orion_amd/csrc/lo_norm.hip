@@ -32,6 +32,7 @@ struct GnFwdArgs {
   float* stats;          // [B][8][2] mean, rstd (saved for backward)
   int HW, C, MT, nchunk, mode;
   int dbg_skip;          // timing experiments only: 1 = return after the prologue
+  uint8_t* y8;           // optional e4m3 copy of y * LO_F8_ACT_SCALE (operand of an fp8 conv), same layout
 };
 
 __device__ __forceinline__ void gn_group_stats(const float* partial, int MT, int n, float inv_m, float* s_stat, int tid) {
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
       int rr = r + u * nslot;
       if (rr < rows) {
         f16x8 y;
+        float yf[8];
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
           const lo_f2 hv = {(float)h[u][j], (float)h[u][j + 1]};
@@ -116,8 +118,15 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
           }
           y[j] = (f16)m[0];
           y[j + 1] = (f16)m[1];
+          yf[j] = m[0];
+          yf[j + 1] = m[1];
         }
         *reinterpret_cast<f16x8*>(a.y + base + (size_t)rr * C) = y;
+        if (a.y8) {
+          constexpr float S8 = LO_F8_ACT_SCALE;
+          *reinterpret_cast<u32x2*>(a.y8 + base + (size_t)rr * C) = (u32x2){lo_pack4_fp8(yf[0] * S8, yf[1] * S8, yf[2] * S8, yf[3] * S8),
+                                                                          lo_pack4_fp8(yf[4] * S8, yf[5] * S8, yf[6] * S8, yf[7] * S8)};
+        }
       }
     }
   }
@@ -404,23 +413,30 @@ __global__ void lo_nhwc_to_nchw_f16_kernel(const f16* __restrict__ src, f16* __r
   int n = i / (HW * C);
   dst[i] = src[((size_t)n * HW + hw) * C + c];
 }
-__global__ void lo_nchw_to_nhwc_f16_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int HW, int C, int total) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void lo_nchw_to_nhwc_f16_kernel(const f16* __restrict__ src, f16* __restrict__ dst, uint8_t* __restrict__ dst8, int HW, int C,
+                                           int total) {
+  int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // four adjacent channels of one pixel (C % 4 == 0)
   if (i >= total) return;
   int c = i % C;
   int hw = (i / C) % HW;
   int n = i / (HW * C);
-  dst[i] = src[((size_t)n * C + c) * HW + hw];
+  f16x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = src[((size_t)n * C + c + j) * HW + hw];
+  *reinterpret_cast<f16x4*>(dst + i) = v;
+  if (dst8)
+    *reinterpret_cast<uint32_t*>(dst8 + i) = lo_pack4_fp8((float)v[0] * LO_F8_ACT_SCALE, (float)v[1] * LO_F8_ACT_SCALE,
+                                                         (float)v[2] * LO_F8_ACT_SCALE, (float)v[3] * LO_F8_ACT_SCALE);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, const float* beta, const f16* other,
-              f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st) {
+              f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st, uint8_t* y8) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_fwd: C=%d unsupported", C);
   static const int dbg_skip = getenv("LO_GN_SKIP_STREAM") ? 1 : 0;
-  GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode, dbg_skip};
+  GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode, dbg_skip, y8};
   LoProfScope _p("lo_gn_fwd", 0, 2.0 * B * HW * C * (mode ? 3 : 2), st);
   hipLaunchKernelGGL(lo_gn_fwd_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("gn_fwd");
@@ -474,10 +490,11 @@ int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStrea
   LO_LAUNCH_CHECK("nhwc_to_nchw");
   return LO_OK;
 }
-int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
+int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st, uint8_t* dst8) {
   int total = B * HW * C;
+  LO_REQUIRE(C % 4 == 0, "lo_nchw_to_nhwc_f16: C=%d must be a multiple of 4", C);
   LoProfScope _p("lo_layout_transpose", 0, 4.0 * total, st);
-  hipLaunchKernelGGL(lo_nchw_to_nhwc_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, HW, C, total);
+  hipLaunchKernelGGL(lo_nchw_to_nhwc_f16_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, st, src, dst, dst8, HW, C, total);
   LO_LAUNCH_CHECK("nchw_to_nhwc");
   return LO_OK;
 }

@@ -135,9 +135,9 @@ class Decoder(nn.Module):
 class _Engine:
     """Native plan + workspace for one (batch, latent_dim, device)."""
 
-    def __init__(self, batch: int, latent_dim: int, device: torch.device):
+    def __init__(self, batch: int, latent_dim: int, device: torch.device, flags: int = 0):
         self.handle = C.c_void_p()
-        _lib.check(_lib.lib.lo_vae_create(batch, latent_dim, C.byref(self.handle)), "lo_vae_create")
+        _lib.check(_lib.lib.lo_vae_create_ex(batch, latent_dim, flags, C.byref(self.handle)), "lo_vae_create_ex")
         self.batch, self.latent_dim, self.device = batch, latent_dim, device
         self.ws = torch.empty(_lib.lib.lo_vae_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
         self.packed_version = -1
@@ -177,8 +177,15 @@ class _VAEFunction(torch.autograd.Function):
 class LunarisCoreVAE(nn.Module):
     """Variational auto-encoder for 128x128 pixel art; see the module docstring for the drop-in contract."""
 
-    def __init__(self, latent_dim: int = 256):
+    #: operand formats of the forward convolutions: "fp16" (default; the parity-tested path) or "fp8" (BASELINE config 5:
+    #: OCP e4m3 operands where the input channel count is a multiple of 128, fp16 backward; see include/lunaris_hip.h)
+    MFMA_PRECISIONS = {"fp16": 0, "fp8": 1}
+
+    def __init__(self, latent_dim: int = 256, mfma_precision: str = "fp16"):
         super().__init__()
+        if mfma_precision not in self.MFMA_PRECISIONS:
+            raise ValueError(f"mfma_precision must be one of {sorted(self.MFMA_PRECISIONS)}, got {mfma_precision!r}")
+        self.mfma_precision = mfma_precision
         self.latent_dim = latent_dim
         self.encoder = Encoder(latent_dim=latent_dim)
         self.decoder = Decoder(latent_dim=latent_dim)
@@ -246,7 +253,7 @@ class LunarisCoreVAE(nn.Module):
         key = (batch, str(self._flat.device))
         eng = self._engines.get(key)
         if eng is None:
-            eng = _Engine(batch, self.latent_dim, self._flat.device)
+            eng = _Engine(batch, self.latent_dim, self._flat.device, self.MFMA_PRECISIONS[self.mfma_precision])
             self._engines[key] = eng
         if eng.packed_version != self._weights_version:
             _lib.check(_lib.lib.lo_vae_pack(eng.handle, self._flat.data_ptr(), eng.ws.data_ptr(), _lib.stream_ptr()), "lo_vae_pack")

@@ -28,6 +28,7 @@ def test_cli_flags_and_defaults_match_reference():
         assert getattr(args, k) == v, k
     assert len(REFERENCE_DEFAULTS) + 1 == 35      # + data_dir
     assert args.generate_samples == 0 and args.max_steps == 0 and not args.vae_only      # additions default to off
+    assert args.mfma_precision == "fp16"
 
 
 def test_unsupported_feature_dim_is_refused_loudly(tmp_path):

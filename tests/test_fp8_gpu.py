@@ -1,0 +1,186 @@
+"""BASELINE config 5: the e4m3 operand path of the forward convolutions (LO_VAE_FP8_FWD / mfma_precision="fp8").
+
+Three levels:
+  * the quantisers (activation: fp8(8 x), weights: one scale per output channel) against torch.float8_e4m3fn;
+  * the fp8 igemm against the parity-tested fp16 igemm run on the DEQUANTISED operands (same products, fp32 accumulation:
+    only the accumulation order and one fp16 rounding of the dequantised weight differ), and against the fp32 convolution of
+    the unquantised operands (the quantisation error itself, stated below);
+  * the whole VAE step in fp8 mode against the fp16 mode and the CPU oracle: loss parity (the check BASELINE.json names).
+Tolerances are measured ones with head-room, stated at each assert.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_ref as R
+from tests.hip_helpers import L as LIB, from_nhwc, h16, sync, to_nhwc_h
+
+pytestmark = pytest.mark.gpu
+KIND_S1, KIND_S2, KIND_T4 = 0, 1, 2
+ACT_SCALE = 8.0
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return h16(torch.randn(*shape, generator=g) * scale)
+
+
+def _decode(u8):
+    return u8.cpu().view(torch.float8_e4m3fn).float()
+
+
+def test_activation_quantiser_matches_torch_e4m3():
+    lib = LIB()
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(4096, generator=g) * 2.0, torch.tensor([0.0, 1e-4, -3e-4, 55.9, 56.0, 57.0, 1000.0, -1000.0])]).half()
+    xd = x.cuda()
+    q = torch.empty(x.numel(), dtype=torch.uint8, device="cuda")
+    lib.check(lib.lib.lo_quantize_act_f8(xd.data_ptr(), q.data_ptr(), x.numel(), lib.stream_ptr()), "quantize")
+    sync()
+    want = (x.float() * ACT_SCALE).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    assert torch.equal(_decode(q), want)                       # round-to-nearest-even, saturating, OCP encoding
+
+
+CASES = [
+    # kind, B, Cin, Cout, H
+    (KIND_S1, 2, 128, 128, 32),
+    (KIND_S1, 3, 512, 512, 8),
+    (KIND_S1, 8, 256, 256, 16),
+    (KIND_S2, 2, 128, 256, 32),
+    (KIND_S2, 2, 256, 512, 16),
+    (KIND_T4, 2, 512, 256, 8),
+    (KIND_T4, 4, 128, 64, 32),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H", CASES)
+def test_fp8_conv_matches_fp16_kernel_on_dequantised_operands(kind, B, Cin, Cout, H):
+    lib = LIB()
+    x = F.mish(_rand(B, Cin, H, H, seed=1))                                    # what these convs read: Mish outputs
+    x = h16(x)
+    if kind == KIND_T4:
+        w = _rand(Cin, Cout, 4, 4, seed=2, scale=(Cin * 4) ** -0.5)
+        ref32 = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+        Ho = 2 * H
+    else:
+        w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+        ref32 = F.conv2d(x, w, None, stride=1 if kind == KIND_S1 else 2, padding=1)
+        Ho = H if kind == KIND_S1 else H // 2
+    bias = _rand(Cout, seed=3, scale=0.1)
+    ref32 = ref32 + bias.view(1, -1, 1, 1)
+    xin = to_nhwc_h(x)
+    n = lib.lib.lo_packed_weight_elems_for(kind, B, H, H, Cin, Cout)
+    wp = torch.empty(n, dtype=torch.float16, device="cuda")
+    lib.check(lib.lib.lo_pack_weight_for(kind, B, H, H, Cin, Cout, w.contiguous().cuda().data_ptr(), wp.data_ptr(), lib.stream_ptr()), "pack")
+    nph = 4 if kind == KIND_T4 else 1
+    x8 = torch.empty(xin.numel(), dtype=torch.uint8, device="cuda")
+    w8 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ws = torch.full((nph * Cout,), float("nan"), dtype=torch.float32, device="cuda")
+    lib.check(lib.lib.lo_quantize_act_f8(xin.data_ptr(), x8.data_ptr(), xin.numel(), lib.stream_ptr()), "quantize")
+    lib.check(lib.lib.lo_pack_weight_f8_for(kind, B, H, H, Cin, Cout, wp.data_ptr(), w8.data_ptr(), ws.data_ptr(), lib.stream_ptr()), "pack8")
+    out8 = torch.full((B, Ho, Ho, Cout), float("nan"), dtype=torch.float16, device="cuda")
+    part = torch.full((B * 4096 * 16,), float("nan"), dtype=torch.float32, device="cuda")
+    mt = C.c_int(0)
+    bd = bias.cuda()
+    lib.check(lib.lib.lo_conv_forward_f8(kind, B, H, H, Cin, Cout, x8.data_ptr(), w8.data_ptr(), ws.data_ptr(), bd.data_ptr(), None,
+                                         out8.data_ptr(), part.data_ptr(), C.byref(mt), lib.stream_ptr()), "conv_f8")
+    sync()
+    # ---- the weight quantiser: every (phase, channel) row uses the full e4m3 range and stays within half an ulp (2^-4 relative)
+    K = n // (nph * Cout)
+    wq = _decode(w8).view(nph * Cout, K)
+    scale = ws.cpu() * ACT_SCALE                                                 # amax / 448
+    wrow = wp.cpu().float().view(nph * Cout, K)
+    assert torch.allclose(wq.abs().amax(dim=1), torch.full((nph * Cout,), 448.0))
+    assert torch.allclose(scale, wrow.abs().amax(dim=1) / 448.0, rtol=1e-6)
+    deq = wq * scale[:, None]
+    assert ((deq - wrow).abs() <= wrow.abs() * 2.0 ** -4 + scale[:, None] * 2.0 ** -10 + 1e-12).all()
+    # ---- the conv: the fp16 kernel on the dequantised operands multiplies the same numbers
+    xdq = (_decode(x8) / ACT_SCALE).half().view_as(xin).cuda()                   # exact in fp16
+    wdq = deq.half().view(-1).cuda()
+    out16 = torch.full((B, Ho, Ho, Cout), float("nan"), dtype=torch.float16, device="cuda")
+    lib.check(lib.lib.lo_conv_forward(kind, B, H, H, Cin, Cout, xdq.data_ptr(), wdq.data_ptr(), bd.data_ptr(), None, out16.data_ptr(),
+                                      None, None, lib.stream_ptr()), "conv_f16")
+    sync()
+    got, ref = from_nhwc(out8), from_nhwc(out16)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-3 * max(1.0, ref.abs().max().item()), err
+    # GroupNorm partial sums of the stored output
+    G = Cout // 8
+    tot = part[: B * mt.value * 16].view(B, mt.value, 8, 2).double().sum(dim=1).cpu()
+    g5 = got.double().view(B, 8, G, -1)
+    assert torch.allclose(tot[:, :, 0], g5.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, :, 1], (g5 * g5).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    # ---- the quantisation error itself against the fp32 conv of the unquantised operands: e4m3 keeps 4 significant bits
+    # (relative step 2^-3, rounding error <= 2^-4) on both operands; over K >= 1152 products the errors average out
+    rel = ((got - ref32).norm() / ref32.norm()).item()
+    print(f"kind {kind} Cin {Cin}: fp8 vs fp32 relative L2 error {rel:.4f}")
+    assert rel <= 6e-2, rel
+
+
+def _vae(L, precision):
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    m = LunarisCoreVAE(latent_dim=L, mfma_precision=precision)
+    m.load_state_dict(R.closed_form_params(L, 0))
+    return m.to("cuda")
+
+
+def test_fp8_mode_loss_parity_with_the_fp16_mode_and_the_oracle():
+    """Forward in fp8 mode vs fp16 mode vs the fp32 CPU oracle (B=2, latent 256), then three optimizer steps of both modes."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    eps = R.closed_form_eps(B, L, salt=0)
+    P = R.closed_form_params(L, 0)
+    r_ref, mu_ref, lv_ref = R.vae_forward(x, eps, P)
+    rl_ref, kl_ref = R.vae_losses(r_ref, x, mu_ref, lv_ref)
+    outs = {}
+    for prec in ("fp16", "fp8"):
+        m = _vae(L, prec)
+        with torch.no_grad():
+            recon, mu, logvar = m(x.cuda(), eps.cuda())
+        torch.cuda.synchronize()
+        outs[prec] = (recon.cpu(), mu.cpu(), logvar.cpu())
+    r8, mu8, lv8 = outs["fp8"]
+    r16, mu16, lv16 = outs["fp16"]
+    assert not torch.equal(mu8, mu16)                      # the mode really changes the arithmetic
+    rl8, kl8 = R.vae_losses(r8, x, mu8, lv8)
+    rl16, kl16 = R.vae_losses(r16, x, mu16, lv16)
+    print("fp8 vs fp16: d recon_loss", abs(rl8.item() - rl16.item()), "d kl", abs(kl8.item() - kl16.item()),
+          "max|dmu|", (mu8 - mu16).abs().max().item(), "max|dlogvar|", (lv8 - lv16).abs().max().item(),
+          "max|drecon|", (r8 - r16).abs().max().item())
+    print("fp8 vs oracle: d recon_loss", abs(rl8.item() - rl_ref.item()), "d kl", abs(kl8.item() - kl_ref.item()))
+    # stated fp8 tolerances (measured on MI355X: d recon_loss 1.1e-3, d kl 1.2e-4, max|dmu| 0.14, max|dlogvar| 0.13,
+    # max|drecon| 0.08 - e4m3 keeps 4 significant bits): losses 3e-3 abs, mu / logvar 0.25 abs, recon 0.15 abs
+    assert abs(rl8.item() - rl16.item()) <= 3e-3 and abs(kl8.item() - kl16.item()) <= 3e-3
+    assert abs(rl8.item() - rl_ref.item()) <= 3e-3 and abs(kl8.item() - kl_ref.item()) <= 3e-3
+    assert (mu8 - mu16).abs().max().item() <= 0.25 and (lv8 - lv16).abs().max().item() <= 0.25
+    assert (r8 - r16).abs().max().item() <= 0.15
+    # three steps: same hyper-parameters as the golden trace test
+    traces = {}
+    for prec in ("fp16", "fp8"):
+        m = _vae(L, prec)
+        st = VAEStepper(m, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0, kl_weight=0.1)
+        tr = []
+        for s in range(3):
+            st.step(x.cuda(), batch_idx=s, eps=R.closed_form_eps(B, L, salt=s).cuda())
+            met = st.metrics()
+            assert met["grads_finite"] == 1.0
+            tr.append((met["recon_loss"], met["kl_loss"], met["grad_norm"]))
+        traces[prec] = tr
+    for a, b in zip(traces["fp8"], traces["fp16"]):
+        print("step", a, b)
+        assert abs(a[0] - b[0]) <= 3e-3 and abs(a[1] - b[1]) <= 5e-3      # measured <= 1.2e-3 / 2.0e-3 over the three steps
+        assert abs(a[2] - b[2]) <= 2e-2 * b[2]                              # gradient norm: measured 0.3 %
+
+
+def test_fp8_mode_rejects_unknown_flags_and_names():
+    from lunaris_orion_amd import _lib
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    with pytest.raises(ValueError):
+        LunarisCoreVAE(latent_dim=256, mfma_precision="fp4")
+    h = C.c_void_p()
+    assert _lib.lib.lo_vae_create_ex(2, 256, 0x10, C.byref(h)) != 0
+    assert b"unknown flag" in _lib.lib.lo_last_error()

@@ -73,6 +73,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--vae_only", action="store_true", help="shorthand for --reward_scale 0 --quality_weight 0")
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many micro-batches (0 = no limit)")
     p.add_argument("--generate_samples", type=int, default=0, help="decode this many prior samples to PNG when training ends (lunar_generate.py:278-291)")
+    p.add_argument("--mfma_precision", choices=["fp16", "fp8"], default="fp16",
+                   help="operand format of the VAE's forward convolutions: fp16 (parity-tested default) or fp8 = OCP e4m3 where Cin %% 128 == 0, fp16 backward")
     return p
 
 
@@ -124,7 +126,7 @@ def main(argv=None):
 
     from lunaris_orion_amd.trainer import HybridStepper, VAEStepper
     from lunaris_orion_amd.vae import LunarisCoreVAE
-    vae = LunarisCoreVAE(latent_dim=args.latent_dim).to("cuda")
+    vae = LunarisCoreVAE(latent_dim=args.latent_dim, mfma_precision=args.mfma_precision).to("cuda")
     common = dict(lr=args.vae_lr, min_lr=args.min_lr, scheduler_t0=args.scheduler_t0, weight_decay=args.weight_decay,
                   max_grad_norm=args.max_grad_norm, recon_weight=args.recon_weight, kl_weight=args.kl_weight,
                   gradient_accumulation_steps=args.gradient_accumulation_steps, grad_sync=grad_sync)
