@@ -173,21 +173,32 @@ __device__ __forceinline__ void gn_du2(int mode, lo_f2 hv, lo_f2 dyv, lo_f2 ov, 
   }
 }
 
+// RES: the mode is a template parameter so that the PLAIN / SKIP launches (13 of 16 per step) do not carry the registers of
+// the identity operand and of the second Mish (occupancy: these kernels are latency-bound streams of 64 elements per thread)
+// G4: C = 32 (4 channels per group, two groups inside a thread's 8-channel chunk); otherwise the chunk lies in ONE group and the
+// per-group factors (rstd, -mean*rstd, the two correction terms) are scalars instead of 8-element arrays
+template <bool RES, bool G4>
 __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
+  const int a_mode = RES ? GN_MODE_RES : GN_MODE_PLAIN;
+  constexpr int NG = G4 ? 2 : 1;
   __shared__ float s_red[256 * 16];
   const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
   const int C = a.C, G = C >> 3, CC = C >> 3;
   const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
   const int c0 = cc * 8;
-  float sc[8], sh[8], nmr[8], rstd[8];
+  float sc[8], sh[8], nmr[NG], rstd[NG];
+#pragma unroll
+  for (int q = 0; q < NG; ++q) {
+    int grp = (c0 + 4 * q) / G;
+    const float mean = a.stats[n * 16 + grp * 2];
+    rstd[q] = a.stats[n * 16 + grp * 2 + 1];
+    nmr[q] = -mean * rstd[q];
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    int grp = (c0 + j) / G;
-    const float mean = a.stats[n * 16 + grp * 2];
-    rstd[j] = a.stats[n * 16 + grp * 2 + 1];
-    nmr[j] = -mean * rstd[j];
-    sc[j] = a.gamma[c0 + j] * rstd[j];
-    sh[j] = a.beta[c0 + j] - mean * sc[j];
+    const int q = G4 ? (j >> 2) : 0;
+    sc[j] = a.gamma[c0 + j] * rstd[q];
+    sh[j] = a.beta[c0 + j] + nmr[q] * a.gamma[c0 + j];     // beta - mean * gamma * rstd
   }
   lo_f2 a1[4], a2[4];
 #pragma unroll
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;
   for (int r = slot; r < rows; r += U * nslot) {
-    f16x8 h[U], d[U], o[U];
+    f16x8 h[U], d[U], o[RES ? U : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int rr = r + u * nslot;
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
         size_t off = base + (size_t)rr * C;
         h[u] = *reinterpret_cast<const f16x8*>(a.v + off);
         d[u] = *reinterpret_cast<const f16x8*>(a.dy + off);
-        if (a.mode == GN_MODE_RES) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
+        if constexpr (RES) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
       }
     }
 #pragma unroll
@@ -215,15 +226,17 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
           lo_f2 du, xh, dsv;
-          const lo_f2 ov = a.mode == GN_MODE_RES ? (lo_f2){(float)o[u][j], (float)o[u][j + 1]} : (lo_f2){0.f, 0.f};
-          gn_du2(a.mode, (lo_f2){(float)h[u][j], (float)h[u][j + 1]}, (lo_f2){(float)d[u][j], (float)d[u][j + 1]}, ov,
-                 (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[j], rstd[j + 1]}, (lo_f2){nmr[j], nmr[j + 1]}, du, xh, dsv);
+          lo_f2 ov = {0.f, 0.f};
+          if constexpr (RES) ov = (lo_f2){(float)o[u][j], (float)o[u][j + 1]};
+          gn_du2(a_mode, (lo_f2){(float)h[u][j], (float)h[u][j + 1]}, (lo_f2){(float)d[u][j], (float)d[u][j + 1]}, ov,
+                 (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[G4 ? (j >> 2) : 0], rstd[G4 ? (j >> 2) : 0]},
+                 (lo_f2){nmr[G4 ? (j >> 2) : 0], nmr[G4 ? (j >> 2) : 0]}, du, xh, dsv);
           a1[j >> 1] += du;
           a2[j >> 1] += du * xh;
           dso[j] = (f16)dsv[0];
           dso[j + 1] = (f16)dsv[1];
         }
-        if (a.mode == GN_MODE_RES) *reinterpret_cast<f16x8*>(a.ds + base + (size_t)rr * C) = dso;
+        if (RES) *reinterpret_cast<f16x8*>(a.ds + base + (size_t)rr * C) = dso;
       }
     }
   }
@@ -241,7 +254,10 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
   }
 }
 
+template <bool RES, bool G4>
 __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
+  const int a_mode = RES ? GN_MODE_RES : GN_MODE_PLAIN;
+  constexpr int NG = G4 ? 2 : 1;
   __shared__ float s_red[256 * 8];
   __shared__ float s_c[16];       // per group: c1, c2
   __shared__ float s_g[512 * 2];  // per channel gamma-weighted sums (scratch)
@@ -276,30 +292,33 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
   }
   __syncthreads();
   // dv = rstd (gamma du - k1 - xhat k2) = du*ka - kb - xhat*kc
-  float sc[8], sh[8], nmr[8], rstd[8], ka[8], kb[8], kc[8];
+  float sc[8], sh[8], nmr[NG], rstd[NG], kb[NG], kc[NG];     // ka[j] == sc[j] (gamma * rstd)
+#pragma unroll
+  for (int q = 0; q < NG; ++q) {
+    const int grp = (c0 + 4 * q) / G;
+    const bool hi = grp != grp_lo;
+    const float mean = hi ? st_hi[0] : st_lo[0];
+    rstd[q] = hi ? st_hi[1] : st_lo[1];
+    nmr[q] = -mean * rstd[q];
+    kb[q] = rstd[q] * s_c[grp * 2];
+    kc[q] = rstd[q] * s_c[grp * 2 + 1];
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    int grp = (c0 + j) / G;
-    bool hi = grp != grp_lo;
-    const float mean = hi ? st_hi[0] : st_lo[0];
-    rstd[j] = hi ? st_hi[1] : st_lo[1];
+    const int q = G4 ? (j >> 2) : 0;
     const float gm = j < 4 ? gm0[j & 3] : gm1[j & 3];
-    nmr[j] = -mean * rstd[j];
-    sc[j] = gm * rstd[j];
-    sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) - mean * sc[j];
-    ka[j] = rstd[j] * gm;
-    kb[j] = rstd[j] * s_c[grp * 2];
-    kc[j] = rstd[j] * s_c[grp * 2 + 1];
+    sc[j] = gm * rstd[q];
+    sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) + nmr[q] * gm;
   }
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (a.dbg_skip) { if (kb[0] == 12345.f) a.dv[0] = (f16)kc[3]; return; }
+  if (a.dbg_skip) { if (kb[0] == 12345.f) a.dv[0] = (f16)kc[0]; return; }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;
   for (int r = slot; r < rows; r += U * nslot) {
-    f16x8 h[U], d[U], o[U];
+    f16x8 h[U], d[U], o[RES ? U : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int rr = r + u * nslot;
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
         size_t off = base + (size_t)rr * C;
         h[u] = *reinterpret_cast<const f16x8*>(a.v + off);
         d[u] = *reinterpret_cast<const f16x8*>(a.dy + off);
-        if (a.mode == GN_MODE_RES) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
+        if constexpr (RES) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
       }
     }
 #pragma unroll
@@ -318,10 +337,13 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
           lo_f2 du, xh, dsv;
-          const lo_f2 ov = a.mode == GN_MODE_RES ? (lo_f2){(float)o[u][j], (float)o[u][j + 1]} : (lo_f2){0.f, 0.f};
-          gn_du2(a.mode, (lo_f2){(float)h[u][j], (float)h[u][j + 1]}, (lo_f2){(float)d[u][j], (float)d[u][j + 1]}, ov,
-                 (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[j], rstd[j + 1]}, (lo_f2){nmr[j], nmr[j + 1]}, du, xh, dsv);
-          const lo_f2 dv = du * (lo_f2){ka[j], ka[j + 1]} - (lo_f2){kb[j], kb[j + 1]} - xh * (lo_f2){kc[j], kc[j + 1]};
+          lo_f2 ov = {0.f, 0.f};
+          if constexpr (RES) ov = (lo_f2){(float)o[u][j], (float)o[u][j + 1]};
+          gn_du2(a_mode, (lo_f2){(float)h[u][j], (float)h[u][j + 1]}, (lo_f2){(float)d[u][j], (float)d[u][j + 1]}, ov,
+                 (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[G4 ? (j >> 2) : 0], rstd[G4 ? (j >> 2) : 0]},
+                 (lo_f2){nmr[G4 ? (j >> 2) : 0], nmr[G4 ? (j >> 2) : 0]}, du, xh, dsv);
+          const int q = G4 ? (j >> 2) : 0;
+          const lo_f2 dv = du * (lo_f2){sc[j], sc[j + 1]} - (lo_f2){kb[q], kb[q]} - xh * (lo_f2){kc[q], kc[q]};
           const f16 d0 = (f16)dv[0], d1 = (f16)dv[1];
           out[j] = d0;
           out[j + 1] = d1;
@@ -432,12 +454,27 @@ __global__ void lo_nchw_to_nhwc_f16_kernel(const f16* __restrict__ src, f16* __r
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+// profiler name of a launch: the kernel name, or "<kernel> C<channels> HW<pixels> m<mode>" under LO_PROF_LAYERS
+static const char* gn_layer_name(const char* base, int C, int HW, int mode) {
+  static const bool per_layer = getenv("LO_PROF_LAYERS") != nullptr;
+  if (!per_layer || !g_lo_prof_on) return base;
+  struct Entry { const char* base; int C, HW, mode; char text[56]; };
+  static Entry table[96];             // one stable string per distinct (kernel, shape, mode): the profiler keeps the pointer
+  static int used = 0;
+  for (int i = 0; i < used; ++i)
+    if (table[i].base == base && table[i].C == C && table[i].HW == HW && table[i].mode == mode) return table[i].text;
+  if (used == 96) return base;
+  Entry& e = table[used++];
+  e.base = base; e.C = C; e.HW = HW; e.mode = mode;
+  snprintf(e.text, sizeof(e.text), "%s C%d HW%d m%d", base, C, HW, mode);
+  return e.text;
+}
 int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, const float* beta, const f16* other,
               f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st, uint8_t* y8) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_fwd: C=%d unsupported", C);
   static const int dbg_skip = getenv("LO_GN_SKIP_STREAM") ? 1 : 0;
   GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode, dbg_skip, y8};
-  LoProfScope _p("lo_gn_fwd", 0, 2.0 * B * HW * C * (mode ? 3 : 2), st);
+  LoProfScope _p(gn_layer_name("lo_gn_fwd", C, HW, mode), 0, 2.0 * B * HW * C * (mode ? 3 : 2), st);
   hipLaunchKernelGGL(lo_gn_fwd_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("gn_fwd");
   return LO_OK;
@@ -450,13 +487,27 @@ int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float
   GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, lo_gn_nchunk(HW, C), mode, 0, dbg_skip};
   a.np1 = np1 > 0 ? np1 : a.nchunk;
   if (np1 == 0) {
-    LoProfScope _p("lo_gn_bwd_reduce", 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 2), st);
-    hipLaunchKernelGGL(lo_gn_bwd_reduce_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+    LoProfScope _p(gn_layer_name("lo_gn_bwd_reduce", C, HW, mode), 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 2), st);
+    const bool g4 = C == 32;
+    if (mode == GN_MODE_RES) {
+      if (g4) hipLaunchKernelGGL((lo_gn_bwd_reduce_kernel<true, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((lo_gn_bwd_reduce_kernel<true, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+    } else {
+      if (g4) hipLaunchKernelGGL((lo_gn_bwd_reduce_kernel<false, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((lo_gn_bwd_reduce_kernel<false, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+    }
   }
   LO_LAUNCH_CHECK("gn_bwd_reduce");
   {
-    LoProfScope _p("lo_gn_bwd_apply", 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 3), st);
-    hipLaunchKernelGGL(lo_gn_bwd_apply_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+    LoProfScope _p(gn_layer_name("lo_gn_bwd_apply", C, HW, mode), 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 3), st);
+    const bool g4 = C == 32;
+    if (mode == GN_MODE_RES) {
+      if (g4) hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<true, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<true, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+    } else {
+      if (g4) hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<false, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<false, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+    }
   }
   LO_LAUNCH_CHECK("gn_bwd_apply");
   return LO_OK;
