@@ -15,7 +15,10 @@ enum { GN_MODE_PLAIN = 0, GN_MODE_SKIP = 1, GN_MODE_RES = 2 };
 
 int lo_gn_nchunk(int HW, int C) {
   static const long chunk_elems = getenv("LO_GN_CHUNK_ELEMS") ? atol(getenv("LO_GN_CHUNK_ELEMS")) : 16384;
-  long e = (long)HW * C / chunk_elems;
+  // the 128x128-resolution layer (32 channels): twice the chunk halves the partial rows its backward apply pass re-reads
+  // per workgroup (measured 50 -> 41 us; neutral for its other two passes, worse for every smaller layer)
+  const long ce = (long)HW * C >= 524288 ? 2 * chunk_elems : chunk_elems;
+  long e = (long)HW * C / ce;
   if (e < 1) e = 1;
   if (e > 256) e = 256;
   while (HW % e) --e;
@@ -60,6 +63,7 @@ __device__ __forceinline__ void gn_group_stats(const float* partial, int MT, int
   }
 }
 
+template <int MODE>   // the mode as a template parameter: the PLAIN launches do not carry the second operand's registers
 __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
   __shared__ float s_stat[16];
   const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
@@ -92,14 +96,14 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;   // rows in flight per thread (memory-level parallelism)
   for (int r = slot; r < rows; r += U * nslot) {
-    f16x8 h[U], o[U];
+    f16x8 h[U], o[MODE != GN_MODE_PLAIN ? U : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int rr = r + u * nslot;
       if (rr < rows) {
         size_t off = base + (size_t)rr * C;
         h[u] = *reinterpret_cast<const f16x8*>(a.v + off);
-        if (a.mode != GN_MODE_PLAIN) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
+        if constexpr (MODE != GN_MODE_PLAIN) o[u] = *reinterpret_cast<const f16x8*>(a.other + off);
       }
     }
 #pragma unroll
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
         for (int j = 0; j < 8; j += 2) {
           const lo_f2 hv = {(float)h[u][j], (float)h[u][j + 1]};
           lo_f2 m = lo_mish2(hv * (lo_f2){sc[j], sc[j + 1]} + (lo_f2){sh[j], sh[j + 1]});
-          if (a.mode != GN_MODE_PLAIN) {
+          if constexpr (MODE != GN_MODE_PLAIN) {
             const lo_f2 ov = {(float)o[u][j], (float)o[u][j + 1]};
-            m = a.mode == GN_MODE_SKIP ? m + ov : lo_mish2(m + ov);
+            m = MODE == GN_MODE_SKIP ? m + ov : lo_mish2(m + ov);
           }
           y[j] = (f16)m[0];
           y[j + 1] = (f16)m[1];
@@ -475,7 +479,9 @@ int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, co
   static const int dbg_skip = getenv("LO_GN_SKIP_STREAM") ? 1 : 0;
   GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode, dbg_skip, y8};
   LoProfScope _p(gn_layer_name("lo_gn_fwd", C, HW, mode), 0, 2.0 * B * HW * C * (mode ? 3 : 2), st);
-  hipLaunchKernelGGL(lo_gn_fwd_kernel, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  if (mode == GN_MODE_PLAIN) hipLaunchKernelGGL(lo_gn_fwd_kernel<GN_MODE_PLAIN>, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  else if (mode == GN_MODE_SKIP) hipLaunchKernelGGL(lo_gn_fwd_kernel<GN_MODE_SKIP>, dim3(a.nchunk, B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(lo_gn_fwd_kernel<GN_MODE_RES>, dim3(a.nchunk, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("gn_fwd");
   return LO_OK;
 }
