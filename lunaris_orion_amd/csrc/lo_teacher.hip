@@ -64,19 +64,22 @@ __global__ __launch_bounds__(256) void lo_t_conv1_kernel(const float* __restrict
   f16* dst = out + (((size_t)n * 128 + oy) * 128 + px) * 32 + cg * 16;
   *reinterpret_cast<f16x8*>(dst) = h0;
   *reinterpret_cast<f16x8*>(dst + 8) = h1;
-  // per-channel sums over the 128 pixels of this row: 16 rounds of a block reduction (channel j of each half)
+  // per-channel sums over the 128 pixels of this row: butterfly over the 32 pixels of a wave (lanes of equal channel half),
+  // then the four waves in a fixed order (was: 16 block-wide rounds with 4 active threads each)
   float* dstp = bn_partial + ((size_t)n * 128 + oy) * 32 * 2;
+  float (*red2)[2][16][2] = reinterpret_cast<float (*)[2][16][2]>(&red[0][0]);   // [wave][half][channel][sum, sumsq]
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
   for (int j = 0; j < 16; ++j) {
-    red[tid][0] = vals[j];
-    red[tid][1] = vals[j] * vals[j];
-    __syncthreads();
-    if (tid < 4) {                       // (cg, which)
-      int c2 = tid >> 1, which = tid & 1;
-      float t = 0.f;
-      for (int p = 0; p < 128; ++p) t += red[p * 2 + c2][which];
-      dstp[(c2 * 16 + j) * 2 + which] = t;
-    }
-    __syncthreads();
+    float s1 = vals[j], s2 = vals[j] * vals[j];
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane < 2) { red2[wave][lane][j][0] = s1; red2[wave][lane][j][1] = s2; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int c2 = tid >> 5, j = (tid >> 1) & 15, which = tid & 1;
+    dstp[(c2 * 16 + j) * 2 + which] = ((red2[0][c2][j][which] + red2[1][c2][j][which]) + red2[2][c2][j][which]) + red2[3][c2][j][which];
   }
 }
 
@@ -263,39 +266,81 @@ __global__ void lo_pool_finalize_kernel(const float* __restrict__ partial, float
 // depthwise KxK conv (groups = 32) on BN(raw1): out[pix][c] = bias[c] + sum_taps w[c][tap] * (raw1[pix+tap][c]*scale[c]+shift[c])
 // (zero padding applies to the normalised tensor).  thread = (pixel, 8-channel chunk)
 // ---------------------------------------------------------------------------------------------
+// Workgroup = a 16 x 32 pixel tile of one image, all 32 channels.  The normalised input tile with its halo is staged ONCE in
+// LDS as fp16 ([row][col][32 ch], BatchNorm applied while staging, zeros outside the image: the padding of the normalised
+// tensor), so a tap costs one fma instead of convert + normalise + fma.  Thread = (column, 8-channel chunk, 8-row half): a
+// wave's 16-byte LDS reads are 1 KiB contiguous (16 pixels x 4 chunks), each loaded input value feeds up to K output rows
+// from registers.  fp32 accumulation.  (Was: thread = pixel x chunk reading every tap from global: 87 us per launch.)
 template <int K>
 __global__ __launch_bounds__(256) void lo_t_dwconv_kernel(const f16* __restrict__ raw, const float* __restrict__ ss,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           f16* __restrict__ out, int B) {
-  __shared__ float ws[K * K][32];
+  constexpr int TR = 16, TC = 32, HR = TR + K - 1, HC = TC + K - 1, P = K / 2;
+  __shared__ __attribute__((aligned(16))) f16 tile[HR * HC * 32];
+  __shared__ __attribute__((aligned(16))) float ws[K * K][32];
   const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int ty0 = (blockIdx.x >> 2) * TR, tx0 = (blockIdx.x & 3) * TC;   // 8 x 4 tiles per 128 x 128 image
   for (int i = tid; i < K * K * 32; i += 256) ws[i / 32][i % 32] = w[(i % 32) * K * K + i / 32];
-  __syncthreads();
-  const size_t gid = (size_t)blockIdx.x * 256 + tid;
-  const size_t pix = gid >> 2;
-  const int c0 = (int)(gid & 3) * 8;
-  if (pix >= (size_t)B * T_HW) return;
-  const int n = (int)(pix >> 14), p = (int)(pix & 16383), y = p >> 7, x = p & 127;
-  float sc[8], sh[8], acc[8];
+  {
+    const int cc = tid & 3;
+    float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = ss[(c0 + j) * 2]; sh[j] = ss[(c0 + j) * 2 + 1]; acc[j] = bias[c0 + j]; }
-#pragma unroll 1
-  for (int r = 0; r < K; ++r) {
-    int iy = y + r - K / 2;
-    if ((unsigned)iy >= 128u) continue;
+    for (int j = 0; j < 8; ++j) { sc[j] = ss[(cc * 8 + j) * 2]; sh[j] = ss[(cc * 8 + j) * 2 + 1]; }
+    for (int q = tid >> 2; q < HR * HC; q += 64) {
+      const int r = q / HC, c = q - r * HC;
+      const int iy = ty0 + r - P, ix = tx0 + c - P;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if ((unsigned)iy < 128u && (unsigned)ix < 128u) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(raw + (((size_t)n * 128 + iy) * 128 + ix) * 32 + cc * 8);
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      int ix = x + s - K / 2;
-      if ((unsigned)ix >= 128u) continue;
-      f16x8 h = *reinterpret_cast<const f16x8*>(raw + (((size_t)n * 128 + iy) * 128 + ix) * 32 + c0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += ws[r * K + s][c0 + j] * ((float)h[j] * sc[j] + sh[j]);
+        for (int j = 0; j < 8; ++j) v[j] = (f16)((float)h[j] * sc[j] + sh[j]);
+      }
+      *reinterpret_cast<f16x8*>(tile + q * 32 + cc * 8) = v;
     }
   }
-  f16x8 o;
+  __syncthreads();
+  const int cc = tid & 3, col = (tid >> 2) & 31, half = tid >> 7;   // rows half*8 .. half*8+7 of the tile
+  const int c0 = cc * 8;
+  float acc[8][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
-  *reinterpret_cast<f16x8*>(out + pix * 32 + c0) = o;
+  for (int j = 0; j < 8; ++j) {
+    const float b = bias[c0 + j];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r][j] = b;
+  }
+#pragma unroll 1
+  for (int s = 0; s < K; ++s) {   // one tap column at a time (not unrolled: 64 accumulators + K x 8 weights already fill the budget)
+    float wv[K][8];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&ws[r * K + s][c0]), w1 = *reinterpret_cast<const f32x4*>(&ws[r * K + s][c0 + 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wv[r][j] = w0[j]; wv[r][4 + j] = w1[j]; }
+    }
+#pragma unroll
+    for (int ir = 0; ir < 8 + K - 1; ++ir) {        // input row of the halo tile (relative to this thread's first output row)
+      const f16x8 h = *reinterpret_cast<const f16x8*>(tile + ((half * 8 + ir) * HC + col + s) * 32 + c0);
+      float hv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (float)h[j];
+#pragma unroll
+      for (int r = 0; r < K; ++r) {                 // tap row r of output row ir - r
+        const int orow = ir - r;
+        if (orow >= 0 && orow < 8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[orow][j] += wv[r][j] * hv[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)acc[r][j];
+    *reinterpret_cast<f16x8*>(out + (((size_t)n * 128 + ty0 + half * 8 + r) * 128 + tx0 + col) * 32 + c0) = o;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1118,11 +1163,10 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
   for (int b = 0; b < 3; ++b) {
     std::string q = fe + "." + brs[b];
-    int nblk = (int)((px * 4 + 255) / 256);
     {
-      LoProfScope _p("lo_t_dwconv", 0, 0, st);
-      if (b == 1) hipLaunchKernelGGL((lo_t_dwconv_kernel<5>), dim3(nblk), dim3(256), 0, st, TW(f16, h->o_raw32), ss32, TP(q + ".0.weight"), TP(q + ".0.bias"), TW(f16, h->o_dw), B);
-      else hipLaunchKernelGGL((lo_t_dwconv_kernel<3>), dim3(nblk), dim3(256), 0, st, TW(f16, h->o_raw32), ss32, TP(q + ".0.weight"), TP(q + ".0.bias"), TW(f16, h->o_dw), B);
+      LoProfScope _p(b == 1 ? "lo_t_dwconv<5>" : "lo_t_dwconv<3>", 0, 4.0 * px * 32, st);
+      if (b == 1) hipLaunchKernelGGL((lo_t_dwconv_kernel<5>), dim3(32, B), dim3(256), 0, st, TW(f16, h->o_raw32), ss32, TP(q + ".0.weight"), TP(q + ".0.bias"), TW(f16, h->o_dw), B);
+      else hipLaunchKernelGGL((lo_t_dwconv_kernel<3>), dim3(32, B), dim3(256), 0, st, TW(f16, h->o_raw32), ss32, TP(q + ".0.weight"), TP(q + ".0.bias"), TW(f16, h->o_dw), B);
     }
     LO_LAUNCH_CHECK("t_dwconv");
     LO_TRYT(lo_conv_run(h->gpw, TW(f16, h->o_dw), TW(f16, h->o_wpw[b]), TP(q + ".1.bias"), nullptr, TW(f16, h->o_br[b]), nullptr, nullptr, 1, st, nullptr, &ex));
