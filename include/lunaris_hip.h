@@ -196,6 +196,10 @@ int lo_vae_linear_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_ele
 /* [begin, end) of the flat gradient buffer that is complete after lo_vae_backward_phase(.., phase = 1): fc_mu.weight up to
  * the end of the buffer (Linear layers, decoder convs, final conv).  The rest (encoder convs) is complete after phase 2. */
 int lo_vae_phase1_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_elem);
+/* Three-call form for the data-parallel exchange: phase 1, then phase 3 (encoder stage 4 = down4, 94 % of the encoder's
+ * gradient bytes; its range below is complete afterwards), then phase 4 (stages 3..1; [0, stage-4 begin) complete).  Phase 2
+ * = 3 + 4 in one call. */
+int lo_vae_stage4_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_elem);
 
 #ifdef __cplusplus
 }

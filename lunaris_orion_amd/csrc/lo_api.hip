@@ -678,7 +678,8 @@ extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* w
 extern "C" int lo_vae_backward_phase(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon,
                                      const float* target, int fused, const float* drecon, const float* gmu, const float* glv,
                                      float loss_scale, float* G, void* stream) {
-  LO_REQUIRE(phase == 1 || phase == 2, "lo_vae_backward_phase: phase must be 1 or 2");
+  LO_REQUIRE(phase >= 1 && phase <= 4, "lo_vae_backward_phase: phase must be 1 (final conv, decoder, Linear layers), 2 (whole encoder), "
+             "3 (encoder stage 4) or 4 (encoder stages 3..1, after 3)");
   return vae_backward_impl(h, phase, x, P, ws, recon, target, fused, drecon, gmu, glv, loss_scale, G, stream);
 }
 extern "C" int lo_vae_linear_grad_range(const LoVae* h, size_t* begin, size_t* end) {
@@ -697,8 +698,17 @@ extern "C" int lo_vae_phase1_grad_range(const LoVae* h, size_t* begin, size_t* e
   return LO_OK;
 }
 
-// GroupNorm affine + conv bias gradients of a set of layers in one launch
-static int vae_gn_finalize(LoVae* h, bool enc, bool dec, float* G, void* ws, float inv, hipStream_t st) {
+// the last encoder stage (down4: strided conv + ResBlock at 512 channels) holds 94 % of the encoder's gradient bytes and is the
+// first to be complete in the backward: the three-call form (phases 1, 3, 4) hands it over before stages 3..1 run
+extern "C" int lo_vae_stage4_grad_range(const LoVae* h, size_t* begin, size_t* end) {
+  LO_REQUIRE(h && begin && end, "lo_vae_stage4_grad_range: null argument");
+  *begin = h->p_off[h->enc[3][0].p_w];
+  *end = h->p_off[h->idx_fc_mu_w];
+  return LO_OK;
+}
+
+// GroupNorm affine + conv bias gradients of a set of layers in one launch (enc_mask: bit s = encoder stage s)
+static int vae_gn_finalize(LoVae* h, unsigned enc_mask, bool dec, float* G, void* ws, float inv, hipStream_t st) {
   const int B = h->B;
   LoGnFinJobs jobs;
   jobs.n = 0;
@@ -712,7 +722,8 @@ static int vae_gn_finalize(LoVae* h, bool enc, bool dec, float* G, void* ws, flo
     j.C = c.Cout; j.block0 = blocks;
     blocks += (c.Cout + 3) / 4;
   };
-  if (enc) for (int s = 0; s < 4; ++s) for (int k = 0; k < 3; ++k) add(h->enc[s][k]);
+  for (int s = 0; s < 4; ++s)
+    if (enc_mask & (1u << s)) for (int k = 0; k < 3; ++k) add(h->enc[s][k]);
   if (dec) for (int s = 0; s < 4; ++s) add(h->dec[s]);
   return lo_gn_finalize_all(jobs, inv, st);
 }
@@ -731,7 +742,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   f16* Gb = WSP(f16, h->o_G[1]);
   f16* Gc = WSP(f16, h->o_G[2]);
   f16* Gd = WSP(f16, h->o_G[3]);
-  if (phase != 2) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
+  if (phase == 0 || phase == 1) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
   h->bwd_layer = 0;
   for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) h->enc[s][k].np1 = 0; h->dec[s].np1 = 0; }
   // padding elements of the flat gradient buffer stay zero
@@ -783,10 +794,11 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
       LO_HIP(hipEventRecord(h->ev_join, h->side));
       LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     }
-    return vae_gn_finalize(h, false, true, G, ws, inv, st);
+    return vae_gn_finalize(h, 0u, true, G, ws, inv, st);
   }
-  // ---- encoder stages 4..1
-  for (int s = 3; s >= 0; --s) {
+  // ---- encoder stages 4..1 (phase 3: stage 4 only; phase 4: the rest)
+  const int s_hi = phase == 4 ? 2 : 3, s_lo = phase == 3 ? 3 : 0;
+  for (int s = s_hi; s >= s_lo; --s) {
     ConvLayer& c0 = h->enc[s][0];
     ConvLayer& c1 = h->enc[s][1];
     ConvLayer& c2 = h->enc[s][2];
@@ -809,7 +821,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     LO_HIP(hipEventRecord(h->ev_join, h->side));
     LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   }
-  // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or the encoder's after phase 2
-  LO_TRY(vae_gn_finalize(h, true, phase != 2, G, ws, inv, st));
+  // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or those of the stages this call ran
+  LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0, G, ws, inv, st));
   return LO_OK;
 }

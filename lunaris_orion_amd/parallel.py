@@ -7,9 +7,10 @@ GroupNorm is per-sample and MSE / KL are means, so averaging the per-rank gradie
 All 72 gradients live in ONE flat fp32 buffer (lunaris_orion_amd.vae), so the exchange is a single collective on a
 contiguous buffer — no bucketing logic, no per-tensor launches.  `FlatGradSync`:
   * backend "nccl" (= RCCL on ROCm): asynchronous `all_reduce(AVG)` (RCCL's own stream, ordered after the producing
-    kernels), joined before clip+AdamW.  VAEStepper splits the backward in two native calls so that the exchange of
+    kernels), joined before clip+AdamW.  VAEStepper splits the backward in three native calls so that the exchange of
     everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final convs: 90 % of the
-    bytes, final after phase 1) overlaps the encoder backward; the encoder conv gradients (25 MB) follow.  Optional
+    bytes, final after phase 1) overlaps the encoder backward, and that of the encoder's last stage (94 % of the rest)
+    overlaps stages 3..1; only their 7.7 MB are exchanged after the backward has ended.  Optional
     fp16 wire format (halves the xGMI bytes; g * 1024 on the wire so that small gradients stay in the normal fp16
     range; the sum is then taken in fp16, so it is off by default to keep DP == single-process to fp32 rounding);
   * backend "gloo" (CPU tests): SUM then divide (gloo has no AVG).

@@ -47,6 +47,7 @@ class VAEStepper:
         self.accum = max(1, int(gradient_accumulation_steps))
         self.betas, self.eps = betas, eps
         self.grad_sync = grad_sync      # data parallel: averages the flat gradient buffer across ranks (RCCL)
+        self.dp_three_phase = True      # hand the encoder's last stage over before stages 3..1 run (False: one encoder range)
         flat = vae.flat_parameters()
         self.grads = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
@@ -76,15 +77,24 @@ class VAEStepper:
                      float(vae.loss_scale), self.grads.data_ptr(), st)
             if self.grad_sync is not None and hasattr(self.grad_sync, "begin"):
                 # data parallel: everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final
-                # convs: 90 % of the bytes) is final after phase 1 and is exchanged while the encoder backward (phase 2)
-                # runs; the encoder conv gradients follow after phase 2
+                # convs: 90 % of the bytes) is final after phase 1 and is exchanged while the encoder backward runs; the
+                # encoder's last stage (94 % of the encoder bytes) is final after phase 3 and is exchanged during stages 3..1;
+                # only the small remainder (7.7 MB) is exchanged with nothing left to hide it
                 import ctypes as C
-                b, e = C.c_size_t(), C.c_size_t()
+                b, e, b4, e4 = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
                 _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
+                _lib.check(_lib.lib.lo_vae_stage4_grad_range(eng.handle, C.byref(b4), C.byref(e4)), "lo_vae_stage4_grad_range")
+                assert e4.value == b.value and e.value == self.grads.numel()
                 _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 1, *bargs), "lo_vae_backward_phase(1)")
                 self.grad_sync.begin(self.grads[b.value:e.value])
-                _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 2, *bargs), "lo_vae_backward_phase(2)")
-                self.grad_sync.begin(self.grads[:b.value])
+                if self.dp_three_phase:
+                    _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 3, *bargs), "lo_vae_backward_phase(3)")
+                    self.grad_sync.begin(self.grads[b4.value:e4.value])
+                    _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 4, *bargs), "lo_vae_backward_phase(4)")
+                    self.grad_sync.begin(self.grads[:b4.value])
+                else:                    # two-call form: the whole encoder range after phase 2
+                    _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 2, *bargs), "lo_vae_backward_phase(2)")
+                    self.grad_sync.begin(self.grads[:b.value])
                 self.grad_sync.finish()
             else:
                 _lib.check(_lib.lib.lo_vae_backward(eng.handle, *bargs), "lo_vae_backward")

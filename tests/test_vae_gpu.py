@@ -160,8 +160,8 @@ def test_state_dict_roundtrip_and_missing_gpu_errors():
         m(torch.zeros(1, 3, 128, 128))                              # CPU tensors: no fallback, must fail loudly
 
 
-def test_two_phase_backward_equals_single_call():
-    """The data-parallel path splits the backward in two native calls; gradients must be bit-identical."""
+def test_phased_backward_equals_single_call():
+    """The data-parallel path splits the backward in three native calls (phases 1, 3, 4); gradients must be bit-identical."""
     from lunaris_orion_amd.trainer import VAEStepper
     L, B = 256, 2
     m, P = _model(L)
@@ -181,17 +181,26 @@ def test_two_phase_backward_equals_single_call():
             pass
 
         def __call__(self, g):
-            raise AssertionError("two-phase path expected")
+            raise AssertionError("phased path expected")
 
     st = VAEStepper(m, lr=0.0, weight_decay=0.0)
     st.step(x, 0, eps)
     ref = st.grads.clone()
+    rec2 = Recorder()                               # two-call form (phases 1, 2)
+    st3 = VAEStepper(m, lr=0.0, weight_decay=0.0, grad_sync=rec2)
+    st3.dp_three_phase = False
+    st3.step(x, 0, eps)
+    torch.cuda.synchronize()
+    assert torch.equal(st3.grads, ref) and len(rec2.slices) == 2
+    for view, snap in rec2.snaps:
+        assert torch.equal(view, snap)
     rec = Recorder()
     st2 = VAEStepper(m, lr=0.0, weight_decay=0.0, grad_sync=rec)
     st2.step(x, 0, eps)
     torch.cuda.synchronize()
     assert torch.equal(st2.grads, ref)
-    assert sum(n for _, n in rec.slices) == st2.grads.numel() and len(rec.slices) == 2
+    assert sum(n for _, n in rec.slices) == st2.grads.numel() and len(rec.slices) == 3
+    assert rec.slices[2][1] <= 0.06 * st2.grads.numel()     # exchanged with nothing left to overlap it: encoder stages 1..3 (1.9 M elements)
     big = max(n for _, n in rec.slices)
     assert big >= 0.75 * st2.grads.numel()         # Linear layers + decoder convs: 78 % of the bytes at latent 256, 90 % at 512
     for view, snap in rec.snaps:                   # a range is handed over only once it is final (nothing writes it later)
