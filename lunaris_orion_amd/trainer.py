@@ -73,33 +73,7 @@ class VAEStepper:
                    "lo_vae_loss")
         if (batch_idx + 1) % self.accum == 0:
             flat = vae._flat
-            bargs = (images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(), images.data_ptr(), 1, None, None, None,
-                     float(vae.loss_scale), self.grads.data_ptr(), st)
-            if self.grad_sync is not None and hasattr(self.grad_sync, "begin"):
-                # data parallel: everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final
-                # convs: 90 % of the bytes) is final after phase 1 and is exchanged while the encoder backward runs; the
-                # encoder's last stage (94 % of the encoder bytes) is final after phase 3 and is exchanged during stages 3..1;
-                # only the small remainder (7.7 MB) is exchanged with nothing left to hide it
-                import ctypes as C
-                b, e, b4, e4 = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-                _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
-                _lib.check(_lib.lib.lo_vae_stage4_grad_range(eng.handle, C.byref(b4), C.byref(e4)), "lo_vae_stage4_grad_range")
-                assert e4.value == b.value and e.value == self.grads.numel()
-                _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 1, *bargs), "lo_vae_backward_phase(1)")
-                self.grad_sync.begin(self.grads[b.value:e.value])
-                if self.dp_three_phase:
-                    _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 3, *bargs), "lo_vae_backward_phase(3)")
-                    self.grad_sync.begin(self.grads[b4.value:e4.value])
-                    _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 4, *bargs), "lo_vae_backward_phase(4)")
-                    self.grad_sync.begin(self.grads[:b4.value])
-                else:                    # two-call form: the whole encoder range after phase 2
-                    _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 2, *bargs), "lo_vae_backward_phase(2)")
-                    self.grad_sync.begin(self.grads[:b.value])
-                self.grad_sync.finish()
-            else:
-                _lib.check(_lib.lib.lo_vae_backward(eng.handle, *bargs), "lo_vae_backward")
-                if self.grad_sync is not None:
-                    self.grad_sync(self.grads)
+            self._backward_and_exchange(eng, images, recon, st)
             lr = self.lr
             self.opt_steps += 1
             _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
@@ -110,6 +84,38 @@ class VAEStepper:
             vae.mark_weights_changed()
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
+
+    def _backward_and_exchange(self, eng, images: torch.Tensor, recon: torch.Tensor, st) -> None:
+        """Native backward of the fused loss into ``self.grads`` (+ the data-parallel exchange, overlapped with it)."""
+        vae = self.vae
+        flat = vae._flat
+        bargs = (images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(), images.data_ptr(), 1, None, None, None,
+                 float(vae.loss_scale), self.grads.data_ptr(), st)
+        if self.grad_sync is not None and hasattr(self.grad_sync, "begin"):
+            # data parallel: everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final
+            # convs: 90 % of the bytes) is final after phase 1 and is exchanged while the encoder backward runs; the
+            # encoder's last stage (94 % of the encoder bytes) is final after phase 3 and is exchanged during stages 3..1;
+            # only the small remainder (7.7 MB) is exchanged with nothing left to hide it
+            import ctypes as C
+            b, e, b4, e4 = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+            _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
+            _lib.check(_lib.lib.lo_vae_stage4_grad_range(eng.handle, C.byref(b4), C.byref(e4)), "lo_vae_stage4_grad_range")
+            assert e4.value == b.value and e.value == self.grads.numel()
+            _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 1, *bargs), "lo_vae_backward_phase(1)")
+            self.grad_sync.begin(self.grads[b.value:e.value])
+            if self.dp_three_phase:
+                _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 3, *bargs), "lo_vae_backward_phase(3)")
+                self.grad_sync.begin(self.grads[b4.value:e4.value])
+                _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 4, *bargs), "lo_vae_backward_phase(4)")
+                self.grad_sync.begin(self.grads[:b4.value])
+            else:                    # two-call form: the whole encoder range after phase 2
+                _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 2, *bargs), "lo_vae_backward_phase(2)")
+                self.grad_sync.begin(self.grads[:b.value])
+            self.grad_sync.finish()
+        else:
+            _lib.check(_lib.lib.lo_vae_backward(eng.handle, *bargs), "lo_vae_backward")
+            if self.grad_sync is not None:
+                self.grad_sync(self.grads)
 
     def decode_sprites(self, u8_hwc: torch.Tensor) -> torch.Tensor:
         """uint8 [B,128,128,3] on the device -> normalised float32 [B,3,128,128] (train_hybrid.py:181-182), native kernel."""
@@ -215,11 +221,7 @@ class HybridStepper(VAEStepper):
                                         float(self.accum), float(vae.loss_scale), self.losses.data_ptr(), st), "lo_vae_loss")
         if (batch_idx + 1) % self.accum == 0:
             flat = vae._flat
-            _lib.check(_lib.lib.lo_vae_backward(eng.handle, images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
-                                                images.data_ptr(), 1, None, None, None, float(vae.loss_scale), self.grads.data_ptr(), st),
-                       "lo_vae_backward")
-            if self.grad_sync is not None:
-                self.grad_sync(self.grads)
+            self._backward_and_exchange(eng, images, recon, st)     # data parallel: exchange overlapped with the backward
             lr = self.lr
             t_lr = cosine_warm_restarts_lr(self.teacher_base_lr, self.min_lr, self.t0, 2, self.opt_steps)
             self.opt_steps += 1
