@@ -194,7 +194,7 @@ class LunarisCoreVAE(nn.Module):
         self._layout: List[Tuple[int, int, torch.Size]] = []
         self._engines: Dict[Tuple[int, str], _Engine] = {}
         self._weights_version = 0      # bumped whenever the fp32 parameters may have changed
-        self._seed = 0x5EED
+        self._seed: Optional[int] = None   # counter-RNG stream of the reparameterisation noise; derived at the first forward
 
     # ---- flat parameter buffer ------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
@@ -275,6 +275,12 @@ class LunarisCoreVAE(nn.Module):
             eps = eps.detach().contiguous().float()
             if tuple(eps.shape) != (B, self.latent_dim):
                 raise ValueError("eps must have shape [B, latent_dim]")
+        if self._seed is None:
+            # one stream per (torch seed, rank): `--seed` selects it (train_hybrid.py:1138-1141 seeds torch the same way) and
+            # the ranks of a data-parallel job draw independent noise for their shards of the global batch
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5EED + 0xD1B54A32D192ED03 * rank) & 0xFFFFFFFFFFFFFFFF
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         _lib.check(_lib.lib.lo_vae_forward(eng.handle, x.data_ptr(), _lib.ptr(eps), self._seed, self._flat.data_ptr(),
                                            eng.ws.data_ptr(), recon.data_ptr(), mu.data_ptr(), logvar.data_ptr(),

@@ -277,3 +277,20 @@ def test_decode_sprites_matches_dataset_arithmetic():
     got = st.decode_sprites(u8.cuda()).cpu()
     ref = R.normalise_sprites(u8)
     assert (got - ref).abs().max().item() <= 1.2e-7      # x/127.5 - 1 in fp32: at most 1 ulp apart
+
+
+def test_noise_stream_follows_the_torch_seed():
+    """Without an explicit eps the reparameterisation noise is a counter RNG keyed by (torch seed, rank): the same seed gives the
+    same reconstructions, another seed gives different ones (mu / logvar do not depend on the noise)."""
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        m, _ = _model(L)
+        with torch.no_grad():
+            recon, mu, _lv = m(x)
+        torch.cuda.synchronize()
+        outs.append((recon.cpu(), mu.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert not torch.equal(outs[0][0], outs[2][0])
