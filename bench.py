@@ -198,7 +198,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": d_by / (d_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_traffic.py); null when absent
+        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/rocpd_extract.py traffic); null when absent
         roof["traffic"] = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
