@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank control flow on one GPU)")
     ap.add_argument("--dp-fp16", action="store_true", help="fp16 wire format for the gradient all-reduce (off: fp32)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--precision", choices=["fp16", "fp8"], default="fp16",
@@ -126,12 +128,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)     # one rank per GPU on a full node; the modulo only matters in rehearsals
+    torch.cuda.set_device(local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from lunaris_orion_amd import _lib
     from lunaris_orion_amd.trainer import VAEStepper
@@ -174,11 +180,13 @@ def main():
         # ---- roofline leg: per-launch HIP events on the launch stream, extra steps after the timed region
         rows = {}
         if args.prof_steps > 0:
+            saved_sync, st.grad_sync = st.grad_sync, None     # rank-local leg: the other ranks are not stepping, so no collective
             _lib.lib.lo_prof_enable(1)
             run(args.prof_steps)
             torch.cuda.synchronize()
             rows = collect_profile(_lib.lib)
             _lib.lib.lo_prof_enable(0)
+            st.grad_sync = saved_sync
         if not rows:
             rows = {"(not profiled)": [1.0, 1, 0.0, 0.0]}
         total_ms = sum(r[0] for r in rows.values())

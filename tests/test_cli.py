@@ -128,3 +128,21 @@ def test_bench_line_contract(tmp_path):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["config3_full_hybrid"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """The driver's N > 1 launch (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) rehearsed with two
+    ranks sharing the one GPU of the test box (gloo carries the collectives; RCCL refuses two ranks on one device): barriers,
+    max-over-ranks timing, the rank-0-only roofline leg (which must not issue collectives) and the single JSON line."""
+    import json
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--latent", "256", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and "cpu_baseline" not in d and "config3_full_hybrid" not in d
+    assert d["roofline"]["launches_per_step"] > 0
