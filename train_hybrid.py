@@ -95,12 +95,14 @@ def main(argv=None):
     torch.cuda.manual_seed_all(args.seed)
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)        # one rank per GPU on a full node; the modulo only matters in rehearsals
     torch.cuda.set_device(local)
     grad_sync = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # nccl = RCCL over xGMI; LO_DIST_BACKEND=gloo rehearses the multi-rank control flow with several ranks on one GPU
+        dist.init_process_group(os.environ.get("LO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
         from lunaris_orion_amd.parallel import FlatGradSync
         grad_sync = FlatGradSync()
 
@@ -198,6 +200,12 @@ def main(argv=None):
                 feeder.close()
                 break
         avg = float(np.mean(epoch_losses)) if epoch_losses else float("nan")
+        if grad_sync is not None:
+            # data parallel: every rank must take the same early-stopping / best-checkpoint decision (a rank that stops alone
+            # leaves the others waiting in the next gradient exchange): decide on the mean over ranks
+            t_avg = torch.tensor([avg], dtype=torch.float32, device="cuda")
+            grad_sync.average_small(t_avg)
+            avg = float(t_avg.item())
         log.info(f"Epoch {epoch + 1} Summary: Time {(time.time() - t0) / 60:.2f} min, Average Loss {avg:.4f}, Best Loss {best_loss:.4f}")
         early(avg)                                                                         # train_hybrid.py:1049-1052
         if early.early_stop:
