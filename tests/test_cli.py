@@ -149,19 +149,22 @@ def test_bench_two_rank_control_flow_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_cli_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["vae_only", "hybrid"])
+def test_cli_two_ranks_on_one_gpu(tmp_path, mode):
     """train_hybrid.py under `torch.distributed.run` with two ranks (rehearsal: both on the test box's one GPU, gloo carrying the
     collectives): disjoint shards per rank, the phased backward with the three overlapped exchanges, the rank-consistent
-    early-stopping mean, rank 0 writing the log and the checkpoint, both ranks ending together."""
+    early-stopping mean, rank 0 writing the log and the checkpoint, both ranks ending together; with the teacher on also the
+    5-float reward-mean exchange and the gate / quality-head gradient exchange."""
     data = tmp_path / "data"
     data.mkdir()
     _make_data(str(data), n=40)
     out = tmp_path / "out"
     env = dict(os.environ, LO_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29543", os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
-                        "--vae_only", "--batch_size", "4", "--gradient_accumulation_steps", "1", "--num_epochs", "2", "--log_every", "1",
-                        "--latent_dim", "256"], capture_output=True, text=True, timeout=900, env=env)
+                        "--master-port", "29543" if mode == "vae_only" else "29545", os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
+                        "--batch_size", "4", "--gradient_accumulation_steps", "1", "--num_epochs", "2", "--log_every", "1",
+                        "--latent_dim", "256"] + (["--vae_only"] if mode == "vae_only" else []),
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     log = (out / "training.log").read_text()
     assert log.count("Average Loss") == 2 and "Training completed." in log
