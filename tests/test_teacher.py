@@ -239,3 +239,21 @@ def test_statistics_only_call_has_the_side_effects_of_forward():
     assert int(states[1]["experts.0.0.conv1.2.num_batches_tracked"]) == 1
     for k in states[0]:
         assert torch.equal(states[0][k], states[1][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3])
+def test_teacher_odd_batch_sizes(B):
+    """A single sprite (BatchNorm statistics over one sample) and an odd batch, train mode, against the oracle."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    S = T.closed_form_teacher_state()
+    m = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=64, dropout_rate=0.0)
+    m.load_state_dict(S)
+    m = m.to("cuda").train()
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    out = m(x.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref, _ = T.teacher_forward(x, S, training=True)
+    for k, t in {"quality_scores": 2e-3, "expert_weights": 2e-3, "semantic_score": 2e-3, "style_embedding": 2e-2}.items():
+        assert (out[k].cpu() - ref[k]).abs().max().item() <= t, k

@@ -294,3 +294,28 @@ def test_noise_stream_follows_the_torch_seed():
         outs.append((recon.cpu(), mu.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[2][1])
     assert not torch.equal(outs[0][0], outs[2][0])
+
+
+@pytest.mark.parametrize("B,L", [(1, 64), (5, 128), (7, 256)])
+def test_odd_batch_sizes_and_small_latents(B, L):
+    """Edge shapes: a single sprite, batches that are not a multiple of any tile height, the smallest latent sizes (the CLI
+    default is 128): forward vs the oracle, one fused step with finite gradients, per-sample consistency with batch 1."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    m, P = _model(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    eps = R.closed_form_eps(B, L, salt=0)
+    with torch.no_grad():
+        recon, mu, logvar = m(x.cuda(), eps.cuda())
+    torch.cuda.synchronize()
+    r_ref, mu_ref, lv_ref = R.vae_forward(x, eps, P)
+    assert (mu.cpu() - mu_ref).abs().max().item() <= 5e-3
+    assert (logvar.cpu() - lv_ref).abs().max().item() <= 5e-3
+    assert (recon.cpu() - r_ref).abs().max().item() <= 5e-3
+    with torch.no_grad():
+        r1, mu1, _ = m(x[-1:].cuda(), eps[-1:].cuda())          # the last sample alone
+    assert (mu1.cpu() - mu[-1:].cpu()).abs().max().item() <= 5e-3 and (r1.cpu() - recon[-1:].cpu()).abs().max().item() <= 5e-3
+    st = VAEStepper(m, lr=1e-4)
+    st.step(x.cuda(), 0, eps.cuda())
+    met = st.metrics()
+    rl_ref, kl_ref = R.vae_losses(r_ref, x, mu_ref, lv_ref)
+    assert met["grads_finite"] == 1.0 and abs(met["recon_loss"] - rl_ref.item()) <= 1e-4 and abs(met["kl_loss"] - kl_ref.item()) <= 1e-4
