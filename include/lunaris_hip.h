@@ -110,7 +110,8 @@ int lo_selfattn2d_backward(const float* x, const float* wq, const float* wk, con
                            int C, int N, void* stream);
 
 /* clip_grad_norm_ + AdamW over one flat fp32 buffer (train_hybrid.py:913,921; :504-509).  scratch: 1024+4 floats;
- * scratch[1024..1026] = (grad norm, clip coef, finite flag) afterwards. */
+ * scratch[1024..1026] = (grad norm, clip coef, finite flag) afterwards; scratch[1027] counts the calls whose gradient norm was
+ * not finite (those updates are skipped, like a step under torch.cuda.amp.GradScaler, train_hybrid.py:917-923). */
 int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float max_norm, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, float* scratch, void* stream);
 

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void lo_sumsq_partial_kernel(const float* __re
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-// norm_out: [0] = total L2 norm, [1] = clip coefficient, [2] = 1 if finite else 0
+// norm_out: [0] = total L2 norm, [1] = clip coefficient, [2] = 1 if finite else 0, [3] += 1 if not finite (sticky count of
+// skipped updates: the host halves its loss scale when it sees the count move, like torch.cuda.amp.GradScaler)
 __global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* __restrict__ partial, int n, float max_norm,
                                                                    float* __restrict__ norm_out) {
   __shared__ double red[256];
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* 
     norm_out[0] = norm;
     norm_out[1] = finite ? coef : 0.f;
     norm_out[2] = finite ? 1.f : 0.f;
+    if (!finite) norm_out[3] += 1.f;
   }
 }
 // torch.optim.AdamW (decoupled weight decay, eps outside the bias-corrected sqrt) with the clip coefficient folded in.

@@ -132,7 +132,8 @@ def flat_offsets(named_params: "OrderedDict[str, torch.Tensor]", flat: torch.Ten
 
 def checkpoint_dict(stepper, vae, teacher, global_step: int, best_loss: float, args: dict) -> dict:
     """The reference's checkpoint dictionary (train_hybrid.py:594-605) from the native state.  Extra key
-    `lunaris_amd_extra` (ignored by the reference) keeps what the reference loses on resume: the reward baseline."""
+    `lunaris_amd_extra` (ignored by the reference) keeps what the reference loses on resume: the reward baseline and the
+    fp16 loss scale."""
     vp = OrderedDict(vae.named_parameters())
     ck = {"global_step": global_step,
           "vae_state_dict": {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()},
@@ -159,6 +160,7 @@ def checkpoint_dict(stepper, vae, teacher, global_step: int, best_loss: float, a
                                                        stepper.betas, stepper.eps, stepper.weight_decay)
         ck["teacher_scheduler"] = scheduler_state_dict(stepper.t0, 2, stepper.min_lr, stepper.teacher_base_lr, stepper.opt_steps, t_lr)
         extra["reward_state"] = stepper.reward_state.detach().cpu().clone()
+    extra["loss_scale"] = float(vae.loss_scale)          # the reference's GradScaler state is not checkpointed either side: keep ours
     ck["lunaris_amd_extra"] = extra
     return ck
 
@@ -179,6 +181,8 @@ def restore_checkpoint(ck: dict, stepper, vae, teacher) -> Tuple[int, float]:
     if teacher is not None and (ck.get("teacher_optimizer") or {}).get("state"):
         stepper._pending_teacher_opt = ck["teacher_optimizer"]          # applied once the teacher buffers exist (first step)
     extra = ck.get("lunaris_amd_extra") or {}
+    if "loss_scale" in extra:
+        vae.loss_scale = float(extra["loss_scale"])
     if teacher is not None and "reward_state" in extra:
         stepper.reward_state.copy_(extra["reward_state"])
     return int(ck.get("global_step", 0)), float(ck.get("best_loss", float("inf")))

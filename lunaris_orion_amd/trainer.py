@@ -56,6 +56,7 @@ class VAEStepper:
         self.losses = torch.zeros(4, dtype=torch.float32, device=flat.device)       # recon, kl, vae_loss, pg_loss
         self.opt_steps = 0
         self.last = None
+        self._skipped_seen, self._scale_changed_at = 0, 0
 
     @property
     def lr(self) -> float:
@@ -127,11 +128,24 @@ class VAEStepper:
                    "lo_decode_sprites_u8")
         return out
 
+    def _update_loss_scale(self, skipped_total: float) -> None:
+        """GradScaler policy on the host, applied whenever the scalars are read anyway (torch.cuda.amp.GradScaler, used by
+        train_hybrid.py:917-923): every update skipped for a non-finite gradient norm halves the fp16 loss scale; 2000
+        optimizer steps without one double it again, up to the initial 2**16."""
+        skipped = int(skipped_total)
+        if skipped > self._skipped_seen:
+            self.vae.loss_scale = max(1.0, self.vae.loss_scale * 0.5 ** (skipped - self._skipped_seen))
+            self._skipped_seen, self._scale_changed_at = skipped, self.opt_steps
+        elif self.vae.loss_scale < 65536.0 and self.opt_steps - self._scale_changed_at >= 2000:
+            self.vae.loss_scale = min(65536.0, self.vae.loss_scale * 2.0)
+            self._scale_changed_at = self.opt_steps
+
     def metrics(self) -> Dict[str, float]:
         """Host copy of the last step's scalars (this synchronises the stream)."""
-        v = torch.cat([self.losses, self.scratch[1024:1027]]).cpu().tolist()
+        v = torch.cat([self.losses, self.scratch[1024:1028]]).cpu().tolist()
+        self._update_loss_scale(v[7])
         return {"recon_loss": v[0], "kl_loss": v[1], "vae_loss": v[2], "pg_loss": v[3], "grad_norm": v[4],
-                "clip_coef": v[5], "grads_finite": v[6], "lr": self.lr}
+                "clip_coef": v[5], "grads_finite": v[6], "lr": self.lr, "skipped_steps": v[7], "loss_scale": self.vae.loss_scale}
 
     def parameter_grads(self):
         """Views of the flat gradient buffer, one per parameter (state_dict order)."""
@@ -249,10 +263,11 @@ class HybridStepper(VAEStepper):
 
     def metrics(self) -> Dict[str, float]:
         """The 12 scalars of train_hybrid.py:929-942 (+ grad norm / lr); one host copy."""
-        v = torch.cat([self.losses, self.scratch[1024:1027], self.reward_out[:7]]).cpu().tolist()
+        v = torch.cat([self.losses, self.scratch[1024:1027], self.reward_out[:7], self.scratch[1027:1028]]).cpu().tolist()
         recon, kl, vae_loss, pg = v[0:4]
         q_loss, sem_r, q_r, baseline, adv, t_loss, q_mean = v[7:14]
+        self._update_loss_scale(v[14])
         return {"recon_loss": recon, "kl_loss": kl, "quality_loss": q_loss, "pg_loss": pg, "semantic_reward": sem_r,
                 "quality_reward": q_r, "baseline": baseline, "advantage": adv, "vae_loss": vae_loss, "teacher_loss": t_loss,
                 "total_loss": vae_loss + t_loss, "quality_scores": q_mean, "grad_norm": v[4], "clip_coef": v[5],
-                "grads_finite": v[6], "lr": self.lr}
+                "grads_finite": v[6], "lr": self.lr, "skipped_steps": v[14], "loss_scale": self.vae.loss_scale}

@@ -319,3 +319,25 @@ def test_odd_batch_sizes_and_small_latents(B, L):
     met = st.metrics()
     rl_ref, kl_ref = R.vae_losses(r_ref, x, mu_ref, lv_ref)
     assert met["grads_finite"] == 1.0 and abs(met["recon_loss"] - rl_ref.item()) <= 1e-4 and abs(met["kl_loss"] - kl_ref.item()) <= 1e-4
+
+
+def test_overflowing_gradients_skip_the_update_and_halve_the_loss_scale():
+    """GradScaler semantics (train_hybrid.py:917-923): a non-finite gradient norm skips the update; the host halves the fp16
+    loss scale when it next reads the scalars, and training goes on."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    L, B = 256, 2
+    m, _ = _model(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    st = VAEStepper(m, lr=1e-3)
+    m.loss_scale = 2.0 ** 40                       # far beyond the fp16 range: every activation gradient overflows
+    before = m.flat_parameters().clone()
+    st.step(x, 0, eps)
+    met = st.metrics()
+    assert met["grads_finite"] == 0.0 and met["skipped_steps"] == 1.0
+    assert torch.equal(m.flat_parameters(), before)            # update skipped
+    assert m.loss_scale == 2.0 ** 39                           # halved on the host
+    m.loss_scale = 65536.0
+    st.step(x, 1, eps)
+    met = st.metrics()
+    assert met["grads_finite"] == 1.0 and met["skipped_steps"] == 1.0 and not torch.equal(m.flat_parameters(), before)
