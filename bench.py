@@ -173,7 +173,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     met = st.metrics()
-    assert os.environ.get("LO_GN_SKIP_STREAM") or (met["grads_finite"] == 1.0 and np.isfinite(met["recon_loss"])), met
+    assert met["grads_finite"] == 1.0 and np.isfinite(met["recon_loss"]), met
 
     out = None
     if rank == 0:

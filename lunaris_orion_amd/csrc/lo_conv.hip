@@ -868,7 +868,6 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   dim3 grid(((a.M + BM - 1) / BM) * (g.Cout / BN) * (a.nsplit > 1 ? a.nsplit : g.n_phase));
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);
-  static const int deep = getenv("LO_DEEP_PIPE") ? atoi(getenv("LO_DEEP_PIPE")) : 0;   // tuning knob: one more LDS stage
   // short K loops (<= 9 steps: the 64-channel 3x3 layers) are prologue / epilogue bound: one LDS stage less puts a third
   // workgroup on the CU (measured 46.9 -> 39.8 us at 64 channels, 64x64; no gain on the longer loops).  LO_SHALLOW_PIPE=0/1 forces.
   static const int shallow_env = getenv("LO_SHALLOW_PIPE") ? atoi(getenv("LO_SHALLOW_PIPE")) : -1;
@@ -879,8 +878,6 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE, true>), grid, dim3(256), 0, st, a);
   else if (shallow && NSTAGE > 2)
     hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, (NSTAGE > 2 ? NSTAGE - 1 : 2), false>), grid, dim3(256), 0, st, a);
-  else if (deep)
-    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE + 1, false>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE, false>), grid, dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("igemm");

@@ -34,7 +34,6 @@ struct GnFwdArgs {
   f16* y;
   float* stats;          // [B][8][2] mean, rstd (saved for backward)
   int HW, C, MT, nchunk, mode;
-  int dbg_skip;          // timing experiments only: 1 = return after the prologue
   uint8_t* y8;           // optional e4m3 copy of y * LO_F8_ACT_SCALE (operand of an fp8 conv), same layout
 };
 
@@ -91,7 +90,6 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
     sc[j] = gm * rstd;
     sh[j] = bt - mean * sc[j];
   }
-  if (a.dbg_skip) { if (sc[0] == 12345.f) a.y[0] = (f16)sh[3]; return; }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;   // rows in flight per thread (memory-level parallelism)
@@ -157,7 +155,6 @@ struct GnBwdArgs {
   float* P2;            // [B][nchunk][C]   (sum dv, for the conv bias gradient)
   int HW, C, nchunk, mode;
   int np1;              // rows of P1 per sample (nchunk, or the tile count of the fused data-gradient epilogue)
-  int dbg_skip;         // timing experiments only: 1 = return after the prologue
 };
 
 // two elements at a time: xhat = hv*rstd + nmr (nmr = -mean*rstd), u = hv*sc + sh
@@ -317,7 +314,6 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (a.dbg_skip) { if (kb[0] == 12345.f) a.dv[0] = (f16)kc[0]; return; }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
   constexpr int U = 4;
@@ -476,8 +472,7 @@ static const char* gn_layer_name(const char* base, int C, int HW, int mode) {
 int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, const float* beta, const f16* other,
               f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st, uint8_t* y8) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_fwd: C=%d unsupported", C);
-  static const int dbg_skip = getenv("LO_GN_SKIP_STREAM") ? 1 : 0;
-  GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode, dbg_skip, y8};
+  GnFwdArgs a{v, partial, gamma, beta, other, y, stats, HW, C, MT, lo_gn_nchunk(HW, C), mode, y8};
   LoProfScope _p(gn_layer_name("lo_gn_fwd", C, HW, mode), 0, 2.0 * B * HW * C * (mode ? 3 : 2), st);
   if (mode == GN_MODE_PLAIN) hipLaunchKernelGGL(lo_gn_fwd_kernel<GN_MODE_PLAIN>, dim3(a.nchunk, B), dim3(256), 0, st, a);
   else if (mode == GN_MODE_SKIP) hipLaunchKernelGGL(lo_gn_fwd_kernel<GN_MODE_SKIP>, dim3(a.nchunk, B), dim3(256), 0, st, a);
@@ -489,8 +484,7 @@ int lo_gn_fwd(const f16* v, const float* partial, int MT, const float* gamma, co
 int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
                       f16* ds, f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st, int np1) {
   LO_REQUIRE(C % 32 == 0 && C <= 512, "lo_gn_bwd: C=%d unsupported", C);
-  static const int dbg_skip = getenv("LO_GN_SKIP_STREAM") ? 1 : 0;
-  GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, lo_gn_nchunk(HW, C), mode, 0, dbg_skip};
+  GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, lo_gn_nchunk(HW, C), mode, 0};
   a.np1 = np1 > 0 ? np1 : a.nchunk;
   if (np1 == 0) {
     LoProfScope _p(gn_layer_name("lo_gn_bwd_reduce", C, HW, mode), 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 2), st);
