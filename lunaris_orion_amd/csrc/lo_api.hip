@@ -153,6 +153,8 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_P1, o_P2;         // GN backward partial sums (kept until the fused finalize at the end of backward)
   int np1;                   // >0: P1 rows per sample written by the consumer's fused data-gradient epilogue
   int MT;
+  size_t o_dv;               // gradient wrt the raw conv output (GroupNorm backward -> data / weight gradient); one per layer, so the
+                             // side-stream weight gradient of layer k never shares a buffer with what the main stream writes next
   // fp8 operand mode (LO_VAE_FP8_FWD): e4m3 weights + per-row scales of the forward op, e4m3 copy of the activation o_a
   bool f8;                   // this layer's forward conv runs on e4m3 operands
   size_t o_wp8, o_wscale, o_a8;   // o_a8 = 0: no consumer needs the copy
@@ -197,7 +199,7 @@ struct LoVae {
   bool forward_done, loss_done;
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
-  hipEvent_t ev_dv[2], ev_wg[2], ev_join, ev_pre, ev_cast;
+  hipEvent_t ev_dv[2], ev_join, ev_pre, ev_cast;
   bool cast_pending;          // the Linear-layer fp16 copies are being refreshed on the side stream (lo_vae_pack)
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
@@ -236,6 +238,7 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   c.np1 = 0;
   c.o_P1 = ar.take((size_t)B * p1rows * Cout * 2 * 4);
   c.o_P2 = ar.take((size_t)B * nchunk * Cout * 4);
+  c.o_dv = ar.take(act);
   c.f8 = false;
   c.o_wp8 = c.o_wscale = c.o_a8 = 0;
   return LO_OK;
@@ -333,7 +336,8 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->o_coefs = ar.take(16 * 4);
   // backward scratch
   size_t max_act = (size_t)B * 128 * 128 * 32 * 2;
-  for (int i = 0; i < 6; ++i) h->o_G[i] = ar.take(max_act);
+  for (int i = 0; i < 4; ++i) h->o_G[i] = ar.take(max_act);
+  h->o_G[4] = h->o_G[5] = 0;
   h->o_skipg[0] = ar.take((size_t)B * 64 * 64 * 64 * 2);    // grad wrt (up3.act + enc1.out)
   h->o_skipg[1] = ar.take((size_t)B * 32 * 32 * 128 * 2);   // grad wrt (up2.act + enc2.out)
   h->o_skipg[2] = ar.take((size_t)B * 16 * 16 * 256 * 2);   // grad wrt (up1.act + enc3.out)
@@ -392,8 +396,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   if (h->overlap) {
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)
-      ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&h->ev_wg[i], hipEventDisableTiming) == hipSuccess;
+      ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_cast, hipEventDisableTiming) == hipSuccess;
@@ -407,7 +410,7 @@ extern "C" void lo_vae_destroy(LoVae* h) {
   if (!h) return;
   if (h->overlap) {
     (void)hipStreamDestroy(h->side);
-    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_dv[i]); (void)hipEventDestroy(h->ev_wg[i]); }
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->ev_dv[i]);
     (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre); (void)hipEventDestroy(h->ev_cast);
   }
   delete h;
@@ -623,19 +626,17 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
 static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, int mode, const f16* layer_in, f16* ds,
                        f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale, hipStream_t st,
                        ConvLayer* prod = nullptr) {
-  // dv alternates between two buffers so that the side-stream weight gradient of layer k may still be reading its
-  // dv while the main stream already produces the dv of layer k+1
+  // every layer has its own dv buffer: the side-stream weight gradient of layer k may still be reading it while the main
+  // stream produces the dv of the following layers (no event back from the side stream: two host calls per layer less)
   const int k = h->bwd_layer++;
-  f16* dv = WSP(f16, h->o_G[4 + (k & 1)]);
+  f16* dv = WSP(f16, c.o_dv);
   const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
-  if (ov && k >= 2) LO_HIP(hipStreamWaitEvent(st, h->ev_wg[k & 1], 0));
   LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
                            WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
   if (ov) {
     LO_HIP(hipEventRecord(h->ev_dv[k & 1], st));
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[k & 1], 0));
     LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
-    LO_HIP(hipEventRecord(h->ev_wg[k & 1], h->side));
   } else {
     static char wtag[32][64];
     if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
