@@ -69,7 +69,8 @@ int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const f
 
 // lo_train.hip
 int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, uint64_t seed, float* mu, float* logvar,
-                   f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st);
+                   f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st, float* mu_user = nullptr,
+                   float* logvar_user = nullptr);
 int lo_loss_finalize(const float* mse_partial, int n_mse, const float* kl_partial, int n_kl, float rw, float kw, float adv,
                      const float* adv_dev, float accum, float ls, float* losses, float* coefs, float n_rec, float n_lat,
                      hipStream_t st);

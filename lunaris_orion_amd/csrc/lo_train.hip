@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void lo_head_reduce_kernel(const float* __rest
                                                              const float* __restrict__ eps_in, uint64_t seed,
                                                              float* __restrict__ mu, float* __restrict__ logvar,
                                                              f16* __restrict__ z, float* __restrict__ eps_out,
-                                                             float* __restrict__ kl_partial, int B, int L, int nsplit) {
+                                                             float* __restrict__ kl_partial, int B, int L, int nsplit,
+                                                             float* __restrict__ mu_user, float* __restrict__ logvar_user) {
   __shared__ float red[4];
   int i = blockIdx.x * 256 + threadIdx.x;
   float term = 0.f;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void lo_head_reduce_kernel(const float* __rest
     float sd = expf(0.5f * lv);
     mu[i] = m;
     logvar[i] = lv;
+    if (mu_user) { mu_user[i] = m; logvar_user[i] = lv; }     // the caller's copies (no device-to-device copy afterwards)
     eps_out[i] = e;
     z[i] = (f16)(m + e * sd);
     term = 1.f + lv - m * m - expf(lv);
@@ -256,11 +258,12 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
 // launchers
 // ---------------------------------------------------------------------------------------------
 int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, uint64_t seed, float* mu, float* logvar,
-                   f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st) {
+                   f16* z, float* eps_out, float* kl_partial, int B, int L, int nsplit, hipStream_t st, float* mu_user,
+                   float* logvar_user) {
   int nb = (B * L + 255) / 256;
   LoProfScope _p("lo_head_reduce", 0, 4.0 * B * 2 * L * (nsplit + 2), st);
   hipLaunchKernelGGL(lo_head_reduce_kernel, dim3(nb), dim3(256), 0, st, slab, bias, eps_in, seed, mu, logvar, z, eps_out,
-                     kl_partial, B, L, nsplit);
+                     kl_partial, B, L, nsplit, mu_user, logvar_user);
   LO_LAUNCH_CHECK("head_reduce");
   return LO_OK;
 }

@@ -341,3 +341,20 @@ def test_overflowing_gradients_skip_the_update_and_halve_the_loss_scale():
     st.step(x, 1, eps)
     met = st.metrics()
     assert met["grads_finite"] == 1.0 and met["skipped_steps"] == 1.0 and not torch.equal(m.flat_parameters(), before)
+
+
+def test_backward_overwrites_every_gradient_element():
+    """The backward zeroes only the alignment gaps of the flat gradient buffer (no 244 MB memset per step): every other element
+    must be overwritten, never accumulated into.  Fill the buffer with garbage before the step and compare with a clean run."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    m, _ = _model(L)
+    st = VAEStepper(m, lr=0.0, weight_decay=0.0)
+    st.step(x, 0, eps)
+    clean = st.grads.clone()
+    st.grads.fill_(float("nan"))
+    st.step(x, 0, eps)
+    torch.cuda.synchronize()
+    assert torch.equal(st.grads, clean) and torch.isfinite(st.grads).all()
