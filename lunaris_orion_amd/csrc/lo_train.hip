@@ -117,12 +117,41 @@ __global__ void lo_latent_bwd_kernel(const f16* __restrict__ dz, const float* __
 }
 
 // column sums of an fp16 matrix [M][N] -> fp32 out[N]*scale  (Linear bias gradients; M = batch, tiny)
-__global__ void lo_colsum_f16_kernel(const f16* __restrict__ x, float* __restrict__ out, int M, int N, float scale) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
-  float t = 0.f;
-  for (int m = 0; m < M; ++m) t += (float)x[(size_t)m * N + j];
-  out[j] = t * scale;
+// out[j] = scale * sum_m x[m][j] (bias gradients of the Linear layers: M = batch rows).  256 threads = 32 column chunks of 8
+// (16-byte loads) x 8 row groups; the row groups are added in a fixed order through LDS (bitwise reproducible).  The one-thread-
+// per-column loop this replaces chained M dependent 2-byte loads: 18 us for a 4 MB matrix.
+__global__ __launch_bounds__(256) void lo_colsum_f16_kernel(const f16* __restrict__ x, float* __restrict__ out, int M, int N, float scale) {
+  __shared__ float red[8][32][8];
+  const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int j0 = (blockIdx.x * 32 + cc) * 8;
+  float t[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t[q] = 0.f;
+  if (j0 < N) {
+    for (int m = rg; m < M; m += 32) {            // four rows in flight per thread
+      f16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (m + 8 * u < M) v[u] = *reinterpret_cast<const f16x8*>(x + (size_t)(m + 8 * u) * N + j0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (m + 8 * u < M) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) t[q] += (float)v[u][q];
+        }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[rg][cc][q] = t[q];
+  __syncthreads();
+  const int c = threadIdx.x;                        // one output column per thread
+  const int j = blockIdx.x * 256 + c;
+  if (j < N) {
+    float tot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tot += red[r][c >> 3][c & 7];
+    out[j] = tot * scale;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,6 +315,7 @@ int lo_latent_bwd(const f16* dz, const float* mu, const float* logvar, const flo
   return LO_OK;
 }
 int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream_t st) {
+  LO_REQUIRE(N % 8 == 0, "lo_colsum_f16: N=%d must be a multiple of 8", N);
   LoProfScope _p("lo_colsum_f16", 0, 2.0 * M * N, st);
   hipLaunchKernelGGL(lo_colsum_f16_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, out, M, N, scale);
   LO_LAUNCH_CHECK("colsum_f16");
