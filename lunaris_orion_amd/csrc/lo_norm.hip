@@ -427,28 +427,39 @@ __global__ __launch_bounds__(256) void lo_gn_finalize_all_kernel(LoGnFinJobs job
 // small layout helpers
 // ---------------------------------------------------------------------------------------------
 // [B][HW][C] (NHWC) <-> [B][C][HW] (the order nn.Flatten sees, lunar_generate.py:150 / .view at :208)
-__global__ void lo_nhwc_to_nchw_f16_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int HW, int C, int total) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  int hw = i % HW;
-  int c = (i / HW) % C;
-  int n = i / (HW * C);
-  dst[i] = src[((size_t)n * HW + hw) * C + c];
-}
-__global__ void lo_nchw_to_nhwc_f16_kernel(const f16* __restrict__ src, f16* __restrict__ dst, uint8_t* __restrict__ dst8, int HW, int C,
-                                           int total) {
-  int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // four adjacent channels of one pixel (C % 4 == 0)
-  if (i >= total) return;
-  int c = i % C;
-  int hw = (i / C) % HW;
-  int n = i / (HW * C);
-  f16x4 v;
+// Per-sample matrix transpose [R][Cc] -> [Cc][R] of fp16 through a 64 x 64 LDS tile: 128-byte coalesced rows on both sides
+// (NHWC <-> NCHW flatten order of the 8 x 8 x 512 bottleneck around the Linear layers: R x Cc = 64 x 512 or 512 x 64).
+// dst8: optional e4m3 copy of the output (fp8 operand mode).  R % 64 == 0, Cc % 64 == 0.
+__global__ __launch_bounds__(256) void lo_transpose_tile_kernel(const f16* __restrict__ src, f16* __restrict__ dst, uint8_t* __restrict__ dst8,
+                                                                int R, int Cc) {
+  __shared__ f16 tile[64][66];
+  const int n = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const f16* s = src + (size_t)n * R * Cc;
+  const int tc = (threadIdx.x & 7) * 8, tr = threadIdx.x >> 3;     // 8 chunks of 8 elements per row, 32 rows per pass
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = src[((size_t)n * C + c + j) * HW + hw];
-  *reinterpret_cast<f16x4*>(dst + i) = v;
-  if (dst8)
-    *reinterpret_cast<uint32_t*>(dst8 + i) = lo_pack4_fp8((float)v[0] * LO_F8_ACT_SCALE, (float)v[1] * LO_F8_ACT_SCALE,
-                                                         (float)v[2] * LO_F8_ACT_SCALE, (float)v[3] * LO_F8_ACT_SCALE);
+  for (int p = 0; p < 2; ++p) {
+    const int r = tr + 32 * p;
+    const f16x8 v = *reinterpret_cast<const f16x8*>(s + (size_t)(r0 + r) * Cc + c0 + tc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[r][tc + j] = v[j];
+  }
+  __syncthreads();
+  f16* d = dst + (size_t)n * R * Cc;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int c = tr + 32 * p;                                     // output row = input column
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[tc + j][c];
+    const size_t off = (size_t)(c0 + c) * R + r0 + tc;
+    *reinterpret_cast<f16x8*>(d + off) = v;
+    if (dst8) {
+      constexpr float S8 = LO_F8_ACT_SCALE;
+      *reinterpret_cast<u32x2*>(dst8 + (size_t)n * R * Cc + off) =
+          (u32x2){lo_pack4_fp8((float)v[0] * S8, (float)v[1] * S8, (float)v[2] * S8, (float)v[3] * S8),
+                  lo_pack4_fp8((float)v[4] * S8, (float)v[5] * S8, (float)v[6] * S8, (float)v[7] * S8)};
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -535,17 +546,16 @@ int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st) {
 }
 
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
-  int total = B * HW * C;
-  LoProfScope _p("lo_layout_transpose", 0, 4.0 * total, st);
-  hipLaunchKernelGGL(lo_nhwc_to_nchw_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, HW, C, total);
+  LO_REQUIRE(HW % 64 == 0 && C % 64 == 0, "lo_nhwc_to_nchw_f16: HW=%d, C=%d must be multiples of 64", HW, C);
+  LoProfScope _p("lo_layout_transpose", 0, 4.0 * B * HW * C, st);
+  hipLaunchKernelGGL(lo_transpose_tile_kernel, dim3(C / 64, HW / 64, B), dim3(256), 0, st, src, dst, (uint8_t*)nullptr, HW, C);
   LO_LAUNCH_CHECK("nhwc_to_nchw");
   return LO_OK;
 }
 int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st, uint8_t* dst8) {
-  int total = B * HW * C;
-  LO_REQUIRE(C % 4 == 0, "lo_nchw_to_nhwc_f16: C=%d must be a multiple of 4", C);
-  LoProfScope _p("lo_layout_transpose", 0, 4.0 * total, st);
-  hipLaunchKernelGGL(lo_nchw_to_nhwc_f16_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, st, src, dst, dst8, HW, C, total);
+  LO_REQUIRE(HW % 64 == 0 && C % 64 == 0, "lo_nchw_to_nhwc_f16: HW=%d, C=%d must be multiples of 64", HW, C);
+  LoProfScope _p("lo_layout_transpose", 0, 4.0 * B * HW * C, st);
+  hipLaunchKernelGGL(lo_transpose_tile_kernel, dim3(HW / 64, C / 64, B), dim3(256), 0, st, src, dst, dst8, C, HW);
   LO_LAUNCH_CHECK("nchw_to_nhwc");
   return LO_OK;
 }
