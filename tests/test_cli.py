@@ -111,7 +111,7 @@ def test_cli_hybrid_end_to_end_on_gpu(tmp_path):
 def test_bench_line_contract(tmp_path):
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and (when asked) `cpu_baseline`."""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--latent", "256",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--min-warmup", "0", "--batch", "8", "--latent", "256",
                         "--hybrid-steps", "1", "--cpu-batch", "2", "--cpu-steps", "1"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -137,7 +137,7 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     max-over-ranks timing, the rank-0-only roofline leg (which must not issue collectives) and the single JSON line."""
     import json
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup", "0",
                         "--batch", "4", "--latent", "256", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
