@@ -199,8 +199,9 @@ struct LoVae {
   bool forward_done, loss_done;
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
-  hipEvent_t ev_dv[2], ev_join, ev_pre, ev_cast;
+  hipEvent_t ev_dv[2], ev_join, ev_pre, ev_cast, ev_pack;
   bool cast_pending;          // the Linear-layer fp16 copies are being refreshed on the side stream (lo_vae_pack)
+  bool pack_pending;          // ... and so are the packed conv weights (first consumer: the second conv of the encoder)
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
@@ -391,6 +392,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->ws_bytes = ar.off;
   h->side = nullptr;
   h->cast_pending = false;
+  h->pack_pending = false;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
   // GroupNorm-backward reduction fused into the producing data-gradient epilogue: +1.4 % on the step (19 190 vs 18 925 sprites/s,
   // same box, interleaved runs; LO_GNB_FUSE=0 turns it off)
@@ -401,7 +403,8 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
       ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_cast, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&h->ev_cast, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); h->overlap = false; }   // no GPU in this process (CPU-side planning only)
   }
   *out = h;
@@ -414,6 +417,7 @@ extern "C" void lo_vae_destroy(LoVae* h) {
     (void)hipStreamDestroy(h->side);
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->ev_dv[i]);
     (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre); (void)hipEventDestroy(h->ev_cast);
+    (void)hipEventDestroy(h->ev_pack);
   }
   delete h;
 }
@@ -486,8 +490,16 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
     cs = h->side;
   }
-  LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, st));
-  if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(WSP(LoPackF8Job, h->o_packjobs8), h->n_packjobs8, h->pack_blocks8, st));
+  // the conv pack too (LO_SIDE_PACK, default on): the first conv of the encoder reads the fp32 weights directly, so the pack
+  // hides behind it and its GroupNorm; every other consumer waits on ev_pack (vae_wait_pack)
+  static const int side_pack = getenv("LO_SIDE_PACK") ? atoi(getenv("LO_SIDE_PACK")) : 1;
+  hipStream_t ps = side_pack ? cs : st;
+  LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, ps));
+  if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(WSP(LoPackF8Job, h->o_packjobs8), h->n_packjobs8, h->pack_blocks8, ps));
+  if (ps != st) {
+    LO_HIP(hipEventRecord(h->ev_pack, ps));
+    h->pack_pending = true;
+  }
   const int L = h->L;
   // encoder head: [fc_mu.weight ; fc_logvar.weight] is one contiguous [2L][32768] fp32 matrix in the flat buffer
   LO_REQUIRE(h->p_off[h->idx_fc_lv_w] == h->p_off[h->idx_fc_mu_w] + (size_t)L * 32768, "flat layout: head weights not adjacent");
@@ -502,6 +514,14 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
   return LO_OK;
 }
 
+// first consumer of a packed conv weight after lo_vae_pack
+static int vae_wait_pack(LoVae* h, hipStream_t st) {
+  if (h->pack_pending) {
+    LO_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));
+    h->pack_pending = false;
+  }
+  return LO_OK;
+}
 // first consumer of a Linear-layer fp16 copy after lo_vae_pack: order it after the side-stream refresh
 static int vae_wait_casts(LoVae* h, hipStream_t st) {
   if (h->cast_pending) {
@@ -540,6 +560,7 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
 static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* ws, float* recon, const float* target,
                                hipStream_t st) {
   const int B = h->B;
+  LO_TRY(vae_wait_pack(h, st));
   LO_TRY(vae_wait_casts(h, st));
   LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
                      nullptr, 1, st));
@@ -573,6 +594,7 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
       LO_TRY(lo_first_conv_fwd(x, PRM(c0.p_w), PRM(c0.p_b), WSP(f16, c0.o_v), WSP(float, c0.o_part), B, st));
       LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
                        WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
+      LO_TRY(vae_wait_pack(h, st));
     } else {
       LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8));
     }
@@ -758,6 +780,8 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   if (fused && (!h->loss_done || !target)) { lo_set_error("lo_vae_backward: fused mode needs lo_vae_loss and a target"); return LO_ERR_STATE; }
   LO_REQUIRE(loss_scale > 0.f, "lo_vae_backward: loss_scale must be positive");
   hipStream_t st = S(stream);
+  LO_TRY(vae_wait_pack(h, st));     // no-ops after a forward; cover a lo_vae_pack issued between forward and backward
+  LO_TRY(vae_wait_casts(h, st));
   const int B = h->B, L = h->L;
   const float inv = 1.0f / loss_scale;
   f16* Ga = WSP(f16, h->o_G[0]);
