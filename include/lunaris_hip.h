@@ -115,6 +115,12 @@ int lo_selfattn2d_backward(const float* x, const float* wq, const float* wk, con
 int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float max_norm, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, float* scratch, void* stream);
 
+/* lo_clip_adamw_step for a caller whose backward already summed the squares of [presummed_begin, n) into scratch[512..1024)
+ * (lo_vae_set_gradnorm_scratch): only [0, presummed_begin) is read for the norm. */
+int lo_clip_adamw_step_presummed(float* p, const float* g, float* m, float* v, size_t n, size_t presummed_begin, float max_norm,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* scratch,
+                                 void* stream);
+
 /* ---- the VAE step executor (LunarisCoreVAE.forward / backward, lunar_generate.py:263-276) -------------------- */
 typedef struct LoVae LoVae;
 int lo_vae_create(int batch, int latent_dim, LoVae** out);
@@ -127,6 +133,12 @@ int lo_vae_create(int batch, int latent_dim, LoVae** out);
 #define LO_VAE_FP8_FWD 1u
 int lo_vae_create_ex(int batch, int latent_dim, unsigned flags, LoVae** out);
 void lo_vae_destroy(LoVae* h);
+/* Early gradient norm: with a scratch set (the 1028-float scratch of lo_clip_adamw_step), a single-call lo_vae_backward takes the
+ * sum of squares of the range lo_vae_phase1_grad_range names as soon as it is final, beside the encoder backward, and
+ * lo_clip_adamw_step_presummed(.., presummed_begin = begin of that range, ..) reads only the rest.  lo_vae_gradnorm_presummed
+ * says whether the next backward will do so (it needs the library's side stream).  NULL scratch: off. */
+int lo_vae_set_gradnorm_scratch(LoVae* h, float* scratch);
+int lo_vae_gradnorm_presummed(const LoVae* h);
 /* parameters live in ONE flat fp32 buffer; tensor i (state_dict order, 72 tensors) starts at this element offset */
 int lo_vae_num_params(const LoVae* h);
 size_t lo_vae_param_offset(const LoVae* h, int index);

@@ -114,6 +114,16 @@ extern "C" int lo_clip_adamw_step(float* p, const float* g, float* m, float* v, 
   return lo_adamw(p, g, m, v, n, scratch + 1024, lr, beta1, beta2, eps, weight_decay, step, S(stream));
 }
 
+// The same step for a caller whose lo_vae_backward already left the sum of squares of [presummed_begin, n) in the scratch
+// (lo_vae_set_gradnorm_scratch): only the head of the buffer is read for the norm.
+extern "C" int lo_clip_adamw_step_presummed(float* p, const float* g, float* m, float* v, size_t n, size_t presummed_begin, float max_norm,
+                                            float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* scratch,
+                                            void* stream) {
+  LO_REQUIRE(p && g && m && v && scratch && presummed_begin <= n && presummed_begin % 4 == 0, "lo_clip_adamw_step_presummed: bad argument");
+  LO_TRY(lo_gradnorm_split(g, presummed_begin, max_norm, scratch, scratch + 1024, S(stream)));
+  return lo_adamw(p, g, m, v, n, scratch + 1024, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
 extern "C" int lo_decode_sprites_u8(const void* u8_hwc, float* out_chw, int B, void* stream) {
   LO_REQUIRE(u8_hwc && out_chw && B > 0, "lo_decode_sprites_u8: bad argument");
   return lo_decode_sprites((const uint8_t*)u8_hwc, out_chw, B, S(stream));
@@ -204,6 +214,7 @@ struct LoVae {
   bool pack_pending;          // ... and so are the packed conv weights (first consumer: the second conv of the encoder)
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
+  float* norm_scratch;   // lo_vae_set_gradnorm_scratch: where a single-call backward leaves the early part of the gradient norm
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
   // fp8 operand mode of the forward convs (lo_vae_create_ex flag LO_VAE_FP8_FWD)
   bool fp8_fwd;
@@ -393,6 +404,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->side = nullptr;
   h->cast_pending = false;
   h->pack_pending = false;
+  h->norm_scratch = nullptr;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
   // GroupNorm-backward reduction fused into the producing data-gradient epilogue: +1.4 % on the step (19 190 vs 18 925 sprites/s,
   // same box, interleaved runs; LO_GNB_FUSE=0 turns it off)
@@ -421,6 +433,16 @@ extern "C" void lo_vae_destroy(LoVae* h) {
   }
   delete h;
 }
+// Single-call backward only, and only when the side stream exists: once every gradient from fc_mu.weight to the end of the
+// buffer is final (decoder weight gradients included), its sum of squares is taken on the side stream, beside the encoder
+// backward, into scratch[512 .. 1024) -- lo_clip_adamw_step_presummed then reads just the encoder range (31 of 244 MB) on the
+// critical path.  NULL turns it off (e.g. when the gradients are still to be exchanged between ranks).
+extern "C" int lo_vae_set_gradnorm_scratch(LoVae* h, float* scratch) {
+  LO_REQUIRE(h, "lo_vae_set_gradnorm_scratch: null handle");
+  h->norm_scratch = scratch;
+  return LO_OK;
+}
+extern "C" int lo_vae_gradnorm_presummed(const LoVae* h) { return h && h->norm_scratch && h->overlap && !g_lo_prof_on; }
 extern "C" int lo_vae_num_params(const LoVae* h) { return h->nparam; }
 extern "C" size_t lo_vae_param_offset(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_off[i] : (size_t)-1; }
 extern "C" size_t lo_vae_param_numel(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_numel[i] : 0; }
@@ -833,6 +855,14 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
   }                   // ---------------- end of part A
+  if (phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on) {
+    // everything from fc_mu.weight on is final once the decoder's side-stream weight gradients are: order the early
+    // sum of squares after both streams' part A and let it run on the side stream beside the encoder backward
+    LO_HIP(hipEventRecord(h->ev_pre, st));
+    LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
+    LO_TRY(vae_gn_finalize(h, 0u, true, G, ws, inv, h->side));      // the decoder's GroupNorm / bias gradients belong to the range
+    LO_TRY(lo_sumsq_range(G, h->p_off[h->idx_fc_mu_w], h->flat_elems, h->norm_scratch, h->side));
+  }
   if (phase == 1) {
     // two-call form: every gradient from fc_mu.weight to the end of the buffer is complete now -> join the side
     // stream (decoder weight gradients) and finish the decoder's GroupNorm / bias gradients, so that the caller can
@@ -869,6 +899,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   }
   // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or those of the stages this call ran
-  LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0, G, ws, inv, st));
+  const bool early_norm = phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on;   // decoder layers finalized above
+  LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0 && !early_norm, G, ws, inv, st));
   return LO_OK;
 }

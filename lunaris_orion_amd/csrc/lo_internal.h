@@ -80,6 +80,8 @@ int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream
 int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st);
 int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st);
 int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st);
+int lo_sumsq_range(const float* g, size_t begin, size_t end, float* partial, hipStream_t st);   // -> partial[512 .. 1024)
+int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st);
 int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
              float eps, float wd, int step, hipStream_t st);
 

@@ -337,6 +337,22 @@ int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st) 
   return LO_OK;
 }
 #define LO_NORM_BLOCKS 1024
+// Split form for a caller that already holds the sum of squares of the tail [presummed_begin, n) in partial[HALF .. 2*HALF)
+// (lo_sumsq_range, issued earlier beside other work): only the head [0, presummed_begin) is read here.
+int lo_sumsq_range(const float* g, size_t begin, size_t end, float* partial, hipStream_t st) {
+  LoProfScope _p("lo_gradnorm (early range)", 0, 4.0 * (end - begin), st);
+  hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS / 2), dim3(256), 0, st, g + begin, end - begin, partial + LO_NORM_BLOCKS / 2);
+  LO_LAUNCH_CHECK("sumsq_range");
+  return LO_OK;
+}
+int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st) {
+  LoProfScope _p("lo_gradnorm", 0, 4.0 * presummed_begin, st);
+  hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS / 2), dim3(256), 0, st, g, presummed_begin, partial);
+  LO_LAUNCH_CHECK("sumsq_head");
+  hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out);
+  LO_LAUNCH_CHECK("gradnorm_finalize");
+  return LO_OK;
+}
 int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial /*>=1024*/, float* norm_out, hipStream_t st) {
   LoProfScope _p("lo_gradnorm", 0, 4.0 * n, st);
   hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS), dim3(256), 0, st, g, n, partial);

@@ -17,6 +17,7 @@ The teacher's contribution is the detached scalar ``mean_advantage`` (SURVEY §3
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -57,6 +58,7 @@ class VAEStepper:
         self.opt_steps = 0
         self.last = None
         self._skipped_seen, self._scale_changed_at = 0, 0
+        self._presummed_begin: Optional[int] = None   # set by a backward that left the early part of the gradient norm in the scratch
 
     @property
     def lr(self) -> float:
@@ -77,11 +79,7 @@ class VAEStepper:
             self._backward_and_exchange(eng, images, recon, st)
             lr = self.lr
             self.opt_steps += 1
-            _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                                   self.exp_avg_sq.data_ptr(), flat.numel(), float(self.max_grad_norm), float(lr),
-                                                   float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                                   float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st),
-                       "lo_clip_adamw_step")
+            self._clip_adamw(flat, lr, st)
             vae.mark_weights_changed()
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
@@ -114,9 +112,31 @@ class VAEStepper:
                 self.grad_sync.begin(self.grads[:b.value])
             self.grad_sync.finish()
         else:
+            # single process: the backward takes the sum of squares of everything from fc_mu.weight on as soon as it is final,
+            # beside the encoder backward; _clip_adamw then reads only the encoder range for the norm
+            early = self.grad_sync is None and os.environ.get("LO_EARLY_NORM", "1") != "0"       # LO_EARLY_NORM=0: A/B knob
+            _lib.check(_lib.lib.lo_vae_set_gradnorm_scratch(eng.handle, self.scratch.data_ptr() if early else None),
+                       "lo_vae_set_gradnorm_scratch")
             _lib.check(_lib.lib.lo_vae_backward(eng.handle, *bargs), "lo_vae_backward")
             if self.grad_sync is not None:
                 self.grad_sync(self.grads)
+            elif _lib.lib.lo_vae_gradnorm_presummed(eng.handle):
+                import ctypes as C
+                b, e = C.c_size_t(), C.c_size_t()
+                _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
+                self._presummed_begin = b.value
+
+    def _clip_adamw(self, flat: torch.Tensor, lr: float, st) -> None:
+        """clip_grad_norm_ + AdamW on the VAE's flat buffers (train_hybrid.py:913,921)."""
+        args = (float(self.max_grad_norm), float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st)
+        pre, self._presummed_begin = self._presummed_begin, None
+        if pre is not None:
+            _lib.check(_lib.lib.lo_clip_adamw_step_presummed(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                             self.exp_avg_sq.data_ptr(), flat.numel(), pre, *args), "lo_clip_adamw_step_presummed")
+        else:
+            _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                                   flat.numel(), *args), "lo_clip_adamw_step")
 
     def decode_sprites(self, u8_hwc: torch.Tensor) -> torch.Tensor:
         """uint8 [B,128,128,3] on the device -> normalised float32 [B,3,128,128] (train_hybrid.py:181-182), native kernel."""
@@ -239,11 +259,7 @@ class HybridStepper(VAEStepper):
             lr = self.lr
             t_lr = cosine_warm_restarts_lr(self.teacher_base_lr, self.min_lr, self.t0, 2, self.opt_steps)
             self.opt_steps += 1
-            _lib.check(_lib.lib.lo_clip_adamw_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                                   self.exp_avg_sq.data_ptr(), flat.numel(), float(self.max_grad_norm), float(lr),
-                                                   float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                                   float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st),
-                       "lo_clip_adamw_step")
+            self._clip_adamw(flat, lr, st)
             vae.mark_weights_changed()
             # teacher: gate + quality heads only (train_hybrid.py:891-904, 914, 922)
             b, e = self.t_range

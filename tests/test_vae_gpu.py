@@ -358,3 +358,22 @@ def test_backward_overwrites_every_gradient_element():
     st.step(x, 0, eps)
     torch.cuda.synchronize()
     assert torch.equal(st.grads, clean) and torch.isfinite(st.grads).all()
+
+
+def test_early_partial_gradient_norm_equals_the_full_one(monkeypatch):
+    """Single process: the backward sums the squares of the range that is final after its first part beside the encoder backward
+    and clip + AdamW reads only the rest.  Same norm (to fp32 summation order), same clip coefficient, same update."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    res = {}
+    for early in ("1", "0"):
+        monkeypatch.setenv("LO_EARLY_NORM", early)
+        m, _ = _model(L)
+        st = VAEStepper(m, lr=1e-4, max_grad_norm=1.0)           # the norm is ~2.9 here: the clip is active
+        st.step(x, 0, eps)
+        met = st.metrics()
+        res[early] = (met["grad_norm"], met["clip_coef"], m.flat_parameters().clone())
+    assert abs(res["1"][0] - res["0"][0]) <= 1e-6 * res["0"][0] and abs(res["1"][1] - res["0"][1]) <= 1e-6
+    assert (res["1"][2] - res["0"][2]).abs().max().item() <= 1e-7
