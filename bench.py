@@ -153,8 +153,9 @@ def main():
     if world > 1:
         from lunaris_orion_amd.parallel import FlatGradSync
         grad_sync = FlatGradSync(compress_fp16=args.dp_fp16)
+    pipeline = os.environ.get("LO_PIPELINE_OPT", "1") != "0"      # A/B knob; the pipelined optimizer step is the default
     st = VAEStepper(model, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
-                    kl_weight=0.1, gradient_accumulation_steps=1, grad_sync=grad_sync)
+                    kl_weight=0.1, gradient_accumulation_steps=1, grad_sync=grad_sync, pipeline_optimizer=pipeline)
     B = args.batch
     pool = [synth_sprites(B, 1000 * rank + i).cuda() for i in range(4)]
 

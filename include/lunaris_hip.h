@@ -147,6 +147,15 @@ size_t lo_vae_flat_elems(const LoVae* h);
 size_t lo_vae_workspace_bytes(const LoVae* h);
 /* refresh the packed fp16 operand copies from the fp32 master parameters (call after every parameter update) */
 int lo_vae_pack(LoVae* h, const float* flat_params, void* ws, void* stream);
+/* clip_grad_norm_ + AdamW (train_hybrid.py:913,921) + lo_vae_pack in ONE call, pipelined with the next forward: the encoder's
+ * parameters (13 %, what the next forward reads first) are updated on `stream`; the Linear layers and the decoder (87 %), their
+ * fp16 casts and packs follow on the library's side stream beside the next encoder forward (lo_vae_forward waits where it needs
+ * them).  p / g / m / v: the flat fp32 buffers of lo_vae_flat_elems() elements; scratch as for lo_clip_adamw_step; presummed as
+ * for lo_clip_adamw_step_presummed.  Afterwards parameters from fc_mu.weight on may still be in flight: call lo_vae_join before
+ * reading them on any stream other than through this executor. */
+int lo_vae_optimizer_step(LoVae* h, float* p, const float* g, float* m, float* v, void* ws, float max_norm, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int step, float* scratch, int presummed, void* stream);
+int lo_vae_join(LoVae* h, void* stream);   /* `stream` waits for the side-stream work of lo_vae_pack / lo_vae_optimizer_step */
 /* forward.  eps: explicit N(0,1) noise [B,L] or NULL (on-device counter RNG with `seed`).  target: images for the fused
  * MSE partial sums or NULL.  Outputs recon [B,3,128,128], mu, logvar [B,L] (fp32). */
 int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* flat_params, void* ws,

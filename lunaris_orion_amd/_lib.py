@@ -69,6 +69,8 @@ SIGNATURES = {
     "lo_vae_create": (i32, [i32, i32, C.POINTER(C.c_void_p)]),
     "lo_vae_create_ex": (i32, [i32, i32, C.c_uint, C.POINTER(C.c_void_p)]),
     "lo_vae_set_gradnorm_scratch": (i32, [vp, f32p]),
+    "lo_vae_optimizer_step": (i32, [vp, f32p, f32p, f32p, f32p, vp, flt, flt, flt, flt, flt, flt, i32, f32p, i32, vp]),
+    "lo_vae_join": (i32, [vp, vp]),
     "lo_vae_gradnorm_presummed": (i32, [vp]),
     "lo_clip_adamw_step_presummed": (i32, [f32p, f32p, f32p, f32p, sz, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),
     "lo_vae_destroy": (None, [vp]),

@@ -202,6 +202,7 @@ struct LoVae {
   size_t o_packjobs;
   std::vector<LoPackJob> packjobs_host;   // kept alive: source of the asynchronous table upload
   int n_packjobs, pack_blocks;
+  int n_packjobs_enc, pack_blocks_enc;   // the encoder's share of the table (its jobs come first)
   const void* packjobs_for_ws;     // workspace / parameter pointers the uploaded job table was built for
   const void* packjobs_for_params;
   size_t ws_bytes;
@@ -221,6 +222,7 @@ struct LoVae {
   size_t o_eout8[4], o_h08, o_packjobs8;
   std::vector<LoPackF8Job> packjobs8_host;
   int n_packjobs8, pack_blocks8;
+  int n_packjobs8_enc, pack_blocks8_enc;
 };
 
 static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin, int Cout, int p_w, Arena& ar, bool first) {
@@ -383,6 +385,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->fp8_fwd = (flags & LO_VAE_FP8_FWD) != 0;
   for (int s = 0; s < 4; ++s) h->o_eout8[s] = 0;
   h->o_h08 = 0; h->o_packjobs8 = 0; h->n_packjobs8 = h->pack_blocks8 = 0;
+  h->n_packjobs8_enc = h->pack_blocks8_enc = 0;
   if (h->fp8_fwd) {
     auto enable = [&](ConvLayer& c, size_t* producer_copy) {
       if (!lo_conv_f8_applies(c.gf)) return;
@@ -453,9 +456,8 @@ extern "C" size_t lo_vae_workspace_bytes(const LoVae* h) { return h->ws_bytes; }
 #define PRM(i) (P + h->p_off[(i)])
 #define GRD(i) (G + h->p_off[(i)])
 
-extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
-  LO_REQUIRE(h && P && ws, "lo_vae_pack: null argument");
-  hipStream_t st = S(stream);
+// (re)build the job tables of the fused pack launches and upload them into the workspace (once per workspace / parameter buffer)
+static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t st) {
   if (h->packjobs_for_ws != ws || h->packjobs_for_params != (const void*)P) {
     // (re)build the job table of the fused pack launch and upload it into the workspace
     std::vector<LoPackJob>& jobs = h->packjobs_host;
@@ -473,6 +475,8 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
         add(h->enc[s][k], h->enc[s][k].gf, h->enc[s][k].o_wp_f);
         add(h->enc[s][k], h->enc[s][k].gd, h->enc[s][k].o_wp_d);
       }
+    h->n_packjobs_enc = (int)jobs.size();
+    h->pack_blocks_enc = blocks;
     for (int s = 0; s < 4; ++s) {
       add(h->dec[s], h->dec[s].gf, h->dec[s].o_wp_f);
       add(h->dec[s], h->dec[s].gd, h->dec[s].o_wp_d);
@@ -494,6 +498,8 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
       };
       for (int s = 0; s < 4; ++s)
         for (int k = 0; k < 3; ++k) add8(h->enc[s][k]);
+      h->n_packjobs8_enc = (int)j8.size();
+      h->pack_blocks8_enc = blocks8;
       for (int s = 0; s < 4; ++s) add8(h->dec[s]);
       LO_REQUIRE(j8.size() <= 32, "too many fp8 pack jobs");
       if (!j8.empty())
@@ -504,6 +510,13 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     h->packjobs_for_ws = ws;
     h->packjobs_for_params = (const void*)P;
   }
+  return LO_OK;
+}
+
+extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
+  LO_REQUIRE(h && P && ws, "lo_vae_pack: null argument");
+  hipStream_t st = S(stream);
+  LO_TRY(vae_ensure_pack_jobs(h, P, ws, st));
   // the four Linear-layer copies (0.15 ms at L=512) are not needed before the end of the encoder: refresh them on the side
   // stream while the conv pack and the encoder forward run; the consumers wait on ev_cast (vae_wait_casts)
   hipStream_t cs = st;
@@ -533,6 +546,66 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
     LO_HIP(hipEventRecord(h->ev_cast, cs));
     h->cast_pending = true;
   }
+  return LO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined optimizer step: clip + AdamW + operand refresh in one call, ordered so that the NEXT forward can start after the
+// encoder's share of the update.  The encoder holds 13 % of the parameters and is what the next step needs first; the Linear
+// layers and the decoder (87 %, 0.24 ms of AdamW at the HBM roofline) are only read after the encoder forward (~1 ms of
+// mostly MFMA-bound work), so their update, their fp16 casts and their packs run on the side stream beside it:
+//   stream:  gradient norm -> AdamW [0, b)                                        (b = offset of fc_mu.weight)
+//   side  :  pack encoder convs (ev_pack) -> AdamW [b, n) -> pack decoder convs, fp8 copies, Linear casts (ev_cast)
+// lo_vae_forward waits for ev_pack before its second conv and for ev_cast before the encoder head, as after lo_vae_pack.
+// Until then parameters [b, n) and their Adam moments are in flight on the side stream: lo_vae_join orders another stream
+// (e.g. before the caller reads the parameters itself).  Without the side stream everything runs in order on `stream`.
+// presummed != 0: scratch[512..1024) already holds the sum of squares of [b, n) (lo_vae_set_gradnorm_scratch).
+// ---------------------------------------------------------------------------------------------
+extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* M, float* V, void* ws, float max_norm, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, int presummed,
+                                     void* stream) {
+  LO_REQUIRE(h && P && G && M && V && ws && scratch, "lo_vae_optimizer_step: null argument");
+  hipStream_t st = S(stream);
+  const size_t n = h->flat_elems, b = h->p_off[h->idx_fc_mu_w];
+  LO_TRY(vae_ensure_pack_jobs(h, P, ws, st));
+  if (presummed) LO_TRY(lo_gradnorm_split(G, b, max_norm, scratch, scratch + 1024, st));
+  else LO_TRY(lo_gradnorm(G, n, max_norm, scratch, scratch + 1024, st));
+  const float* norm = scratch + 1024;
+  if (!(h->overlap && !g_lo_prof_on)) {
+    LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
+    return lo_vae_pack(h, P, ws, stream);
+  }
+  LO_TRY(lo_adamw(P, G, M, V, b, norm, lr, beta1, beta2, eps, weight_decay, step, st));
+  LO_HIP(hipEventRecord(h->ev_pre, st));
+  LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
+  hipStream_t sd = h->side;
+  const LoPackJob* jobs = WSP(LoPackJob, h->o_packjobs);
+  const LoPackF8Job* jobs8 = WSP(LoPackF8Job, h->o_packjobs8);
+  LO_TRY(lo_pack_all(jobs, h->n_packjobs_enc, h->pack_blocks_enc, sd));
+  if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(jobs8, h->n_packjobs8_enc, h->pack_blocks8_enc, sd));
+  LO_HIP(hipEventRecord(h->ev_pack, sd));
+  h->pack_pending = true;
+  LO_TRY(lo_adamw(P + b, G + b, M + b, V + b, n - b, norm, lr, beta1, beta2, eps, weight_decay, step, sd));
+  LO_TRY(lo_pack_all(jobs + h->n_packjobs_enc, h->n_packjobs - h->n_packjobs_enc, h->pack_blocks - h->pack_blocks_enc, sd, h->pack_blocks_enc));
+  if (h->fp8_fwd)
+    LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8 - h->n_packjobs8_enc, h->pack_blocks8 - h->pack_blocks8_enc, sd,
+                          h->pack_blocks8_enc));
+  const int L = h->L;
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, sd));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, sd));
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, sd));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, sd));
+  LO_HIP(hipEventRecord(h->ev_cast, sd));
+  h->cast_pending = true;
+  return LO_OK;
+}
+// `stream` waits for whatever lo_vae_pack / lo_vae_optimizer_step left running on the side stream.
+extern "C" int lo_vae_join(LoVae* h, void* stream) {
+  LO_REQUIRE(h, "lo_vae_join: null handle");
+  hipStream_t st = S(stream);
+  if (h->pack_pending) LO_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));
+  if (h->cast_pending) LO_HIP(hipStreamWaitEvent(st, h->ev_cast, 0));
+  // the flags stay set: the executor's own stream may be a different one and still has to wait
   return LO_OK;
 }
 

@@ -134,15 +134,16 @@ __global__ void lo_pack_weight_kernel(const float* __restrict__ w, f16* __restri
 // convs / transposed-conv gradients and along n for the others), staged as fp16 in LDS, and written along c, the
 // contiguous axis of the packed operand.  lo_pack_blocks() gives the block count of one job.
 int lo_pack_blocks(const LoGeom& g) { return ((g.Cout + 15) / 16) * ((g.Cin + 63) / 64); }
-__global__ __launch_bounds__(256) void lo_pack_all_kernel(const LoPackJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void lo_pack_all_kernel(const LoPackJob* __restrict__ jobs, int njobs, int block_base) {
   __shared__ f16 tile[16][17][66];
+  const int bid = (int)blockIdx.x + block_base;     // block_base: first block of a sub-range of the job table
   int j = 0;
-  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
+  while (j + 1 < njobs && bid >= jobs[j + 1].block0) ++j;
   const LoPackJob& J = jobs[j];
   const LoGeom& g = J.g;
   const int tid = threadIdx.x;
   const int tiles_c = (g.Cin + 63) / 64;
-  const int b = (int)blockIdx.x - J.block0;
+  const int b = bid - J.block0;
   const int n0 = (b / tiles_c) * 16, c0 = (b % tiles_c) * 64;
   const bool n_fast = g.sn < g.sc;
   const int t_all = n_fast ? g.sn : g.sc;     // taps of the canonical weight (9, 16; 1 for a Linear)
@@ -834,9 +835,10 @@ __global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st) {
+int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base) {
+  if (njobs <= 0 || nblocks <= 0) return LO_OK;
   LoProfScope _p("lo_pack_all", 0, 0, st);
-  hipLaunchKernelGGL(lo_pack_all_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  hipLaunchKernelGGL(lo_pack_all_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, block_base);
   LO_LAUNCH_CHECK("pack_all");
   return LO_OK;
 }
@@ -964,10 +966,11 @@ __device__ __forceinline__ void lo_pack_f8_row(const LoPackF8Job& J, int row) { 
   }
   if (tid == 0) J.scale[row] = scale * (1.0f / LO_F8_ACT_SCALE);
 }
-__global__ __launch_bounds__(256) void lo_pack_f8_kernel(const LoPackF8Job* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void lo_pack_f8_kernel(const LoPackF8Job* __restrict__ jobs, int njobs, int block_base) {
+  const int bid = (int)blockIdx.x + block_base;
   int j = 0;
-  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
-  lo_pack_f8_row(jobs[j], (int)blockIdx.x - jobs[j].block0);
+  while (j + 1 < njobs && bid >= jobs[j + 1].block0) ++j;
+  lo_pack_f8_row(jobs[j], bid - jobs[j].block0);
 }
 __global__ __launch_bounds__(256) void lo_pack_f8_one_kernel(LoPackF8Job J) { lo_pack_f8_row(J, (int)blockIdx.x); }
 int lo_pack_f8_one(const LoGeom& g, const f16* wp, uint8_t* w8, float* wscale, hipStream_t st) {
@@ -997,10 +1000,10 @@ void lo_pack_f8_job(LoPackF8Job* j, const LoGeom& g, const f16* src, uint8_t* ds
   j->src = src; j->dst = dst; j->scale = scale; j->Cout = g.Cout; j->n_phase = g.n_phase; j->block0 = block0;
   for (int p = 0; p < g.n_phase; ++p) { j->K[p] = g.T[p] * g.Cin; j->wofs[p] = g.wofs[p]; }
 }
-int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStream_t st) {
-  if (njobs <= 0) return LO_OK;
+int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base) {
+  if (njobs <= 0 || nblocks <= 0) return LO_OK;
   LoProfScope _p("lo_pack_f8", 0, 0, st);
-  hipLaunchKernelGGL(lo_pack_f8_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  hipLaunchKernelGGL(lo_pack_f8_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, block_base);
   LO_LAUNCH_CHECK("pack_f8");
   return LO_OK;
 }

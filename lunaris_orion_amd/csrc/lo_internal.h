@@ -6,7 +6,7 @@ const char* lo_get_error();
 
 // lo_conv.hip
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
-int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st);
+int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base = 0);   // block_base: a sub-range of the table
 int lo_pack_blocks(const LoGeom& g);   // blocks of one job in the fused pack launch
 struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
 struct LoConvExtra { int act; float* bn_partial; };   // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums
@@ -19,7 +19,7 @@ bool lo_conv_f8_applies(const LoGeom& g);
 int lo_conv_run_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, const f16* add_src,
                    f16* out, float* gn_partial, hipStream_t st);
 void lo_pack_f8_job(LoPackF8Job* j, const LoGeom& g, const f16* src, uint8_t* dst, float* scale, int block0);   // blocks: n_phase * Cout
-int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStream_t st);
+int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base = 0);
 int lo_pack_f8_one(const LoGeom& g, const f16* wp, uint8_t* w8, float* wscale, hipStream_t st);
 int lo_quantize_f8(const f16* x, uint8_t* x8, size_t n, hipStream_t st);
 int lo_conv_tile_m(const LoGeom& g);

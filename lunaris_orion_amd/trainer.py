@@ -39,9 +39,15 @@ class VAEStepper:
     def __init__(self, vae: LunarisCoreVAE, lr: float = 1e-4, min_lr: float = 1e-6, scheduler_t0: int = 10,
                  weight_decay: float = 0.01, max_grad_norm: float = 1.0, recon_weight: float = 1.0, kl_weight: float = 0.1,
                  gradient_accumulation_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8,
-                 grad_sync: Optional[Callable[[torch.Tensor], None]] = None):
+                 grad_sync: Optional[Callable[[torch.Tensor], None]] = None, pipeline_optimizer: bool = False):
         _lib.require_gpu()
         self.vae = vae
+        # pipeline_optimizer: the update of the Linear / decoder parameters (87 % of AdamW's 1.7 GB) and their operand refresh run
+        # on the library's side stream beside the NEXT step's encoder forward (lo_vae_optimizer_step).  Parameters may then still
+        # be in flight when step() returns: call synchronize_parameters() before touching them outside this stepper
+        # (state_dict(), checkpoints, your own torch ops); forward / decode / sample through the module order themselves.
+        self.pipeline_optimizer = bool(pipeline_optimizer)
+        self._pipelined_engine = None
         self.base_lr, self.min_lr, self.t0 = lr, min_lr, scheduler_t0
         self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
         self.recon_weight, self.kl_weight = recon_weight, kl_weight
@@ -79,8 +85,9 @@ class VAEStepper:
             self._backward_and_exchange(eng, images, recon, st)
             lr = self.lr
             self.opt_steps += 1
-            self._clip_adamw(flat, lr, st)
-            vae.mark_weights_changed()
+            self._clip_adamw(flat, lr, st, eng)
+            if not self.pipeline_optimizer:
+                vae.mark_weights_changed()
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
 
@@ -126,11 +133,24 @@ class VAEStepper:
                 _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
                 self._presummed_begin = b.value
 
-    def _clip_adamw(self, flat: torch.Tensor, lr: float, st) -> None:
+    def synchronize_parameters(self) -> None:
+        """Make the current stream wait for a pipelined optimizer step's side-stream work (no-op otherwise)."""
+        if self._pipelined_engine is not None:
+            _lib.check(_lib.lib.lo_vae_join(self._pipelined_engine.handle, _lib.stream_ptr()), "lo_vae_join")
+
+    def _clip_adamw(self, flat: torch.Tensor, lr: float, st, eng=None) -> None:
         """clip_grad_norm_ + AdamW on the VAE's flat buffers (train_hybrid.py:913,921)."""
         args = (float(self.max_grad_norm), float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                 float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st)
         pre, self._presummed_begin = self._presummed_begin, None
+        if self.pipeline_optimizer and eng is not None:
+            _lib.check(_lib.lib.lo_vae_optimizer_step(eng.handle, flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                      self.exp_avg_sq.data_ptr(), eng.ws.data_ptr(), *args[:7], self.scratch.data_ptr(),
+                                                      1 if pre is not None else 0, st), "lo_vae_optimizer_step")
+            self.vae.mark_weights_changed()
+            eng.packed_version = self.vae._weights_version     # this engine's operand copies were refreshed by the call itself
+            self._pipelined_engine = eng
+            return
         if pre is not None:
             _lib.check(_lib.lib.lo_clip_adamw_step_presummed(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                              self.exp_avg_sq.data_ptr(), flat.numel(), pre, *args), "lo_clip_adamw_step_presummed")
@@ -259,8 +279,9 @@ class HybridStepper(VAEStepper):
             lr = self.lr
             t_lr = cosine_warm_restarts_lr(self.teacher_base_lr, self.min_lr, self.t0, 2, self.opt_steps)
             self.opt_steps += 1
-            self._clip_adamw(flat, lr, st)
-            vae.mark_weights_changed()
+            self._clip_adamw(flat, lr, st, eng)
+            if not self.pipeline_optimizer:
+                vae.mark_weights_changed()
             # teacher: gate + quality heads only (train_hybrid.py:891-904, 914, 922)
             b, e = self.t_range
             _lib.check(_lib.lib.lo_teacher_heads_backward(h, t._flat.data_ptr(), ws.data_ptr(), tout["expert_weights"].data_ptr(),

@@ -377,3 +377,34 @@ def test_early_partial_gradient_norm_equals_the_full_one(monkeypatch):
         res[early] = (met["grad_norm"], met["clip_coef"], m.flat_parameters().clone())
     assert abs(res["1"][0] - res["0"][0]) <= 1e-6 * res["0"][0] and abs(res["1"][1] - res["0"][1]) <= 1e-6
     assert (res["1"][2] - res["0"][2]).abs().max().item() <= 1e-7
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp8"])
+def test_pipelined_optimizer_step_equals_the_plain_one(precision):
+    """VAEStepper(pipeline_optimizer=True): encoder update on the stream, Linear / decoder update + operand refresh on the side
+    stream beside the next forward.  Same arithmetic, different schedule: bitwise equal losses, norms and weights."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    L, B = 256, 4
+    xs = [R.normalise_sprites(R.closed_form_sprites(B) if i % 2 == 0 else R.closed_form_sprites(B).flip(0)).cuda() for i in range(3)]
+    runs = {}
+    for pipe in (False, True):
+        torch.manual_seed(5)
+        m = LunarisCoreVAE(latent_dim=L, mfma_precision=precision)
+        m.load_state_dict(R.closed_form_params(L, 0))
+        m = m.to("cuda")
+        st = VAEStepper(m, lr=1e-4, min_lr=1e-6, scheduler_t0=4, pipeline_optimizer=pipe)
+        trace = []
+        for s in range(6):
+            st.step(xs[s % 3], s)
+            met = st.metrics()
+            trace.append((met["recon_loss"], met["kl_loss"], met["grad_norm"]))
+        st.synchronize_parameters()
+        torch.cuda.synchronize()
+        runs[pipe] = (trace, m.flat_parameters().clone(), st.exp_avg.clone())
+        with torch.no_grad():                                   # an eager forward after the pipelined steps orders itself
+            recon, _, _ = m(xs[0], R.closed_form_eps(B, L, salt=0).cuda())
+        runs[pipe] += (recon.clone(),)
+    assert runs[False][0] == runs[True][0]
+    assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
+    assert torch.equal(runs[False][3], runs[True][3])

@@ -131,7 +131,8 @@ def main(argv=None):
     vae = LunarisCoreVAE(latent_dim=args.latent_dim, mfma_precision=args.mfma_precision).to("cuda")
     common = dict(lr=args.vae_lr, min_lr=args.min_lr, scheduler_t0=args.scheduler_t0, weight_decay=args.weight_decay,
                   max_grad_norm=args.max_grad_norm, recon_weight=args.recon_weight, kl_weight=args.kl_weight,
-                  gradient_accumulation_steps=args.gradient_accumulation_steps, grad_sync=grad_sync)
+                  gradient_accumulation_steps=args.gradient_accumulation_steps, grad_sync=grad_sync,
+                  pipeline_optimizer=True)     # Linear / decoder update beside the next encoder forward; checkpoints synchronise first
     teacher = None
     if teacher_on:
         from lunaris_orion_amd.teacher import LunarMoETeacher
@@ -149,6 +150,7 @@ def main(argv=None):
     def save_checkpoint(tag="latest"):
         if rank != 0:
             return
+        stepper.synchronize_parameters()          # the pipelined optimizer step may still be updating the decoder's parameters
         torch.cuda.synchronize()
         torch.save(hostside.checkpoint_dict(stepper, vae, teacher, global_step, best_loss, vars(args)), out_dir / "checkpoints" / f"{tag}.pt")
         log.info(f"Checkpoint saved at step {global_step}")
