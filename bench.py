@@ -286,7 +286,7 @@ def main():
                 torch.manual_seed(42)
                 m = LunarisCoreVAE(latent_dim=args.latent, mfma_precision=prec).to("cuda")
                 return m, VAEStepper(m, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
-                                     kl_weight=0.1, gradient_accumulation_steps=1)
+                                     kl_weight=0.1, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
             first = {}
             for prec in ("fp16", "fp8"):
                 m8, s8 = fresh(prec)
@@ -319,7 +319,7 @@ def main():
             del st
             torch.cuda.empty_cache()
             teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256).to("cuda").train()
-            hs = HybridStepper(model, teacher, gradient_accumulation_steps=1)
+            hs = HybridStepper(model, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
             for i in range(10):
                 hs.step(pool[i % len(pool)], batch_idx=i)
             torch.cuda.synchronize()
