@@ -147,11 +147,11 @@ size_t lo_vae_flat_elems(const LoVae* h);
 size_t lo_vae_workspace_bytes(const LoVae* h);
 /* refresh the packed fp16 operand copies from the fp32 master parameters (call after every parameter update) */
 int lo_vae_pack(LoVae* h, const float* flat_params, void* ws, void* stream);
-/* clip_grad_norm_ + AdamW (train_hybrid.py:913,921) + lo_vae_pack in ONE call, pipelined with the next forward: the encoder's
- * parameters (13 %, what the next forward reads first) are updated on `stream`; the Linear layers and the decoder (87 %), their
- * fp16 casts and packs follow on the library's side stream beside the next encoder forward (lo_vae_forward waits where it needs
- * them).  p / g / m / v: the flat fp32 buffers of lo_vae_flat_elems() elements; scratch as for lo_clip_adamw_step; presummed as
- * for lo_clip_adamw_step_presummed.  Afterwards parameters from fc_mu.weight on may still be in flight: call lo_vae_join before
+/* clip_grad_norm_ + AdamW (train_hybrid.py:913,921) + lo_vae_pack in ONE call, pipelined with the next forward: encoder stages
+ * 1..3 (3 % of the parameters, what the next forward reads first) are updated on `stream`; the last encoder stage, the Linear
+ * layers and the decoder (97 %), their fp16 casts and packs follow on the library's side stream beside the next encoder forward
+ * (lo_vae_forward waits where it needs them).  p / g / m / v: the flat fp32 buffers of lo_vae_flat_elems() elements; scratch as for lo_clip_adamw_step; presummed as
+ * for lo_clip_adamw_step_presummed.  Afterwards parameters from encoder.down4 on may still be in flight: call lo_vae_join before
  * reading them on any stream other than through this executor. */
 int lo_vae_optimizer_step(LoVae* h, float* p, const float* g, float* m, float* v, void* ws, float max_norm, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int step, float* scratch, int presummed, void* stream);

@@ -202,7 +202,7 @@ struct LoVae {
   size_t o_packjobs;
   std::vector<LoPackJob> packjobs_host;   // kept alive: source of the asynchronous table upload
   int n_packjobs, pack_blocks;
-  int n_packjobs_enc, pack_blocks_enc;   // the encoder's share of the table (its jobs come first)
+  int n_packjobs_enc, pack_blocks_enc;   // the early share of the table: encoder stages 1..3 (their jobs come first)
   const void* packjobs_for_ws;     // workspace / parameter pointers the uploaded job table was built for
   const void* packjobs_for_params;
   size_t ws_bytes;
@@ -469,14 +469,14 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
       blocks += lo_pack_blocks(g);
       jobs.push_back(j);
     };
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+      if (s == 3) { h->n_packjobs_enc = (int)jobs.size(); h->pack_blocks_enc = blocks; }   // "early" share: encoder stages 1..3
       for (int k = 0; k < 3; ++k) {
         if (s == 0 && k == 0) continue;
         add(h->enc[s][k], h->enc[s][k].gf, h->enc[s][k].o_wp_f);
         add(h->enc[s][k], h->enc[s][k].gd, h->enc[s][k].o_wp_d);
       }
-    h->n_packjobs_enc = (int)jobs.size();
-    h->pack_blocks_enc = blocks;
+    }
     for (int s = 0; s < 4; ++s) {
       add(h->dec[s], h->dec[s].gf, h->dec[s].o_wp_f);
       add(h->dec[s], h->dec[s].gd, h->dec[s].o_wp_d);
@@ -496,10 +496,10 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
         blocks8 += c.gf.n_phase * c.Cout;
         j8.push_back(j);
       };
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        if (s == 3) { h->n_packjobs8_enc = (int)j8.size(); h->pack_blocks8_enc = blocks8; }
         for (int k = 0; k < 3; ++k) add8(h->enc[s][k]);
-      h->n_packjobs8_enc = (int)j8.size();
-      h->pack_blocks8_enc = blocks8;
+      }
       for (int s = 0; s < 4; ++s) add8(h->dec[s]);
       LO_REQUIRE(j8.size() <= 32, "too many fp8 pack jobs");
       if (!j8.empty())
@@ -551,12 +551,12 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined optimizer step: clip + AdamW + operand refresh in one call, ordered so that the NEXT forward can start after the
-// encoder's share of the update.  The encoder holds 13 % of the parameters and is what the next step needs first; the Linear
-// layers and the decoder (87 %, 0.24 ms of AdamW at the HBM roofline) are only read after the encoder forward (~1 ms of
-// mostly MFMA-bound work), so their update, their fp16 casts and their packs run on the side stream beside it:
-//   stream:  gradient norm -> AdamW [0, b)                                        (b = offset of fc_mu.weight)
-//   side  :  pack encoder convs (ev_pack) -> AdamW [b, n) -> pack decoder convs, fp8 copies, Linear casts (ev_cast)
-// lo_vae_forward waits for ev_pack before its second conv and for ev_cast before the encoder head, as after lo_vae_pack.
+// first encoder stages' share of the update.  Encoder stages 1..3 hold 3 % of the parameters and are what the next step needs
+// first; stage 4, the Linear layers and the decoder (97 %, 0.27 ms of AdamW at the HBM roofline) are only read 0.6 ms or more
+// into the next forward, so their update, their fp16 casts and their packs run on the side stream beside it:
+//   stream:  gradient norm -> AdamW [0, b4)                                (b4 = offset of the encoder's last stage: 3 % of the bytes)
+//   side  :  pack encoder stages 1..3 (ev_pack) -> AdamW [b4, n) -> pack stage 4 + decoder convs, fp8 copies, Linear casts (ev_cast)
+// lo_vae_forward waits for ev_pack before its second conv and for ev_cast before the encoder's last stage (0.6 ms in).
 // Until then parameters [b, n) and their Adam moments are in flight on the side stream: lo_vae_join orders another stream
 // (e.g. before the caller reads the parameters itself).  Without the side stream everything runs in order on `stream`.
 // presummed != 0: scratch[512..1024) already holds the sum of squares of [b, n) (lo_vae_set_gradnorm_scratch).
@@ -566,7 +566,9 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
                                      void* stream) {
   LO_REQUIRE(h && P && G && M && V && ws && scratch, "lo_vae_optimizer_step: null argument");
   hipStream_t st = S(stream);
-  const size_t n = h->flat_elems, b = h->p_off[h->idx_fc_mu_w];
+  // b: begin of the range whose sum of squares may be presummed (fc_mu.weight);  b4: begin of the encoder's last stage -- the
+  // stream itself only updates stages 1..3 (3 % of the parameters, what the next forward reads in its first 0.6 ms)
+  const size_t n = h->flat_elems, b = h->p_off[h->idx_fc_mu_w], b4 = h->p_off[h->enc[3][0].p_w];
   LO_TRY(vae_ensure_pack_jobs(h, P, ws, st));
   if (presummed) LO_TRY(lo_gradnorm_split(G, b, max_norm, scratch, scratch + 1024, st));
   else LO_TRY(lo_gradnorm(G, n, max_norm, scratch, scratch + 1024, st));
@@ -575,7 +577,7 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
     LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
     return lo_vae_pack(h, P, ws, stream);
   }
-  LO_TRY(lo_adamw(P, G, M, V, b, norm, lr, beta1, beta2, eps, weight_decay, step, st));
+  LO_TRY(lo_adamw(P, G, M, V, b4, norm, lr, beta1, beta2, eps, weight_decay, step, st));
   LO_HIP(hipEventRecord(h->ev_pre, st));
   LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
   hipStream_t sd = h->side;
@@ -585,7 +587,7 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
   if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(jobs8, h->n_packjobs8_enc, h->pack_blocks8_enc, sd));
   LO_HIP(hipEventRecord(h->ev_pack, sd));
   h->pack_pending = true;
-  LO_TRY(lo_adamw(P + b, G + b, M + b, V + b, n - b, norm, lr, beta1, beta2, eps, weight_decay, step, sd));
+  LO_TRY(lo_adamw(P + b4, G + b4, M + b4, V + b4, n - b4, norm, lr, beta1, beta2, eps, weight_decay, step, sd));
   LO_TRY(lo_pack_all(jobs + h->n_packjobs_enc, h->n_packjobs - h->n_packjobs_enc, h->pack_blocks - h->pack_blocks_enc, sd, h->pack_blocks_enc));
   if (h->fp8_fwd)
     LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8 - h->n_packjobs8_enc, h->pack_blocks8 - h->pack_blocks8_enc, sd,
@@ -691,6 +693,9 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
                        WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
       LO_TRY(vae_wait_pack(h, st));
     } else {
+      // the last stage's packed weights are refreshed at the END of the side-stream chain of a pipelined optimizer step
+      // (after the AdamW of everything from this stage on): same event as the Linear casts
+      if (s == 3) LO_TRY(vae_wait_casts(h, st));
       LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8));
     }
     LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8));
