@@ -257,8 +257,18 @@ __global__ void lo_pool_finalize_kernel(const float* __restrict__ partial, float
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int n = i / C, c = i - n * C;
+  // eight loads in flight (the plain loop chained nblk dependent loads: 25 us for 8192 outputs); fixed order, so reproducible
+  const float* p = partial + (size_t)n * nblk * C + c;
   float t = 0.f;
-  for (int k = 0; k < nblk; ++k) t += partial[((size_t)n * nblk + k) * C + c];
+  int k = 0;
+  for (; k + 8 <= nblk; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * C];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; k < nblk; ++k) t += p[(size_t)k * C];
   pooled[i] = t * (1.0f / (float)T_HW);
 }
 
