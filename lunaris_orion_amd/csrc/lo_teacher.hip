@@ -7,6 +7,7 @@
 //   the chunk-local attention with the reference's write-offset quirk, global average pooling, and the gate /
 //   quality / semantic / embedding heads (one workgroup per sample).
 #include "lo_internal.h"
+#include <unordered_map>
 #include "../../include/lunaris_hip.h"
 #include <stdlib.h>
 #include <string.h>
@@ -927,6 +928,7 @@ __global__ void lo_hybrid_reward_kernel(const float* __restrict__ quality, const
 struct LoTeacher {
   int B, E, I, emb, layers;
   std::vector<std::string> names;
+  std::unordered_map<std::string, size_t> index;   // names[i] -> i
   std::vector<size_t> off, numel;
   std::vector<char> is_float;
   size_t flat_elems;
@@ -950,9 +952,11 @@ struct LoTeacher {
   const void* att_zeroed_ws;
 };
 
+// name -> index of the state table: hashed (a forward makes ~1000 of these look-ups; the linear scan over 351 names they used to be
+// cost the host 33 us per kernel launch, more than most of the small kernels between the big convolutions take to run)
 static size_t t_idx(const LoTeacher* h, const std::string& k) {
-  for (size_t i = 0; i < h->names.size(); ++i) if (h->names[i] == k) return i;
-  return (size_t)-1;
+  auto it = h->index.find(k);
+  return it == h->index.end() ? (size_t)-1 : it->second;
 }
 #define TP(name) (P + h->off[t_idx(h, name)])
 #define TW(T, o) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (o))
@@ -1002,6 +1006,7 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
     std::string p = hn[k];
     add(p + ".2.weight", 128); add(p + ".2.bias", 128); lin(p + ".3", 128, 128); lin(p + ".6", ho[k], 128);
   }
+  for (size_t i = 0; i < h->names.size(); ++i) h->index[h->names[i]] = i;
   size_t o = 0;
   h->off.assign(h->names.size(), 0);
   for (size_t i = 0; i < h->names.size(); ++i) {
