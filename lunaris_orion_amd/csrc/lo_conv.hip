@@ -191,6 +191,7 @@ struct IgemmArgs {
   const float* gb_beta;
   float* gb_P1;
   const float* f8_scale;   // fp8 operand path: [n_phase][Cout] dequantisation factor (weight row scale / activation scale)
+  int out_pitch, out_choff;   // out_pitch > 0: `out` has out_pitch channels per pixel, this op's channels start at out_choff
   int M;               // rows per phase = B*GH*GW
   int nsplit;          // >= 1
   int ksteps_per_split;
@@ -482,7 +483,10 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; h[j] = (f16)(x > 0.f ? x : 0.2f * x); }
     }
-    *reinterpret_cast<f16x8*>(a.out + off) = h;
+    if (a.out_pitch > 0)   // concatenated output tensor (teacher feature extractor); add_src / gb_v are not used with it
+      *reinterpret_cast<f16x8*>(a.out + ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * a.out_pitch + a.out_choff + n0 + ochunk * 8) = h;
+    else
+      *reinterpret_cast<f16x8*>(a.out + off) = h;
     if (a.bn_partial) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; ga1[j] += x; ga2[j] += x * x; }
@@ -1016,6 +1020,8 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
   a.gb_beta = gb ? gb->beta : nullptr; a.gb_P1 = gb ? gb->P1 : nullptr;
   a.act = ex ? ex->act : 0; a.bn_partial = ex ? ex->bn_partial : nullptr;
+  a.out_pitch = ex ? ex->out_pitch : 0; a.out_choff = ex ? ex->out_choff : 0;
+  LO_REQUIRE(a.out_pitch == 0 || (!add_src && !gb && a.out_pitch % 8 == 0 && a.out_choff % 8 == 0), "lo_conv_run: bad concatenated-output arguments");
   a.f8_scale = nullptr;
   a.g = g;
   a.M = g.B * g.GH * g.GW;

@@ -9,7 +9,9 @@ int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
 int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base = 0);   // block_base: a sub-range of the table
 int lo_pack_blocks(const LoGeom& g);   // blocks of one job in the fused pack launch
 struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
-struct LoConvExtra { int act; float* bn_partial; };   // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums
+// teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums; out_pitch > 0: the output tensor has out_pitch channels per pixel
+// and this op writes its Cout channels starting at channel out_choff (writing straight into a concatenated tensor)
+struct LoConvExtra { int act; float* bn_partial; int out_pitch = 0; int out_choff = 0; };
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr,
                 const LoConvExtra* ex = nullptr);
