@@ -409,9 +409,10 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->pack_pending = false;
   h->norm_scratch = nullptr;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
-  // GroupNorm-backward reduction fused into the producing data-gradient epilogue: +1.4 % on the step (19 190 vs 18 925 sprites/s,
-  // same box, interleaved runs; LO_GNB_FUSE=0 turns it off)
-  h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
+  // GroupNorm-backward reduction fused into the producing data-gradient epilogue (LO_GNB_FUSE=1): +1.4 % on the step, but with
+  // the 128-pixel tiles that batches >= 16 select, its sum(du * xhat) column is not bitwise reproducible from run to run (1e-5
+  // relative; found by tests/test_fullsize_gpu.py, cause not yet located) -- off by default until it is
+  h->fuse_gnb = getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) != 0;
   if (h->overlap) {
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)

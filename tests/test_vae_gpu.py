@@ -232,7 +232,9 @@ for sync in (None, FlatGradSync(force=True), FlatGradSync(force=True, compress_f
         st.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
     out.append(st.metrics())
 torch.cuda.synchronize()
-assert abs(out[0]["recon_loss"] - out[1]["recon_loss"]) == 0.0 and out[0]["grad_norm"] == out[1]["grad_norm"], out
+# (the single-process path sums the squares for the gradient norm in two parts, see lo_vae_set_gradnorm_scratch: same norm to fp32
+# summation order, so the clipped update and the second step's losses agree to 1e-5, not bitwise)
+assert abs(out[0]["recon_loss"] - out[1]["recon_loss"]) <= 1e-5 and abs(out[0]["grad_norm"] - out[1]["grad_norm"]) <= 1e-5 * out[0]["grad_norm"], out
 assert abs(out[0]["recon_loss"] - out[2]["recon_loss"]) < 1e-4, out
 # the hybrid step under data parallelism: gradient ranges of both models + the 5-float reward-mean exchange
 from oracle import teacher_ref as T
@@ -247,9 +249,9 @@ for sync in (None, FlatGradSync(force=True)):
         hs.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
     hy.append(hs.metrics())
 torch.cuda.synchronize()
-for k in ("recon_loss", "baseline", "quality_reward", "teacher_loss"):
-    assert abs(hy[0][k] - hy[1][k]) <= 1e-6, (k, hy)
-assert abs(hy[0]["advantage"] - hy[1]["advantage"]) <= 1e-7, hy
+for k in ("recon_loss", "baseline", "quality_reward", "teacher_loss"):     # second step: after one update clipped with the two-part norm
+    assert abs(hy[0][k] - hy[1][k]) <= 1e-5, (k, hy)
+assert abs(hy[0]["advantage"] - hy[1]["advantage"]) <= 1e-6, hy
 dist.destroy_process_group()
 print("RCCL_PATH_OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
