@@ -410,8 +410,9 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->norm_scratch = nullptr;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
   // GroupNorm-backward reduction fused into the producing data-gradient epilogue (LO_GNB_FUSE=1): +1.4 % on the step, but with
-  // the 128-pixel tiles that batches >= 16 select, its sum(du * xhat) column is not bitwise reproducible from run to run (1e-5
-  // relative; found by tests/test_fullsize_gpu.py, cause not yet located) -- off by default until it is
+  // the weight gradients on the side stream its sum(du * xhat) column is not bitwise reproducible from run to run at batches
+  // >= 16 (1e-5 relative; stable with LO_NO_OVERLAP=1; found by tests/test_fullsize_gpu.py, race not yet located) -- off by
+  // default until it is
   h->fuse_gnb = getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) != 0;
   if (h->overlap) {
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
