@@ -736,9 +736,8 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
   hipStream_t st = S(stream);
   const int B = h->B, L = h->L;
   LO_TRY(lo_loss_finalize(WSP(float, h->o_msep), B * 64, WSP(float, h->o_klp), (B * L + 255) / 256, recon_weight, kl_weight,
-                          mean_advantage, adv_dev, accum, loss_scale, WSP(float, h->o_losses), WSP(float, h->o_coefs),
-                          (float)B * 3.f * 128.f * 128.f, (float)B * (float)L, st));
-  LO_HIP(hipMemcpyAsync(losses_dev, WSP(float, h->o_losses), 16, hipMemcpyDeviceToDevice, st));
+                          mean_advantage, adv_dev, accum, loss_scale, losses_dev, WSP(float, h->o_coefs),
+                          (float)B * 3.f * 128.f * 128.f, (float)B * (float)L, st));   // the four scalars go straight to the caller's buffer
   h->loss_done = true;
   return LO_OK;
 }

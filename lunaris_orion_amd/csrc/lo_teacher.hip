@@ -1140,7 +1140,7 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
 }
 
 static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, const std::string& bnp, float* P, void* ws,
-                         int training, hipStream_t st, int tps = 1, int vtps = 1, const float* cvec = nullptr) {
+                         int training, hipStream_t st, int tps = 1, int vtps = 1, const float* cvec = nullptr, float* ss_dst = nullptr) {
   LoProfScope _p("lo_bn_finalize", 0, 0, st);
   if (training && nrow > 256) {
     // two stages: 64 row splits in parallel, then the 64 split sums
@@ -1152,7 +1152,7 @@ static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, co
   }
   hipLaunchKernelGGL(lo_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nrow, C, (float)((size_t)h->B * T_HW),
                      TP(bnp + ".weight"), TP(bnp + ".bias"), TP(bnp + ".running_mean"), TP(bnp + ".running_var"), training,
-                     TW(float, h->o_ss), tps, vtps, cvec, (float)h->B);
+                     ss_dst ? ss_dst : TW(float, h->o_ss), tps, vtps, cvec, (float)h->B);   // ss_dst: (scale, shift) kept elsewhere than the shared slot
   LO_LAUNCH_CHECK("bn_finalize");
   return LO_OK;
 }
@@ -1199,10 +1199,9 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
                        TW(f16, h->o_raw32), bnp);
   }
   LO_LAUNCH_CHECK("t_conv1");
-  LO_TRYT(t_bn_finalize(h, bnp, B * 128, 32, fe + ".conv1.2", P, ws, training, st));
-  // the depthwise convs read BN(conv1) through (scale, shift) of o_ss: keep a private copy, o_ss is reused below
+  // the depthwise convs read BN(conv1) through its (scale, shift): kept in a private slot, the shared one is reused below
   float* ss32 = TW(float, h->o_ss) + 2 * 192;
-  LO_HIP(hipMemcpyAsync(ss32, TW(float, h->o_ss), 32 * 2 * 4, hipMemcpyDeviceToDevice, st));
+  LO_TRYT(t_bn_finalize(h, bnp, B * 128, 32, fe + ".conv1.2", P, ws, training, st, 1, 1, nullptr, ss32));
   const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
   for (int b = 0; b < 3; ++b) {
     std::string q = fe + "." + brs[b];
@@ -1216,8 +1215,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     LoConvExtra exb{1, bnp, 192, 64 * b};
     LO_TRYT(lo_conv_run(h->gpw, TW(f16, h->o_dw), TW(f16, h->o_wpw[b]), TP(q + ".1.bias"), nullptr, TW(f16, h->o_cat), nullptr, nullptr, 1, st, nullptr, &exb));
     int mt = (int)(px / lo_conv_tile_m(h->gpw));
-    LO_TRYT(t_bn_finalize(h, bnp, mt, 64, q + ".3", P, ws, training, st));
-    LO_HIP(hipMemcpyAsync(TW(float, h->o_ss_cat) + 128 * b, TW(float, h->o_ss), 64 * 2 * 4, hipMemcpyDeviceToDevice, st));
+    LO_TRYT(t_bn_finalize(h, bnp, mt, 64, q + ".3", P, ws, training, st, 1, 1, nullptr, TW(float, h->o_ss_cat) + 128 * b));
   }
   // the branch BatchNorms fold into the fusion conv (see lo_t_fold_fusion_kernel)
   hipLaunchKernelGGL(lo_t_fold_fusion_kernel, dim3(128), dim3(256), 0, st, TP(fe + ".fusion.0.weight"), TP(fe + ".fusion.0.bias"),
