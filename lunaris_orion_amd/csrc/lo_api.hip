@@ -409,11 +409,12 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->pack_pending = false;
   h->norm_scratch = nullptr;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
-  // GroupNorm-backward reduction fused into the producing data-gradient epilogue (LO_GNB_FUSE=1): +1.4 % on the step, but with
-  // the weight gradients on the side stream its sum(du * xhat) column is not bitwise reproducible from run to run at batches
-  // >= 16 (1e-5 relative; stable with LO_NO_OVERLAP=1; found by tests/test_fullsize_gpu.py, race not yet located) -- off by
-  // default until it is
-  h->fuse_gnb = getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) != 0;
+  // GroupNorm-backward reduction fused into the producing data-gradient epilogue (+1.4 % on the step; LO_GNB_FUSE=0 runs the
+  // separate reduction kernel).  The epilogue accumulates (sum du, sum du*v) and forms sum du*xhat = rstd * (sum du*v - mean *
+  // sum du) after its store loop: the first version multiplied by xhat inside the loop, with mean / rstd live across it, and
+  // was not bitwise reproducible while a weight-gradient kernel ran beside it (tools/gnb_det.py: 1365 mismatching tensors
+  // in 24 runs; 0 with this form) -- the determinism tests of tests/test_fullsize_gpu.py and test_vae_gpu.py guard it
+  h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
   if (h->overlap) {
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   const int G = g.Cout >> 3;          // channels per GroupNorm group (8 groups)
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   // fused GN-backward reduction: per-thread constants of its 8 channels (the tile lies inside one sample)
-  float gsc[8], gsh[8], gmean[8], grstd[8], ga1[8], ga2[8];
+  float gsc[8], gsh[8], ga1[8], ga2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
   if (a.gb_v) {
@@ -456,11 +456,9 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     for (int j = 0; j < 8; ++j) {
       int c = n0 + ochunk * 8 + j;
       int grp = c / G;
-      gmean[j] = a.gb_stats[n_img_t * 16 + grp * 2];
-      grstd[j] = a.gb_stats[n_img_t * 16 + grp * 2 + 1];
-      gsc[j] = a.gb_gamma[c] * grstd[j];
-      gsh[j] = a.gb_beta[c] - gmean[j] * gsc[j];
-      ga1[j] = 0.f; ga2[j] = 0.f;
+      float mean = a.gb_stats[n_img_t * 16 + grp * 2], rstd = a.gb_stats[n_img_t * 16 + grp * 2 + 1];
+      gsc[j] = a.gb_gamma[c] * rstd;
+      gsh[j] = a.gb_beta[c] - mean * gsc[j];
     }
   }
 #pragma unroll
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
         float hv = (float)vv[j];
         float du = (float)h[j] * lo_mish_grad(hv * gsc[j] + gsh[j]);
         ga1[j] += du;
-        ga2[j] += du * ((hv - gmean[j]) * grstd[j]);
+        ga2[j] += du * hv;          // sum du*xhat = rstd * (sum du*v - mean * sum du): finished after the loop
       }
     }
     if (a.gn_partial) {
@@ -525,6 +523,14 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     __syncthreads();
   }
   if (a.gb_v) {
+    // the saved mean / rstd are read here, after the store loop, not held in registers across it
+    const int n_img_t = m0 >> (g.lgw + g.lgh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int grp = (n0 + ochunk * 8 + j) / G;
+      float mean = a.gb_stats[n_img_t * 16 + grp * 2], rstd = a.gb_stats[n_img_t * 16 + grp * 2 + 1];
+      ga2[j] = rstd * (ga2[j] - mean * ga1[j]);
+    }
     // reduce (ga1, ga2) over the row slots in a fixed order: BN*2 outputs, one per thread (looped)
     float* red = reinterpret_cast<float*>(smem + BM * OPITCH);   // [256][16] floats
 #pragma unroll
