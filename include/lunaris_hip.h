@@ -175,7 +175,7 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
                     int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                     float* flat_grads, void* stream);
 
-/* ---- LunarMoETeacher.forward as executed (lunar_evaluator.py:408-462; feature_dim 128, dropout off) --------------- */
+/* ---- LunarMoETeacher.forward as executed (lunar_evaluator.py:408-462; feature_dim 128) ---------------------------- */
 typedef struct LoTeacher LoTeacher;
 int lo_teacher_create(int batch, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out);
 void lo_teacher_destroy(LoTeacher* h);
@@ -191,13 +191,25 @@ int lo_teacher_pack(LoTeacher* h, const float* flat_state, void* ws, void* strea
 /* training != 0: BatchNorm uses batch statistics and updates running_mean / running_var inside flat_state  Passing NULL for all five output
  * pointers makes it a statistics-only call (BatchNorm running statistics updated, pooling of the last block and heads
  * skipped): the first teacher call of _process_batch, train_hybrid.py:853-855, whose outputs are dead in the reference. */
-int lo_teacher_forward(LoTeacher* h, const float* x, float* flat_state, void* ws, int training, float* quality_scores,
-                       float* expert_weights, float* style_embedding, float* prompt_embedding, float* semantic_score,
-                       void* stream);
+/* dropout_p, drop_seed: the reference's six dropout sites (nn.Dropout after the branch concat lunar_evaluator.py:97-99,108;
+ * attn_drop / proj_drop :139-140,212,225; nn.Dropout2d after both ExpertBlock convs :246,253; nn.Dropout in the gate and
+ * every head :353-397) with torch semantics (elementwise / per (sample, channel), kept values scaled by 1/(1-p)), active
+ * only when training != 0 and dropout_p > 0.  The masks come from a counter RNG keyed by (drop_seed, site, element): pass a
+ * fresh drop_seed per call.  With dropout the constant-field shortcuts of the default path do not hold (proj_drop makes the
+ * conv2 input a random field) and every 3x3 convolution runs in full; lo_teacher_last_path reports which path the last call
+ * took: 0 sparse shortcuts, 1 dense (LO_T_DENSE=1), 2 dropout. */
+int lo_teacher_forward(LoTeacher* h, const float* x, float* flat_state, void* ws, int training, float dropout_p,
+                       uint64_t drop_seed, float* quality_scores, float* expert_weights, float* style_embedding,
+                       float* prompt_embedding, float* semantic_score, void* stream);
+int lo_teacher_last_path(const LoTeacher* h);
+/* keep[i] (1 / 0) of element i < n of dropout site `site` for call seed drop_seed: the decisions lo_teacher_forward applies
+ * (nn.Dropout semantics: lunar_evaluator.py:99,139-140; site numbering in csrc/lo_common.h, oracle/dropout_ref.py). */
+int lo_dropout_mask(uint64_t drop_seed, int site, float dropout_p, size_t n, uint8_t* keep, void* stream);
 
 /* gradients of teacher_loss = -(quality_weight/accum) * mean(quality_scores) for the parameters that receive gradients in
  * the reference step (gate.*, quality_heads.*; train_hybrid.py:891-904 with the reentrant-checkpoint quirk):
- * one contiguous range [begin,end) of the flat state layout.  rows: B*(end-begin) floats of scratch. */
+ * one contiguous range [begin,end) of the flat state layout.  rows: B*(end-begin) floats of scratch.  Replays the dropout
+ * masks of the gate / quality-head hidden layers of the lo_teacher_forward call it follows. */
 int lo_teacher_grad_range(const LoTeacher* h, size_t* begin_elem, size_t* end_elem);
 int lo_teacher_heads_backward(LoTeacher* h, const float* flat_state, void* ws, const float* expert_weights, float coef,
                               float* rows, float* flat_grads, void* stream);

@@ -62,7 +62,9 @@ SIGNATURES = {
     "lo_teacher_flat_elems": (sz, [vp]),
     "lo_teacher_workspace_bytes": (sz, [vp]),
     "lo_teacher_pack": (i32, [vp, f32p, vp, vp]),
-    "lo_teacher_forward": (i32, [vp, f32p, f32p, vp, i32, f32p, f32p, f32p, f32p, f32p, vp]),
+    "lo_teacher_forward": (i32, [vp, f32p, f32p, vp, i32, flt, u64, f32p, f32p, f32p, f32p, f32p, vp]),
+    "lo_teacher_last_path": (i32, [vp]),
+    "lo_dropout_mask": (i32, [u64, i32, flt, sz, vp, vp]),
     "lo_teacher_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lo_teacher_heads_backward": (i32, [vp, f32p, vp, f32p, flt, f32p, f32p, vp]),
     "lo_hybrid_reward": (i32, [f32p, f32p, i32, flt, flt, flt, flt, flt, f32p, f32p, f32p, vp]),

@@ -165,6 +165,55 @@ __device__ __forceinline__ float lo_mish_grad(float u) {
   return t * r + u * (4.0f * w * (w + 1.0f)) * (r * r);
 }
 
+// ---- counter RNG of the teacher's dropout layers (nn.Dropout / nn.Dropout2d, lunar_evaluator.py:97-99,139-140,212,225,246,
+// 253,353-397).  A dropout SITE of one forward call owns two 32-bit keys (lo_drop_site_keys: splitmix64 of the call's 64-bit
+// seed and the site number); element `idx` of the site's tensor (this library's own index order, stated at each use) takes
+// 16 bits of word(idx >> 1):  keep  <=>  bits >= thr,  thr = round(p * 65536)  (keep rate 1 - thr/65536; p = 0.1 -> 0.899994).
+// Kept elements are scaled by 1/(1-p) like torch.  oracle/dropout_ref.py restates these three functions in numpy (bit-exact),
+// so the CPU oracle and the reference (through forward hooks, oracle/make_golden.py) can run with the very same masks.
+__host__ __device__ __forceinline__ uint64_t lo_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+struct LoDropSite { uint32_t k0, k1; };
+__host__ __device__ __forceinline__ LoDropSite lo_drop_site_keys(uint64_t call_seed, uint32_t site) {
+  const uint64_t k = lo_splitmix64(call_seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(site + 1u)));
+  return LoDropSite{(uint32_t)k, (uint32_t)(k >> 32)};
+}
+__host__ __device__ __forceinline__ uint32_t lo_drop_word(LoDropSite s, uint32_t pair) {
+  uint32_t x = pair ^ s.k0;
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  x += s.k1;
+  x *= 0x9E3779B1U; x ^= x >> 15;
+  return x;
+}
+// keep decision of element idx (one word per call: for runs of consecutive indices use lo_drop_word + the two halves)
+__host__ __device__ __forceinline__ bool lo_drop_keep(LoDropSite s, uint32_t idx, uint32_t thr) {
+  return ((lo_drop_word(s, idx >> 1) >> ((idx & 1u) * 16u)) & 0xFFFFu) >= thr;
+}
+// eight consecutive elements idx0 .. idx0+7 (idx0 % 8 == 0): bit j of the result = keep(idx0 + j)
+__device__ __forceinline__ uint32_t lo_drop_keep8(LoDropSite s, uint32_t idx0, uint32_t thr) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t x = lo_drop_word(s, (idx0 >> 1) + w);
+    m |= ((x & 0xFFFFu) >= thr ? 1u : 0u) << (2 * w);
+    m |= ((x >> 16) >= thr ? 1u : 0u) << (2 * w + 1);
+  }
+  return m;
+}
+// dropout sites of one teacher forward (E <= 8 experts, 3 blocks each)
+#define LO_DS_FE 0u                                   // feature extractor, [B][HW][192] (NHWC index)
+#define LO_DS_GATE 1u                                 // gate hidden layer, [B][256]
+#define LO_DS_BLOCK(e, l, k) (2u + ((e) * 3u + (l)) * 4u + (k))   // k: 0 conv1 Dropout2d [B][C], 1 attn_drop [B][543][8][32],
+                                                                  //    2 proj_drop [B][HW][C] (NHWC), 3 conv2 Dropout2d [B][C]
+#define LO_DS_QUALITY(e) (100u + (e))                 // quality head hidden layer, [B][64]
+#define LO_DS_SEM 110u                                // semantic head hidden layer [B][128]
+#define LO_DS_STYLE 111u
+#define LO_DS_PROMPT 112u
+
 // ---- fp8 operand path (OCP e4m3, gfx950): activations are stored as fp8(value * LO_F8_ACT_SCALE) with saturation at the
 // e4m3 maximum (448): 8 covers |value| <= 56 with 3 mantissa bits down to 2^-9 (subnormal step 2.4e-4); the GroupNorm +
 // Mish outputs these buffers hold are O(1).  Weights carry one scale per output channel (lo_pack_f8_kernel).

@@ -175,6 +175,7 @@ struct BnApplyArgs {
   const f16* raw; const float* ss; const float* ls; const f16* identity; f16* y; float* pool_partial;
   int C, dst_pitch, dst_off, mode, rows_per_block;
   const float* cvec;
+  int ss_stride;   // floats between the (scale, shift) tables of consecutive samples: 0 = one table (BatchNorm), 2*C = per sample (BatchNorm + Dropout2d)
 };
 __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   __shared__ float s_red[256 * 8];
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   float sc[8], sh[8], lsv[8], acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sc[j] = a.ss[(c0 + j) * 2];
-    sh[j] = a.ss[(c0 + j) * 2 + 1];
+    sc[j] = a.ss[(size_t)n * a.ss_stride + (c0 + j) * 2];
+    sh[j] = a.ss[(size_t)n * a.ss_stride + (c0 + j) * 2 + 1];
     lsv[j] = a.mode >= 1 ? a.ls[c0 + j] : 1.f;
     acc[j] = 0.f;
   }
@@ -470,7 +471,9 @@ __global__ __launch_bounds__(128) void lo_t_fold_qk_kernel(const float* __restri
   wu[(size_t)r * 128 + cp] = (f16)(0.25f * acc);
   if (cp == 0) ub[r] = 0.25f * accb;
 }
-// WZ[o][(h,c)] = sum_d Wp[o][h16+d] Wv[h16+d][c];  WZ[o][1024] = sum_hd Wp[o][hd] bv[hd];  WZ[o][1025..1087] = 0.  grid 128, block 256
+// WZ[o][(h,c)] = sum_d Wp[o][h16+d] Wv[h16+d][c];  WZ[o][1024] = sum_hd Wp[o][hd] bv[hd];  WZ[o][1025 + h] = sum_d Wp[o][h16+d]
+// bv[h16+d] (the same term per head: with attn_drop the probabilities of head h sum to s_h != 1 and the Z row carries s_h in
+// column 1025 + h and 0 in column 1024);  WZ[o][1033..1087] = 0.  grid 128, block 256
 __global__ __launch_bounds__(256) void lo_t_fold_pv_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
                                                            const float* __restrict__ wp, f16* __restrict__ wz) {
   const int o = blockIdx.x;
@@ -482,6 +485,10 @@ __global__ __launch_bounds__(256) void lo_t_fold_pv_kernel(const float* __restri
       for (int d = 0; d < 16; ++d) acc += wp[o * 128 + h * 16 + d] * wqkv[(size_t)(256 + h * 16 + d) * 128 + c];
     } else if (col == 1024) {
       for (int k = 0; k < 128; ++k) acc += wp[o * 128 + k] * bqkv[256 + k];
+    } else if (col < 1033) {
+      const int h = col - 1025;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) acc += wp[o * 128 + h * 16 + d] * bqkv[256 + h * 16 + d];
     }
     wz[(size_t)o * 1088 + col] = (f16)acc;
   }
@@ -489,13 +496,14 @@ __global__ __launch_bounds__(256) void lo_t_fold_pv_kernel(const float* __restri
 
 // query rows: qin[b*543 + p][128] = fp16(BN(raw[b][qtok(p)]))  (16-byte chunks; thread = (row, chunk))
 __global__ __launch_bounds__(256) void lo_t_gather_q_kernel(const f16* __restrict__ raw, const float* __restrict__ ss,
-                                                            f16* __restrict__ qin, int B) {
+                                                            f16* __restrict__ qin, int B, int ss_stride) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int chunk = gid & 15, row = gid >> 4;
   if (row >= B * 543) return;
   const int b = row / 543, p = row - b * 543;
   const int qtok = p < 512 ? 32 * p : 32 * 511 + (p - 511);
   f16x8 v = *reinterpret_cast<const f16x8*>(raw + ((size_t)b * T_HW + qtok) * 128 + chunk * 8), o;
+  ss += (size_t)b * ss_stride;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * ss[(chunk * 8 + j) * 2] + ss[(chunk * 8 + j) * 2 + 1]);
   *reinterpret_cast<f16x8*>(qin + (size_t)row * 128 + chunk * 8) = o;
@@ -509,8 +517,13 @@ __device__ __forceinline__ int t_off(int row, int ch) { return 256 * row + 16 * 
 // S^T[key][head] = X U^T on MFMA (the key order of the M index is chosen so that the accumulators ARE the A operand of
 // the second product), softmax over the 32 keys (8 in-lane values x 4 lane groups), Z[head][c] = P X on MFMA with X
 // fragments by transposed LDS reads; Z row (8 x 128 fp16 + the constant-one column 1024) -> Z[b*1024 + p][1088].
+// DROP: x = Dropout2d(BN(raw)) through the per-sample (scale, shift) table (ss_stride = 256), attn_drop on the probabilities
+// (element index ((b*543 + p)*8 + head)*32 + key of site `ds`), the per-head sums s_h of the dropped probabilities in
+// columns 1025.. of the Z row (see lo_t_fold_pv_kernel).
+template <bool DROP>
 __global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __restrict__ raw, const float* __restrict__ ss,
-                                                               const f16* __restrict__ U, f16* __restrict__ Z, int B) {
+                                                               const f16* __restrict__ U, f16* __restrict__ Z, int B, int ss_stride,
+                                                               LoDropSite ds, uint32_t thr, float inv_keep) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4][12288];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + wave;
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __rest
   {
     const int c0 = (lane & 15) * 8;
     float sc[8], sh[8];
+    ss += (size_t)b * ss_stride;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = ss[(c0 + j) * 2]; sh[j] = ss[(c0 + j) * 2 + 1]; }
     const f16* src = raw + ((size_t)b * T_HW + 32 * chunk) * 128;
@@ -571,9 +585,28 @@ __global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __rest
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
   f16x8 pf;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) pf[r] = (f16)(e[r] * inv);
   const int r0 = 8 * (g & 1) + 4 * (g >> 1), tq = m >> 2, tp = m & 3;
+  float hsum = 0.f;
+  if (DROP) {
+    // this lane's keys: r0 .. r0+3 (e[0..3]) and 16+r0 .. 16+r0+3 (e[4..7]) of head m (lanes with m >= 8 hold padding)
+    const uint32_t base = ((uint32_t)(b * 543 + p) * 8u + (uint32_t)(m & 7)) * 32u;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const uint32_t i0 = base + hf * 16 + r0;
+      const uint32_t w0 = lo_drop_word(ds, i0 >> 1), w1 = lo_drop_word(ds, (i0 >> 1) + 1);
+      const bool k0 = (w0 & 0xFFFFu) >= thr, k1 = (w0 >> 16) >= thr, k2 = (w1 & 0xFFFFu) >= thr, k3 = (w1 >> 16) >= thr;
+      e[hf * 4 + 0] = k0 ? e[hf * 4 + 0] * inv_keep : 0.f;
+      e[hf * 4 + 1] = k1 ? e[hf * 4 + 1] * inv_keep : 0.f;
+      e[hf * 4 + 2] = k2 ? e[hf * 4 + 2] * inv_keep : 0.f;
+      e[hf * 4 + 3] = k3 ? e[hf * 4 + 3] * inv_keep : 0.f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { pf[r] = (f16)(e[r] * inv); if (DROP) hsum += (float)pf[r]; }
+  if (DROP) {
+    hsum += __shfl_xor(hsum, 16, 64);
+    hsum += __shfl_xor(hsum, 32, 64);
+  }
 #pragma unroll
   for (int ct = 0; ct < 8; ++ct) {
     h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(sx + t_off(r0 + tq, 2 * ct + (tp >> 1)) + 8 * (tp & 1)));
@@ -590,7 +623,61 @@ __global__ __launch_bounds__(256) void lo_t_attn_folded_kernel(const f16* __rest
   f16* dst = Z + (size_t)(b * 1024 + p) * 1088;
   *reinterpret_cast<f16x8*>(dst + lane * 8) = *reinterpret_cast<const f16x8*>(sz + lane * 16);
   *reinterpret_cast<f16x8*>(dst + (64 + lane) * 8) = *reinterpret_cast<const f16x8*>(sz + (64 + lane) * 16);
-  if (lane == 0) *reinterpret_cast<f16x8*>(dst + 1024) = (f16x8){(f16)1.0f, 0, 0, 0, 0, 0, 0, 0};
+  // columns 1024 .. 1039: [1, 0 x 15] without attn_drop, [0, s_0 .. s_7, 0 x 7] with it
+  float sh8[8];
+#pragma unroll
+  for (int hh = 0; hh < 8; ++hh) sh8[hh] = DROP ? __shfl(hsum, hh, 64) : 0.f;
+  if (lane == 0) {
+    *reinterpret_cast<f16x8*>(dst + 1024) = DROP ? (f16x8){(f16)0.f, (f16)sh8[0], (f16)sh8[1], (f16)sh8[2], (f16)sh8[3], (f16)sh8[4], (f16)sh8[5], (f16)sh8[6]}
+                                                 : (f16x8){(f16)1.0f, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<f16x8*>(dst + 1032) = (f16x8){(f16)sh8[7], 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+// ---- dropout glue (train mode with dropout_rate > 0: the sparse shortcuts above do not hold, see lo_teacher_forward) ----------
+// Dropout2d after a BatchNorm: ssb[b][c] = (scale, shift)[c] * (keep(b*C + c) ? 1/(1-p) : 0)   (lunar_evaluator.py:245-246,252-253)
+__global__ void lo_t_drop2d_ss_kernel(const float* __restrict__ ss, float* __restrict__ ssb, int B, int C, LoDropSite ds, uint32_t thr,
+                                      float inv_keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int c = i % C;
+  const float f = lo_drop_keep(ds, (uint32_t)i, thr) ? inv_keep : 0.f;
+  ssb[i * 2] = ss[c * 2] * f;
+  ssb[i * 2 + 1] = ss[c * 2 + 1] * f;
+}
+// feature extractor: cat[pix][192] <- Dropout(BN(cat)) in place (lunar_evaluator.py:108-111); element index pix*192 + c
+__global__ __launch_bounds__(256) void lo_t_cat_bn_drop_kernel(f16* __restrict__ cat, const float* __restrict__ ss, size_t nchunk,
+                                                               LoDropSite ds, uint32_t thr, float inv_keep) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8-channel chunk
+  if (i >= nchunk) return;
+  const int c0 = (int)(i % 24) * 8;
+  f16x8 v = *reinterpret_cast<const f16x8*>(cat + i * 8), o;
+  const uint32_t keep = lo_drop_keep8(ds, (uint32_t)(i * 8), thr);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? (f16)(((float)v[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1]) * inv_keep) : (f16)0.f;
+  *reinterpret_cast<f16x8*>(cat + i * 8) = o;
+}
+// proj_drop: full-resolution conv2 input = Dropout(proj(att)) (lunar_evaluator.py:224-225).  proj(att) is the compact tensor
+// projc [B][1024][128] on image rows 0..7 and fp16(proj.bias) everywhere else (what the dense 1x1 conv stores for a zero
+// attention row).  Element index (b*HW + pix)*128 + c.
+__global__ __launch_bounds__(256) void lo_t_projdrop_kernel(const f16* __restrict__ projc, const float* __restrict__ pbias,
+                                                            f16* __restrict__ out, size_t nchunk, LoDropSite ds, uint32_t thr, float inv_keep) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8-channel chunk of pixel i >> 4
+  if (i >= nchunk) return;
+  const int c0 = (int)(i & 15) * 8;
+  const size_t gp = i >> 4;
+  const int pix = (int)(gp & (T_HW - 1));
+  const size_t b = gp >> 14;
+  f16x8 v, o;
+  if (pix < 1024) v = *reinterpret_cast<const f16x8*>(projc + (b * 1024 + pix) * 128 + c0);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (f16)pbias[c0 + j];
+  }
+  const uint32_t keep = lo_drop_keep8(ds, (uint32_t)(i * 8), thr);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? (f16)((float)v[j] * inv_keep) : (f16)0.f;
+  *reinterpret_cast<f16x8*>(out + i * 8) = o;
 }
 
 // ---- fused block tail -------------------------------------------------------------------------------------------
@@ -737,7 +824,16 @@ struct HeadsArgs {
   float *quality, *weights, *style_out, *prompt_out, *sem_out;   // [B][4], [B][E], [B][emb], [B][emb], [B][1]
   float* raw_q;                  // [B][E][4] pre-weighting quality logits (kept for the backward)
   int B, E, I, emb;
+  // nn.Dropout after the hidden LeakyReLU of the gate and of every head (lunar_evaluator.py:353-397); thr = 0: off
+  uint32_t thr; float inv_keep;
+  LoDropSite ds_gate, ds_q[8], ds_sem, ds_style, ds_prompt;
 };
+// h[o] <- Dropout(h)[o] for sample `row` of a [B][n] hidden layer (element index row*n + o)
+__device__ void t_dropout(float* h, int n, int row, LoDropSite ds, uint32_t thr, float inv_keep, int tid) {
+  if (!thr) return;
+  for (int o = tid; o < n; o += 256) h[o] = lo_drop_keep(ds, (uint32_t)(row * n + o), thr) ? h[o] * inv_keep : 0.f;
+  __syncthreads();
+}
 __device__ void t_layernorm(const float* x, const float* w, const float* b, float* y, float* scratch, int tid) {
   // 128 features; threads 0..127
   float v = tid < 128 ? x[tid] : 0.f;
@@ -769,6 +865,7 @@ __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
   if (tid < 128) xin[tid] = a.pooled_f[n * 128 + tid];
   __syncthreads();
   t_linear(xin, 128, a.g_w1, a.g_b1, h1, a.I, 1, tid);
+  t_dropout(h1, a.I, n, a.ds_gate, a.thr, a.inv_keep, tid);
   t_linear(h1, a.I, a.g_w2, a.g_b2, o2, a.E, 0, tid);
   if (tid == 0) {
     float m = -INFINITY, l = 0.f;
@@ -784,12 +881,14 @@ __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
     __syncthreads();
     t_layernorm(xin, a.q[e].ln_w, a.q[e].ln_b, xn, scratch, tid);
     t_linear(xn, 128, a.q[e].w1, a.q[e].b1, h1, a.I / 4, 1, tid);
+    t_dropout(h1, a.I / 4, n, a.ds_q[e], a.thr, a.inv_keep, tid);
     t_linear(h1, a.I / 4, a.q[e].w2, a.q[e].b2, o2, 4, 0, tid);
     if (tid < 4) { ql[e][tid] = o2[tid]; a.raw_q[((size_t)n * a.E + e) * 4 + tid] = o2[tid]; }
     __syncthreads();
     if (e == 0) {
       t_layernorm(xin, a.sem.ln_w, a.sem.ln_b, xn, scratch, tid);
       t_linear(xn, 128, a.sem.w1, a.sem.b1, h1, a.I / 2, 1, tid);
+      t_dropout(h1, a.I / 2, n, a.ds_sem, a.thr, a.inv_keep, tid);
       t_linear(h1, a.I / 2, a.sem.w2, a.sem.b2, o2, 1, 0, tid);
       if (tid == 0) a.sem_out[n] = 1.f / (1.f + __expf(-o2[0]));
       __syncthreads();
@@ -806,6 +905,7 @@ __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
     float* dst = which ? a.prompt_out : a.style_out;
     t_layernorm(comb, hw.ln_w, hw.ln_b, xn, scratch, tid);
     t_linear(xn, 128, hw.w1, hw.b1, h1, a.I / 2, 1, tid);
+    t_dropout(h1, a.I / 2, n, which ? a.ds_prompt : a.ds_style, a.thr, a.inv_keep, tid);
     t_linear(h1, a.I / 2, hw.w2, hw.b2, o2, a.emb, 0, tid);
     for (int o = tid; o < a.emb; o += 256) dst[(size_t)n * a.emb + o] = o2[o];
     __syncthreads();
@@ -828,6 +928,8 @@ struct HeadsBwdArgs {
   size_t o_q[8][6];                                 // ln_w, ln_b, w1, b1, w2, b2
   float scale;                                      // -(quality_weight/accum) / (B*4)
   int B, E, I;
+  uint32_t thr; float inv_keep;                     // the forward's dropout (same call seed): gate and quality-head hidden layers
+  LoDropSite ds_gate, ds_q[8];
 };
 __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
   __shared__ float x[128], xh[128], ln[128], a1[256], h1[256], dz[8], dw[8], dq[8][4], dh[256], da[256], scratch[8], wts[8];
@@ -867,9 +969,10 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
   }
   __syncthreads();
   for (int i = tid; i < a.I; i += 256) {
+    const float dm = !a.thr ? 1.f : (lo_drop_keep(a.ds_gate, (uint32_t)(n * a.I + i), a.thr) ? a.inv_keep : 0.f);   // d Dropout(h)/dh
     float t = 0.f;
-    for (int e = 0; e < a.E; ++e) { t += a.g_w2[e * a.I + i] * dz[e]; row[a.o_g_w2 + (size_t)e * a.I + i] = dz[e] * h1[i]; }
-    da[i] = t * (a1[i] > 0.f ? 1.f : 0.2f);
+    for (int e = 0; e < a.E; ++e) { t += a.g_w2[e * a.I + i] * dz[e]; row[a.o_g_w2 + (size_t)e * a.I + i] = dz[e] * (h1[i] * dm); }
+    da[i] = t * dm * (a1[i] > 0.f ? 1.f : 0.2f);
     row[a.o_g_b1 + i] = da[i];
   }
   if (tid < a.E) row[a.o_g_b2 + tid] = dz[tid];
@@ -901,9 +1004,10 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
     }
     __syncthreads();
     if (tid < H) {
+      const float dm = !a.thr ? 1.f : (lo_drop_keep(a.ds_q[e], (uint32_t)(n * H + tid), a.thr) ? a.inv_keep : 0.f);
       float t = 0.f;
-      for (int j = 0; j < 4; ++j) { t += hw.w2[j * H + tid] * dq[e][j]; row[a.o_q[e][4] + (size_t)j * H + tid] = dq[e][j] * h1[tid]; }
-      da[tid] = t * (a1[tid] > 0.f ? 1.f : 0.2f);
+      for (int j = 0; j < 4; ++j) { t += hw.w2[j * H + tid] * dq[e][j]; row[a.o_q[e][4] + (size_t)j * H + tid] = dq[e][j] * (h1[tid] * dm); }
+      da[tid] = t * dm * (a1[tid] > 0.f ? 1.f : 0.2f);
       row[a.o_q[e][3] + tid] = da[tid];
     }
     if (tid < 4) row[a.o_q[e][5] + tid] = dq[e][tid];
@@ -972,9 +1076,13 @@ struct LoTeacher {
   bool fuse_tail;             // block tail folded into the next conv1 (LO_T_FUSE_TAIL=0 turns it off)
   size_t o_xc[2], o_kx[8];    // compact rows of x_l (ping-pong), transform constants [3][6][128] fp16 per expert (contiguous)
   size_t o_xc3, o_poolpe;     // compact rows of x_3 of every expert [E][B][1024][128]; pool partials [E][B][64][128]
+  size_t o_ssb;               // per-sample (scale, shift) of a BatchNorm followed by Dropout2d: [B][128][2]
   size_t ws_bytes;
   bool att_zeroed;
   const void* att_zeroed_ws;
+  // dropout of the last forward (lo_teacher_heads_backward replays the head masks), and which path it took:
+  // 0 sparse (constant-field shortcuts), 1 dense (LO_T_DENSE=1), 2 dropout (train mode, dropout_p > 0)
+  float last_p; uint64_t last_seed; int last_path;
 };
 
 // name -> index of the state table: hashed (a forward makes ~1000 of these look-ups; the linear scan over 351 names they used to be
@@ -997,6 +1105,7 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
   LoTeacher* h = new LoTeacher();
   h->B = B; h->E = num_experts; h->I = 256; h->emb = embedding_dim; h->layers = 3;
   h->att_zeroed = false; h->att_zeroed_ws = nullptr;
+  h->last_p = 0.f; h->last_seed = 0; h->last_path = -1;
   // ---- state table in the reference's state_dict order (lunar_evaluator.py; checked against the oracle in tests)
   auto add = [&](const std::string& k, size_t n, bool f = true) { h->names.push_back(k); h->numel.push_back(n); h->is_float.push_back(f); };
   auto conv = [&](const std::string& p, int co, int ci, int k, int groups = 1) { add(p + ".weight", (size_t)co * (ci / groups) * k * k); add(p + ".bias", co); };
@@ -1097,10 +1206,12 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
       h->o_cvec[e][l] = take(6 * 128 * 4);
       h->o_wu[e][l] = take((size_t)1024 * 128 * 2); h->o_ub[e][l] = take(1024 * 4); h->o_wz[e][l] = take((size_t)128 * 1088 * 2);
     }
+  h->o_ssb = take((size_t)B * 128 * 2 * 4);
   h->ws_bytes = off;
   *out = h;
   return LO_OK;
 }
+extern "C" int lo_teacher_last_path(const LoTeacher* h) { return h ? h->last_path : -1; }
 extern "C" void lo_teacher_destroy(LoTeacher* h) { delete h; }
 extern "C" int lo_teacher_num_tensors(const LoTeacher* h) { return (int)h->names.size(); }
 extern "C" const char* lo_teacher_tensor_name(const LoTeacher* h, int i) { return (i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : nullptr; }
@@ -1157,8 +1268,9 @@ static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, co
   return LO_OK;
 }
 static int t_bn_apply(LoTeacher* h, const f16* raw, const float* ls, const f16* identity, f16* y, int C, int dst_pitch, int dst_off,
-                      int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr) {
-  BnApplyArgs a{raw, TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode, T_HW / 64, cvec};
+                      int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr, bool per_sample = false) {
+  BnApplyArgs a{raw, per_sample ? TW(float, h->o_ssb) : TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode,
+                T_HW / 64, cvec, per_sample ? 2 * C : 0};
   LoProfScope _p(mode ? "lo_bn_apply (block tail)" : "lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode == 1 ? 3 : 2), st);
   hipLaunchKernelGGL(lo_bn_apply_kernel, dim3(64, h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("bn_apply");
@@ -1173,16 +1285,33 @@ static int t_pool(LoTeacher* h, float* pooled, int C, void* ws, hipStream_t st) 
 
 // x: fp32 NCHW images.  P: flat state (parameters AND BatchNorm running statistics; the latter are updated in place when
 // training != 0).  outputs: quality_scores [B,4], expert_weights [B,E], style/prompt embeddings [B,emb], semantic [B,1].
-extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* ws, int training, float* quality, float* weights,
-                                  float* style, float* prompt, float* semantic, void* stream) {
+// dropout_p / drop_seed: train mode applies the reference's six dropout sites with probability dropout_p from the counter RNG
+// stream drop_seed (lo_common.h); the constant-field shortcuts of the sparse path do not survive proj_drop, so that call runs
+// every convolution in full (path 2).  Eval mode, or dropout_p = 0: no dropout, sparse path.
+extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* ws, int training, float dropout_p, uint64_t drop_seed,
+                                  float* quality, float* weights, float* style, float* prompt, float* semantic, void* stream) {
   // all five output pointers null = statistics-only call: everything that feeds a BatchNorm layer runs (the running
   // statistics are the call's side effect), the pooling of the last block and the heads do not.  This is the first
   // teacher call of _process_batch (train_hybrid.py:853-855), whose outputs the reference overwrites before use.
   const bool stats_only = !quality && !weights && !style && !prompt && !semantic;
   LO_REQUIRE(h && x && P && ws && (stats_only || (quality && weights && style && prompt && semantic)), "lo_teacher_forward: null argument");
+  LO_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "lo_teacher_forward: dropout_p %g outside [0, 1)", (double)dropout_p);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int B = h->B;
   const size_t px = (size_t)B * T_HW;
+  const bool drop = training && dropout_p > 0.f;
+  uint32_t thr = drop ? (uint32_t)lrintf(dropout_p * 65536.f) : 0u;
+  if (drop && thr == 0) thr = 1;
+  const float inv_keep = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  h->last_p = drop ? dropout_p : 0.f; h->last_seed = drop_seed;
+  h->last_path = drop ? 2 : (h->sparse ? 0 : 1);
+  auto site = [&](uint32_t s) { return lo_drop_site_keys(drop_seed, s); };
+  auto drop2d = [&](uint32_t s) -> int {     // o_ss (BatchNorm) -> o_ssb (BatchNorm + Dropout2d, per sample)
+    hipLaunchKernelGGL(lo_t_drop2d_ss_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, st, TW(float, h->o_ss), TW(float, h->o_ssb), B, 128,
+                       site(s), thr, inv_keep);
+    LO_LAUNCH_CHECK("t_drop2d_ss");
+    return LO_OK;
+  };
   if (!h->att_zeroed || h->att_zeroed_ws != ws) {
     LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
     LO_HIP(hipMemsetAsync(TW(void, h->o_Z), 0, (size_t)B * 1024 * 1088 * 2, st));    // rows >= 543 of every sample stay zero
@@ -1217,11 +1346,23 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     int mt = (int)(px / lo_conv_tile_m(h->gpw));
     LO_TRYT(t_bn_finalize(h, bnp, mt, 64, q + ".3", P, ws, training, st, 1, 1, nullptr, TW(float, h->o_ss_cat) + 128 * b));
   }
-  // the branch BatchNorms fold into the fusion conv (see lo_t_fold_fusion_kernel)
-  hipLaunchKernelGGL(lo_t_fold_fusion_kernel, dim3(128), dim3(256), 0, st, TP(fe + ".fusion.0.weight"), TP(fe + ".fusion.0.bias"),
-                     TW(float, h->o_ss_cat), TW(f16, h->o_wfus_fold), TW(float, h->o_bfus_fold));
-  LO_LAUNCH_CHECK("t_fold_fusion");
-  LO_TRYT(lo_conv_run(h->gfus, TW(f16, h->o_cat), TW(f16, h->o_wfus_fold), TW(float, h->o_bfus_fold), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+  if (drop) {
+    // Dropout sits between the branch BatchNorms and the fusion conv (lunar_evaluator.py:108-111): normalise + drop in place
+    {
+      LoProfScope _p("lo_t_cat_bn_drop", 0, 4.0 * px * 192, st);
+      const size_t nchunk = px * 24;
+      hipLaunchKernelGGL(lo_t_cat_bn_drop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_cat), TW(float, h->o_ss_cat),
+                         nchunk, site(LO_DS_FE), thr, inv_keep);
+    }
+    LO_LAUNCH_CHECK("t_cat_bn_drop");
+    LO_TRYT(lo_conv_run(h->gfus, TW(f16, h->o_cat), TW(f16, h->o_wfus), TP(fe + ".fusion.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+  } else {
+    // the branch BatchNorms fold into the fusion conv (see lo_t_fold_fusion_kernel)
+    hipLaunchKernelGGL(lo_t_fold_fusion_kernel, dim3(128), dim3(256), 0, st, TP(fe + ".fusion.0.weight"), TP(fe + ".fusion.0.bias"),
+                       TW(float, h->o_ss_cat), TW(f16, h->o_wfus_fold), TW(float, h->o_bfus_fold));
+    LO_LAUNCH_CHECK("t_fold_fusion");
+    LO_TRYT(lo_conv_run(h->gfus, TW(f16, h->o_cat), TW(f16, h->o_wfus_fold), TW(float, h->o_bfus_fold), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+  }
   LO_TRYT(t_bn_finalize(h, bnp, (int)(px / lo_conv_tile_m(h->gfus)), 128, fe + ".fusion.2", P, ws, training, st));
   LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_feat), 128, 128, 0, 0, TW(float, h->o_poolp), ws, st));
   LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
@@ -1232,6 +1373,47 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     for (int l = 0; l < 3; ++l) {
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
       f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
+      if (drop) {
+        // ---- dropout path: both 3x3 convs in full, the attention still folded (only 543 positions of its output are ever
+        //      non-zero BEFORE proj_drop; Dropout2d is a per-sample channel scale that rides on the BatchNorm table)
+        const bool pp = lo_conv3_pp_applies(h->g3);
+        auto conv3 = [&](const char* tag, const f16* in, const f16* w, const float* bias, f16* out) -> int {
+          if (pp) { LO_TAGGED(tag, lo_conv3_run_pp_xf(h->g3, in, nullptr, nullptr, 0, w, bias, out, st, &ex)); }
+          else { LO_TAGGED(tag, lo_conv_run(h->g3, in, w, bias, nullptr, out, nullptr, nullptr, 1, st, nullptr, &ex)); }
+          return LO_OK;
+        };
+        const int rows3 = pp ? B * 64 : mt3;
+        LO_TRYT(conv3("t_conv1 (dense, dropout path)", xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), TW(f16, h->o_rawA)));
+        LO_TRYT(t_bn_finalize(h, bnp, rows3, 128, p + ".conv1.2", P, ws, training, st));
+        LO_TRYT(drop2d(LO_DS_BLOCK(e, l, 0)));
+        {
+          LoProfScope _p("lo_t_gather_q", 0, 0, st);
+          hipLaunchKernelGGL(lo_t_gather_q_kernel, dim3((B * 543 * 16 + 255) / 256), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ssb), TW(f16, h->o_qin), B, 256);
+        }
+        LO_LAUNCH_CHECK("t_gather_q");
+        LO_TAGGED("t_U (igemm)", lo_conv_run(h->gU, TW(f16, h->o_qin), TW(f16, h->o_wu[e][l]), TW(float, h->o_ub[e][l]), nullptr, TW(f16, h->o_U), nullptr, nullptr, 1, st));
+        {
+          LoProfScope _p("lo_t_attn_folded", 2.0 * B * 543 * 2 * 8 * 32 * 128, 2.0 * px * 128 + 2.0 * B * 543 * 2112, st);
+          hipLaunchKernelGGL((lo_t_attn_folded_kernel<true>), dim3((B * 543 + 3) / 4), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ssb), TW(f16, h->o_U),
+                             TW(f16, h->o_Z), B, 256, site(LO_DS_BLOCK(e, l, 1)), thr, inv_keep);
+        }
+        LO_LAUNCH_CHECK("t_attn_folded");
+        LO_TAGGED("t_proj (igemm)", lo_conv_run(h->gZ, TW(f16, h->o_Z), TW(f16, h->o_wz[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_projc), nullptr, nullptr, 1, st));
+        {
+          LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * 128, st);
+          const size_t nchunk = px * 16;
+          hipLaunchKernelGGL(lo_t_projdrop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
+                             TW(f16, h->o_proj), nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
+        }
+        LO_LAUNCH_CHECK("t_projdrop");
+        LO_TRYT(conv3("t_conv2 (dense, dropout path)", TW(f16, h->o_proj), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), TW(f16, h->o_rawB)));
+        LO_TRYT(t_bn_finalize(h, bnp, rows3, 128, p + ".conv2.2", P, ws, training, st));
+        LO_TRYT(drop2d(LO_DS_BLOCK(e, l, 3)));
+        LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 1, (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st,
+                           nullptr, true));
+        xin = xout;
+        continue;
+      }
       if (h->fuse_tail) {
         // conv1 reads the expert's input and applies the l previous block tails to its LDS patch (rows 0..7: xc)
         LO_TAGGED(l ? "t_conv1 (fused tap, tail on load)" : "t_conv1 (fused tap)",
@@ -1246,13 +1428,14 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         // folded attention: BN(conv1) is applied on the fly, k / v never exist (see lo_t_attn_folded_kernel)
         {
           LoProfScope _p("lo_t_gather_q", 0, 0, st);
-          hipLaunchKernelGGL(lo_t_gather_q_kernel, dim3((B * 543 * 16 + 255) / 256), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ss), TW(f16, h->o_qin), B);
+          hipLaunchKernelGGL(lo_t_gather_q_kernel, dim3((B * 543 * 16 + 255) / 256), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ss), TW(f16, h->o_qin), B, 0);
         }
         LO_LAUNCH_CHECK("t_gather_q");
         LO_TAGGED("t_U (igemm)", lo_conv_run(h->gU, TW(f16, h->o_qin), TW(f16, h->o_wu[e][l]), TW(float, h->o_ub[e][l]), nullptr, TW(f16, h->o_U), nullptr, nullptr, 1, st));
         {
           LoProfScope _p("lo_t_attn_folded", 2.0 * B * 543 * 2 * 8 * 32 * 128, 2.0 * px * 128 + 2.0 * B * 543 * 2112, st);
-          hipLaunchKernelGGL(lo_t_attn_folded_kernel, dim3((B * 543 + 3) / 4), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ss), TW(f16, h->o_U), TW(f16, h->o_Z), B);
+          hipLaunchKernelGGL((lo_t_attn_folded_kernel<false>), dim3((B * 543 + 3) / 4), dim3(256), 0, st, TW(f16, h->o_rawA), TW(float, h->o_ss), TW(f16, h->o_U), TW(f16, h->o_Z), B,
+                             0, LoDropSite{0u, 0u}, 0u, 1.0f);
         }
         LO_LAUNCH_CHECK("t_attn_folded");
         LO_TAGGED("t_proj (igemm)", lo_conv_run(h->gZ, TW(f16, h->o_Z), TW(f16, h->o_wz[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_projc), nullptr, nullptr, 1, st));
@@ -1290,10 +1473,10 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
       LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 1, l == 2 ? TW(float, h->o_poolp) : nullptr, ws, st));
       xin = xout;
     }
-    if (!h->fuse_tail) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
+    if ((drop && !stats_only) || (!drop && !h->fuse_tail)) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
   }
   if (stats_only) return LO_OK;
-  if (h->fuse_tail) {
+  if (h->fuse_tail && !drop) {
     // x_3 of every expert is pooled in ONE pass over feat (the full-resolution x_l were never written)
     {
       LoProfScope _p("lo_t_pool (tail on load)", 0, 2.0 * px * 128, st);
@@ -1321,11 +1504,30 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   a.quality = quality; a.weights = weights; a.style_out = style; a.prompt_out = prompt; a.sem_out = semantic;
   a.raw_q = TW(float, h->o_rawq);
   a.B = B; a.E = h->E; a.I = h->I; a.emb = h->emb;
+  a.thr = thr; a.inv_keep = inv_keep;
+  a.ds_gate = site(LO_DS_GATE); a.ds_sem = site(LO_DS_SEM); a.ds_style = site(LO_DS_STYLE); a.ds_prompt = site(LO_DS_PROMPT);
+  for (int e = 0; e < h->E; ++e) a.ds_q[e] = site(LO_DS_QUALITY(e));
   {
     LoProfScope _p("lo_t_heads", 0, 0, st);
     hipLaunchKernelGGL(lo_t_heads_kernel, dim3(B), dim3(256), 0, st, a);
   }
   LO_LAUNCH_CHECK("t_heads");
+  return LO_OK;
+}
+
+// the keep decisions of one dropout site as bytes (what lo_teacher_forward applies for this call seed): checked bit for bit
+// against oracle/dropout_ref.py by the tests
+__global__ void lo_dropout_mask_kernel(uint8_t* __restrict__ keep, size_t n, LoDropSite ds, uint32_t thr) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keep[i] = lo_drop_keep(ds, (uint32_t)i, thr) ? 1 : 0;
+}
+extern "C" int lo_dropout_mask(uint64_t drop_seed, int site, float dropout_p, size_t n, uint8_t* keep, void* stream) {
+  LO_REQUIRE(keep && site >= 0 && dropout_p > 0.f && dropout_p < 1.f && n < ((size_t)1 << 32), "lo_dropout_mask: bad argument");
+  uint32_t thr = (uint32_t)lrintf(dropout_p * 65536.f);
+  if (thr == 0) thr = 1;
+  hipLaunchKernelGGL(lo_dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keep, n,
+                     lo_drop_site_keys(drop_seed, (uint32_t)site), thr);
+  LO_LAUNCH_CHECK("dropout_mask");
   return LO_OK;
 }
 
@@ -1359,6 +1561,11 @@ extern "C" int lo_teacher_heads_backward(LoTeacher* h, const float* P, void* ws,
   a.rows = rows; a.row_len = b1 - b0;
   a.scale = -coef / ((float)h->B * 4.f);
   a.B = h->B; a.E = h->E; a.I = h->I;
+  a.thr = h->last_p > 0.f ? (uint32_t)lrintf(h->last_p * 65536.f) : 0u;
+  if (h->last_p > 0.f && a.thr == 0) a.thr = 1;
+  a.inv_keep = h->last_p > 0.f ? 1.0f / (1.0f - h->last_p) : 1.0f;
+  a.ds_gate = lo_drop_site_keys(h->last_seed, LO_DS_GATE);
+  for (int e = 0; e < h->E; ++e) a.ds_q[e] = lo_drop_site_keys(h->last_seed, LO_DS_QUALITY(e));
   LO_HIP(hipMemsetAsync(rows, 0, (size_t)h->B * a.row_len * sizeof(float), st));   // alignment padding inside the rows
   hipLaunchKernelGGL(lo_t_heads_bwd_kernel, dim3(h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("t_heads_bwd");

@@ -8,10 +8,16 @@ unit norms, ``rel_pos ~ N(0, 0.02)``, ``layer_scale = 0.1``), ``forward(x, promp
 six-key dict.  The sub-modules are containers; ``forward`` is one native call (``lo_teacher_forward``) that reproduces
 the forward AS EXECUTED — including the chunk-index write offset of ``PixelArtAttention``.
 
-Limits of this round (stated, enforced): ``feature_dim == 128`` (the CLI default), dropout is not applied (the
-reference's dropout masks come from the global RNG and cannot be matched on another device anyway; parity is checked
-against the reference built with ``dropout_rate=0``), forward only (the gate / quality-head gradients of
-``teacher_loss``, SURVEY §8 row A13, are not built yet), ``feature_maps`` is always ``None``.
+Dropout (``dropout_rate``, default 0.1 like the reference; lunar_evaluator.py:97-99,139-140,212,225,246,253,353-397): in
+train mode all six sites are applied on the device with torch semantics (``nn.Dropout`` elementwise, ``nn.Dropout2d`` per
+(sample, channel), kept values scaled by 1/(1-p)).  The masks come from a counter RNG keyed by (torch seed, rank, call,
+site, element) — ``oracle/dropout_ref.py`` regenerates them bit-exactly, which is how the parity tests run the CPU oracle
+and the reference itself on the same masks.  With dropout the native forward runs every 3x3 convolution in full (the
+constant-field shortcuts of the p = 0 path do not survive ``proj_drop``); eval mode and ``dropout_rate=0`` take the
+shortcut path.  The gate / quality-head gradients of ``teacher_loss`` are ``lo_teacher_heads_backward``
+(driven by ``trainer.HybridStepper``).
+
+Limits (stated, enforced): ``feature_dim == 128`` (the CLI default), ``feature_maps`` is always ``None``.
 """
 from __future__ import annotations
 
@@ -68,6 +74,28 @@ class ExpertBlock(nn.Module):
         self.layer_scale = nn.Parameter(torch.ones(1, out_channels, 1, 1) * layer_scale_init)
 
 
+class _TeacherEngine:
+    """Native plan + workspace for one batch size; the handle is released with the object (lo_teacher_destroy)."""
+
+    def __init__(self, model: "LunarMoETeacher", batch: int):
+        h = C.c_void_p()
+        _lib.check(_lib.lib.lo_teacher_create(batch, model.num_experts, model.feature_dim, model.embedding_dim, C.byref(h)), "lo_teacher_create")
+        self.handle = h
+        self.ws = torch.empty(_lib.lib.lo_teacher_workspace_bytes(h), dtype=torch.uint8, device=model._flat.device)
+        self.packed_version = -1
+
+    def __iter__(self):          # (handle, workspace, packed version): the tuple form older call sites unpack
+        return iter((self.handle, self.ws, self.packed_version))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h is not None:
+            try:
+                _lib.lib.lo_teacher_destroy(h)
+            except Exception:
+                pass
+
+
 class LunarMoETeacher(nn.Module):
     def __init__(self, num_experts=4, feature_dim=128, dropout_rate=0.1, rel_pos_size=8, use_checkpointing=True,
                  expert_layers=3, intermediate_dim=256, embedding_dim=64):
@@ -100,8 +128,10 @@ class LunarMoETeacher(nn.Module):
         self.apply(self._init_weights)
         self._flat: Optional[torch.Tensor] = None
         self._nbt: Optional[torch.Tensor] = None      # the BatchNorm step counters, stacked (see _ensure_flat)
-        self._engines: Dict[int, tuple] = {}
+        self._engines: Dict[int, "_TeacherEngine"] = {}
         self._weights_version = 0
+        self._drop_seed: Optional[int] = None     # counter-RNG stream of the dropout masks; derived at the first train-mode forward
+        self.last_drop_seed: Optional[int] = None  # the seed the last forward ran with (tests regenerate its masks from it)
 
     @staticmethod
     def _init_weights(m):
@@ -176,15 +206,38 @@ class LunarMoETeacher(nn.Module):
         self._ensure_flat()
         eng = self._engines.get(batch)
         if eng is None:
-            h = C.c_void_p()
-            _lib.check(_lib.lib.lo_teacher_create(batch, self.num_experts, self.feature_dim, self.embedding_dim, C.byref(h)), "lo_teacher_create")
-            ws = torch.empty(_lib.lib.lo_teacher_workspace_bytes(h), dtype=torch.uint8, device=self._flat.device)
-            eng = [h, ws, -1]
+            eng = _TeacherEngine(self, batch)
             self._engines[batch] = eng
-        if eng[2] != self._weights_version:
-            _lib.check(_lib.lib.lo_teacher_pack(eng[0], self._flat.data_ptr(), eng[1].data_ptr(), _lib.stream_ptr()), "lo_teacher_pack")
-            eng[2] = self._weights_version
+        if eng.packed_version != self._weights_version:
+            _lib.check(_lib.lib.lo_teacher_pack(eng.handle, self._flat.data_ptr(), eng.ws.data_ptr(), _lib.stream_ptr()), "lo_teacher_pack")
+            eng.packed_version = self._weights_version
         return eng
+
+    # ---- dropout stream -----------------------------------------------------------------------------------
+    def set_dropout_stream(self, seed: int, exact_next: bool = False) -> None:
+        """Restart the dropout mask stream from ``seed`` (otherwise derived from ``torch.initial_seed()`` and the rank).
+        ``exact_next``: the next train-mode forward uses ``seed`` itself as its call seed (parity tests)."""
+        self._drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._drop_exact = bool(exact_next)
+
+    def _next_drop_seed(self) -> int:
+        """One 64-bit stream value per forward call (the same scheme as the VAE's noise stream, vae.py): keyed by the torch
+        seed (`--seed`, train_hybrid.py:1138-1141) and the rank, advanced by an LCG per call."""
+        if self._drop_seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._drop_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0xD209 + 0xD1B54A32D192ED03 * rank) & 0xFFFFFFFFFFFFFFFF
+        if getattr(self, "_drop_exact", False):
+            self._drop_exact = False
+        else:
+            self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        self.last_drop_seed = self._drop_seed
+        return self._drop_seed
+
+    def last_path(self, batch: int) -> int:
+        """0 = sparse shortcuts, 1 = dense (LO_T_DENSE=1), 2 = dropout path; -1 before the first forward of that batch size."""
+        eng = self._engines.get(batch)
+        return -1 if eng is None else int(_lib.lib.lo_teacher_last_path(eng.handle))
 
     def update_statistics_only(self, x: torch.Tensor) -> None:
         """The side effects of `forward(x)` in train mode without its outputs: every BatchNorm layer sees the batch
@@ -195,8 +248,10 @@ class LunarMoETeacher(nn.Module):
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
             raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
-        h, ws, _ = self._engine(x.shape[0])
-        _lib.check(_lib.lib.lo_teacher_forward(h, x.data_ptr(), self._flat.data_ptr(), ws.data_ptr(), 1, None, None, None, None, None,
+        eng = self._engine(x.shape[0])
+        p = float(self.dropout_rate)
+        _lib.check(_lib.lib.lo_teacher_forward(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), 1, p,
+                                               self._next_drop_seed() if p > 0 else 0, None, None, None, None, None,
                                                _lib.stream_ptr()), "lo_teacher_forward(statistics only)")
         with torch.no_grad():
             self._nbt += 1
@@ -208,14 +263,16 @@ class LunarMoETeacher(nn.Module):
             raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
         B = x.shape[0]
-        h, ws, _ = self._engine(B)
+        eng = self._engine(B)
         dev = x.device
         q = torch.empty(B, 4, dtype=torch.float32, device=dev)
         w = torch.empty(B, self.num_experts, dtype=torch.float32, device=dev)
         st = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
         pr = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
         sem = torch.empty(B, 1, dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib.lo_teacher_forward(h, x.data_ptr(), self._flat.data_ptr(), ws.data_ptr(), 1 if self.training else 0,
+        p = float(self.dropout_rate) if self.training else 0.0
+        _lib.check(_lib.lib.lo_teacher_forward(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), 1 if self.training else 0,
+                                               p, self._next_drop_seed() if p > 0 else 0,
                                                q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
                                                _lib.stream_ptr()), "lo_teacher_forward")
         if self.training:

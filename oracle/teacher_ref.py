@@ -8,8 +8,10 @@ Plain-PyTorch fp32 restatement of /root/reference/lunar_evaluator.py:57-462 on a
     INDEX, so the final map holds chunk_p.row0 at p <= 511, chunk_511.rows 1..31 at p = 512..542 and zeros elsewhere;
   * ``prompt_embedding`` passed by the caller is overwritten before use (:438), cosine similarity with itself is 1;
   * BatchNorm2d runs with batch statistics in training mode (and updates its running stats, returned separately).
-Dropout is stochastic in the reference; the oracle takes ``dropout_rate = 0`` (parity runs construct the reference
-with ``dropout_rate=0.0``).  Parity status: PINNED by oracle/make_golden.py (fixtures tests/golden/teacher_*.npz).
+Dropout is stochastic in the reference; the oracle applies it at the reference's six sites (:97-99,108; :139-140,212,225;
+:246,253; :353-397) from an explicit mask provider (``oracle/dropout_ref.TeacherMasks``: the masks the native library draws
+for a given call seed), or not at all (``masks=None`` = ``dropout_rate 0``).  Parity status: PINNED by oracle/make_golden.py
+(fixtures tests/golden/teacher_*.npz; the dropout fixture runs the reference itself on the same injected masks).
 """
 from __future__ import annotations
 
@@ -133,7 +135,7 @@ def _bn(x, S, p, training, new_stats):
     return (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS) * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
 
 
-def feature_extractor(x, S, training, new_stats):
+def feature_extractor(x, S, training, new_stats, masks=None):
     """lunar_evaluator.py:105-112."""
     p = "feature_extractor"
     h = _bn(F.leaky_relu(F.conv2d(x, S[p + ".conv1.0.weight"], S[p + ".conv1.0.bias"], padding=1), 0.2), S, p + ".conv1.2", training, new_stats)
@@ -144,12 +146,16 @@ def feature_extractor(x, S, training, new_stats):
         t = F.conv2d(t, S[q + ".1.weight"], S[q + ".1.bias"])
         outs.append(_bn(F.leaky_relu(t, 0.2), S, q + ".3", training, new_stats))
     c = torch.cat(outs, dim=1)
+    if masks is not None:
+        from .dropout_ref import DS_FE
+        c = c * masks.elementwise_nchw(DS_FE, 192)                       # self.dropout(combined), :108
     f = F.conv2d(c, S[p + ".fusion.0.weight"], S[p + ".fusion.0.bias"])
     return _bn(F.leaky_relu(f, 0.2), S, p + ".fusion.2", training, new_stats)
 
 
-def attention_as_executed(x, S, p, num_heads=8, chunk=32):
-    """PixelArtAttention.forward (lunar_evaluator.py:188-227) in closed form (see module docstring)."""
+def attention_as_executed(x, S, p, num_heads=8, chunk=32, att_mask=None, proj_mask=None):
+    """PixelArtAttention.forward (lunar_evaluator.py:188-227) in closed form (see module docstring).  att_mask: [B, 543,
+    heads, chunk] multiplicative attn_drop mask of the rows that reach the output; proj_mask: [B, C, H, W] (proj_drop)."""
     B, C, H, W = x.shape
     N, hd = H * W, C // num_heads
     qkv = F.conv2d(x, S[p + ".qkv.weight"], S[p + ".qkv.bias"])
@@ -159,58 +165,82 @@ def attention_as_executed(x, S, p, num_heads=8, chunk=32):
     k = qkv[:, 1].reshape(B, num_heads, nchunk, chunk, hd)
     v = qkv[:, 2].reshape(B, num_heads, nchunk, chunk, hd)
     att = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) * (hd ** -0.5), dim=-1)   # rel-pos term: softmax-invariant
+    if att_mask is not None:                                                           # attn_drop (:212) on the surviving rows
+        att = att.clone()
+        att[:, :, :, 0, :] = att[:, :, :, 0, :] * att_mask[:, :nchunk].permute(0, 2, 1, 3)
+        att[:, :, nchunk - 1, 1:, :] = att[:, :, nchunk - 1, 1:, :] * att_mask[:, nchunk:].permute(0, 2, 1, 3)
     co = torch.matmul(att, v)                                                          # [B,heads,nchunk,chunk,hd]
     out = torch.zeros(B, num_heads, N, hd, dtype=x.dtype)
     out[:, :, :nchunk] = co[:, :, :, 0]                      # p <= nchunk-1 : row 0 of chunk p
     out[:, :, nchunk:nchunk + chunk - 1] = co[:, :, nchunk - 1, 1:]   # rows 1..31 of the last chunk
     out = out.permute(0, 1, 3, 2).reshape(B, C, H, W)
-    return F.conv2d(out, S[p + ".proj.weight"], S[p + ".proj.bias"])
+    out = F.conv2d(out, S[p + ".proj.weight"], S[p + ".proj.bias"])
+    return out if proj_mask is None else out * proj_mask                               # proj_drop (:225)
 
 
-def expert_block(x, S, p, training, new_stats):
+def expert_block(x, S, p, training, new_stats, masks=None, e=0, l=0):
     """ExpertBlock.forward (lunar_evaluator.py:260-275)."""
+    m1 = am = pm = m2 = None
+    if masks is not None:
+        from .dropout_ref import ds_block
+        C = S[p + ".conv1.0.weight"].shape[0]
+        m1, m2 = masks.channelwise(ds_block(e, l, 0), C), masks.channelwise(ds_block(e, l, 3), C)
+        am, pm = masks.attention(ds_block(e, l, 1)), masks.elementwise_nchw(ds_block(e, l, 2), C)
     if (p + ".shortcut.0.weight") in S:
         idt = _bn(F.conv2d(x, S[p + ".shortcut.0.weight"], S[p + ".shortcut.0.bias"]), S, p + ".shortcut.1", training, new_stats)
     else:
         idt = x
     o = _bn(F.leaky_relu(F.conv2d(x, S[p + ".conv1.0.weight"], S[p + ".conv1.0.bias"], padding=1), 0.2), S, p + ".conv1.2", training, new_stats)
-    o = attention_as_executed(o, S, p + ".attention")
+    if m1 is not None:
+        o = o * m1                                                                     # Dropout2d (:246)
+    o = attention_as_executed(o, S, p + ".attention", att_mask=am, proj_mask=pm)
     o = _bn(F.leaky_relu(F.conv2d(o, S[p + ".conv2.0.weight"], S[p + ".conv2.0.bias"], padding=1), 0.2), S, p + ".conv2.2", training, new_stats)
+    if m2 is not None:
+        o = o * m2                                                                     # Dropout2d (:253)
     return F.leaky_relu(o * S[p + ".layer_scale"] + idt, 0.2)
 
 
-def _head(pooled, S, p, final=None):
-    """AdaptiveAvgPool -> Flatten -> LayerNorm -> Linear -> LeakyReLU -> (Dropout) -> Linear [-> Sigmoid]."""
+def _head(pooled, S, p, final=None, mask=None):
+    """AdaptiveAvgPool -> Flatten -> LayerNorm -> Linear -> LeakyReLU -> Dropout -> Linear [-> Sigmoid]."""
     h = F.layer_norm(pooled, (pooled.shape[1],), S[p + ".2.weight"], S[p + ".2.bias"], LN_EPS)
     h = F.leaky_relu(F.linear(h, S[p + ".3.weight"], S[p + ".3.bias"]), 0.2)
+    if mask is not None:
+        h = h * mask
     h = F.linear(h, S[p + ".6.weight"], S[p + ".6.bias"])
     return torch.sigmoid(h) if final == "sigmoid" else h
 
 
-def teacher_forward(x, S: Dict[str, torch.Tensor], training: bool = True, num_experts=4, expert_layers=3):
-    """LunarMoETeacher.forward (lunar_evaluator.py:408-462), dropout 0.  Returns (outputs, new BN running stats)."""
+def teacher_forward(x, S: Dict[str, torch.Tensor], training: bool = True, num_experts=4, expert_layers=3, masks=None):
+    """LunarMoETeacher.forward (lunar_evaluator.py:408-462).  masks: dropout_ref.TeacherMasks (train mode with dropout) or
+    None (no dropout).  Returns (outputs, new BN running stats)."""
+    from . import dropout_ref as D
+    if not training:
+        masks = None
+    hm = (lambda site, width: masks.rows(site, width)) if masks is not None else (lambda site, width: None)
     new_stats: Dict[str, torch.Tensor] = {}
-    feats = feature_extractor(x, S, training, new_stats)
+    feats = feature_extractor(x, S, training, new_stats, masks)
     pooled = feats.mean(dim=(2, 3))
     g = F.leaky_relu(F.linear(pooled, S["gate.2.weight"], S["gate.2.bias"]), 0.2)
+    if masks is not None:
+        g = g * masks.rows(D.DS_GATE, g.shape[1])                                      # gate Dropout (:358)
     w = torch.softmax(F.linear(g, S["gate.5.weight"], S["gate.5.bias"]), dim=1)
     q_all, pooled_e = [], []
     sem_feat = None
     for e in range(num_experts):
         h = feats
         for l in range(expert_layers):
-            h = expert_block(h, S, f"experts.{e}.{l}", training, new_stats)
+            h = expert_block(h, S, f"experts.{e}.{l}", training, new_stats, masks, e, l)
         pe = h.mean(dim=(2, 3))
         pooled_e.append(pe)
-        q_all.append(_head(pe, S, f"quality_heads.{e}"))
+        q_all.append(_head(pe, S, f"quality_heads.{e}", mask=hm(D.ds_quality(e), S[f"quality_heads.{e}.3.weight"].shape[0])))
         if e == 0:
             sem_feat = pe
     qt = torch.stack(q_all, dim=1)
     weighted_q = (qt * w.unsqueeze(-1)).sum(dim=1)
     comb = (torch.stack(pooled_e, dim=1) * w.unsqueeze(-1)).sum(dim=1)
-    style = _head(comb, S, "style_net")
-    prompt = _head(comb, S, "prompt_net")
-    sem = _head(sem_feat, S, "semantic_head", final="sigmoid") * 1.0     # cosine_similarity(p, p.detach()) == 1
+    style = _head(comb, S, "style_net", mask=hm(D.DS_STYLE, S["style_net.3.weight"].shape[0]))
+    prompt = _head(comb, S, "prompt_net", mask=hm(D.DS_PROMPT, S["prompt_net.3.weight"].shape[0]))
+    sem = _head(sem_feat, S, "semantic_head", final="sigmoid", mask=hm(D.DS_SEM, S["semantic_head.3.weight"].shape[0])) * 1.0     # cosine_similarity(p, p.detach()) == 1
     out = {"quality_scores": torch.sigmoid(weighted_q), "expert_weights": w, "style_embedding": style,
            "prompt_embedding": prompt, "semantic_score": sem}
     return out, new_stats

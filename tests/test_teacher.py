@@ -257,3 +257,152 @@ def test_teacher_odd_batch_sizes(B):
         ref, _ = T.teacher_forward(x, S, training=True)
     for k, t in {"quality_scores": 2e-3, "expert_weights": 2e-3, "semantic_score": 2e-3, "style_embedding": 2e-2}.items():
         assert (out[k].cpu() - ref[k]).abs().max().item() <= t, k
+
+
+# ---- dropout (the reference's default: dropout_rate 0.1, train mode) ------------------------------------------------------
+def test_dropout_reference_fixture_matches_oracle_with_the_same_masks():
+    """CPU: tests/golden/teacher_drop_B2.npz was produced by the REFERENCE teacher (dropout 0.1, train mode) with its own
+    nn.Dropout modules hooked to apply the masks of oracle/dropout_ref for DROP_SEED; the oracle on the same masks agrees."""
+    from oracle import dropout_ref as D
+    g = np.load(os.path.join(GOLD, "teacher_drop_B2.npz"))
+    B, seed, p = int(g["meta"][0]), int(g["drop_seed"]), float(g["drop_p"])
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    with torch.no_grad():
+        o, stats = T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(seed, p, B))
+    for k in ("quality_scores", "expert_weights", "style_embedding", "prompt_embedding", "semantic_score"):
+        assert np.abs(o[k].numpy() - g["train/" + k]).max() <= 2e-5, k
+        assert float(g["nodrop_delta/" + k]) > 1e-3, k          # the masks matter: the no-dropout forward is far away
+    for k in ("feature_extractor.fusion.2.running_mean", "experts.0.0.conv2.2.running_var", "experts.3.2.conv2.2.running_var"):
+        assert np.abs(stats[k].numpy() - g["train/" + k]).max() <= 1e-5, k
+    assert abs(float(g["train/attn_zero_fraction"]) - p) < 2e-3    # proj_drop zeroes ~p of the attention output
+
+
+def test_dropout_mask_generator_statistics():
+    """CPU restatement of the counter RNG: keep rate, independence of sites / calls, threshold."""
+    from oracle import dropout_ref as D
+    n = 1 << 20
+    a = D.keep_flat(1, D.ds_block(0, 0, 2), n, 0.1)
+    b = D.keep_flat(1, D.ds_block(0, 1, 2), n, 0.1)
+    c = D.keep_flat(2, D.ds_block(0, 0, 2), n, 0.1)
+    for k in (a, b, c):
+        assert abs(k.mean() - 0.9) < 1.5e-3
+    assert abs(np.corrcoef(a, b)[0, 1]) < 5e-3 and abs(np.corrcoef(a, c)[0, 1]) < 5e-3
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 5e-3
+    assert D.threshold(0.1) == 6554 and D.keep_flat(1, 3, 1000, 0.5).mean() == pytest.approx(0.5, abs=0.06)
+    m = D.TeacherMasks(5, 0.1, 2)
+    ch = m.channelwise(D.ds_block(1, 2, 0), 128)
+    assert ch.shape == (2, 128, 1, 1) and all(min(abs(v), abs(v - 1 / 0.9)) < 1e-6 for v in np.unique(ch.numpy()).tolist())
+
+
+@pytest.mark.gpu
+def test_device_dropout_masks_equal_the_cpu_restatement():
+    """The device RNG (lo_dropout_mask = the decisions lo_teacher_forward applies) equals oracle/dropout_ref bit for bit."""
+    from lunaris_orion_amd import _lib
+    from oracle import dropout_ref as D
+    for seed, site, p, n in ((0x5EEDD209C0FFEE11, D.ds_block(2, 1, 2), 0.1, 1 << 20), (7, D.DS_GATE, 0.1, 511), (2**63 + 5, D.ds_quality(3), 0.25, 4097)):
+        keep = torch.empty(n, dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib.lo_dropout_mask(seed, site, p, n, keep.data_ptr(), _lib.stream_ptr()), "lo_dropout_mask")
+        torch.cuda.synchronize()
+        ref = D.keep_flat(seed, site, n, p)
+        assert np.array_equal(keep.cpu().numpy().astype(bool), ref), (seed, site)
+        assert abs(ref.mean() - (1 - p)) < 0.05
+
+
+@pytest.mark.gpu
+def test_teacher_dropout_forward_matches_reference_fixture_and_oracle():
+    """Train mode, dropout 0.1 (the reference's default): the native forward with call seed DROP_SEED against (a) the fixture the
+    REFERENCE produced on the same masks and (b) the CPU oracle on the same masks; BatchNorm running statistics included.
+    Same tolerances as the dropout-free parity test."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from oracle import dropout_ref as D
+    g = np.load(os.path.join(GOLD, "teacher_drop_B2.npz"))
+    B, seed, p = int(g["meta"][0]), int(g["drop_seed"]), float(g["drop_p"])
+    S = T.closed_form_teacher_state()
+    m = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=64)      # dropout_rate: the default 0.1
+    assert m.dropout_rate == p
+    m.load_state_dict(S)
+    m = m.to("cuda").train()
+    m.set_dropout_stream(seed, exact_next=True)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    out = m(x.cuda())
+    torch.cuda.synchronize()
+    assert m.last_drop_seed == seed and m.last_path(B) == 2
+    with torch.no_grad():
+        ref, new_stats = T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(seed, p, B))
+    tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}
+    for k, t in tol.items():
+        got = out[k].cpu()
+        d = (got - ref[k]).abs().max().item()
+        print("dropout", k, d, "(masks move it by", float(g["nodrop_delta/" + k]), ")")
+        assert d <= t, (k, d)
+        assert np.abs(got.numpy() - g["train/" + k]).max() <= t, k
+    sd = m.state_dict()
+    for k in ("feature_extractor.fusion.2.running_mean", "experts.0.0.conv2.2.running_var", "experts.3.2.conv2.2.running_var"):
+        d = np.abs(sd[k].cpu().numpy() - g["train/" + k]).max()
+        assert d <= 2e-3 * max(1.0, np.abs(g["train/" + k]).max()), (k, d)
+
+
+@pytest.mark.gpu
+def test_teacher_dropout_modes_and_streams():
+    """eval mode = identity (and the shortcut path); dropout_rate 0 in train mode = shortcut path; with p > 0 the shortcut path
+    is not taken; consecutive calls and different torch seeds draw different masks; the same stream repeats bitwise."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(2)).cuda()
+
+    def fresh(p):
+        t = LunarMoETeacher(dropout_rate=p); t.load_state_dict(S)
+        return t.to("cuda")
+    t0, t1 = fresh(0.0).eval(), fresh(0.1).eval()
+    a, b = t0(x), t1(x)
+    assert torch.equal(a["quality_scores"], b["quality_scores"]) and torch.equal(a["style_embedding"], b["style_embedding"])
+    assert t1.last_path(2) == 0 and t1.last_drop_seed is None
+    tz = fresh(0.0).train(); tz(x)
+    assert tz.last_path(2) == 0                      # p = 0: constant-field shortcuts
+    t1.train()
+    o1 = t1(x)["style_embedding"].clone(); s1 = t1.last_drop_seed
+    o2 = t1(x)["style_embedding"].clone(); s2 = t1.last_drop_seed
+    assert t1.last_path(2) == 2 and s1 != s2         # p > 0: every conv in full, a new call seed per forward
+    assert (o1 - o2).abs().max().item() > 1e-3       # different masks (BatchNorm running stats do not enter a train-mode output)
+    t2 = fresh(0.1).train(); t2.set_dropout_stream(s1, exact_next=True)
+    assert torch.equal(t2(x)["style_embedding"], o1)                                   # same stream -> same bits
+    torch.manual_seed(1234)
+    t3 = fresh(0.1).train(); t3(x)
+    torch.manual_seed(4321)
+    t4 = fresh(0.1).train(); t4(x)
+    assert t3.last_drop_seed != t4.last_drop_seed    # keyed by the torch seed (train_hybrid.py:1138-1141)
+
+
+@pytest.mark.gpu
+def test_teacher_head_gradients_with_dropout_match_autograd_of_oracle():
+    """A13 with the reference's default dropout: the backward replays the gate / quality-head masks of its forward."""
+    import ctypes as C
+
+    from lunaris_orion_amd import _lib
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from oracle import dropout_ref as D
+    B, seed, p = 2, 0xABCDEF0123456789, 0.1
+    S = T.closed_form_teacher_state()
+    m = LunarMoETeacher(); m.load_state_dict(S); m = m.to("cuda").train()
+    m.set_dropout_stream(seed, exact_next=True)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    out = m(x.cuda())
+    h, ws, _ = m._engine(B)
+    b, e = C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.lib.lo_teacher_grad_range(h, C.byref(b), C.byref(e)))
+    rows = torch.empty(B * (e.value - b.value), device="cuda")
+    grads = torch.zeros_like(m._flat)
+    _lib.check(_lib.lib.lo_teacher_heads_backward(h, m._flat.data_ptr(), ws.data_ptr(), out["expert_weights"].data_ptr(), 0.5,
+                                                  rows.data_ptr(), grads.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    S2 = {k: (v.clone().requires_grad_(True) if (k.startswith("gate.") or k.startswith("quality_heads.")) else v) for k, v in S.items()}
+    o, _ = T.teacher_forward(x, S2, training=True, masks=D.TeacherMasks(seed, p, B))
+    (0.5 * (-o["quality_scores"].mean())).backward()
+    for k, t in m._named_state():
+        if not (k.startswith("gate.") or k.startswith("quality_heads.")):
+            continue
+        off = (t.data_ptr() - m._flat.data_ptr()) // 4
+        gg = grads[off: off + t.numel()].view(t.shape).cpu()
+        ref = S2[k].grad
+        assert (gg - ref).norm().item() / (ref.norm().item() + 1e-12) <= 2e-2, k
