@@ -54,43 +54,55 @@ def collect_profile(lib):
     return rows
 
 
-def cpu_baseline_hybrid(latent: int, batch: int = 4):
-    """One full hybrid step of the CPU oracle (VAE step + two teacher forwards + head gradients), bounded sample."""
-    from oracle import teacher_ref as T
+def _host_cores() -> int:
+    # the GPU box gives one GPU's share of the host (16 cores); more threads than that only oversubscribes
+    return min(16, len(os.sched_getaffinity(0)))
+
+
+def _oracle_trainer(latent: int):
     from oracle import vae_ref as R
-    cores = min(16, len(os.sched_getaffinity(0)))
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     P = {k: torch.randn(shp) * (0.02 if len(shp) > 1 else 0.0) + (1.0 if k.endswith(".1.weight") else 0.0)
          for k, shp in R.param_shapes(latent).items()}
-    tr = R.OracleTrainer(P)
+    return R.OracleTrainer(P)
+
+
+def cpu_baseline_hybrid(latent: int, batch: int = 4, warm: int = 1, steps: int = 2, dropout: float = 0.1):
+    """Full hybrid steps of the CPU oracle (VAE step + two train-mode teacher forwards with dropout masks), bounded sample:
+    `warm` untimed + `steps` timed steps, median."""
+    from oracle import dropout_ref as D
+    from oracle import teacher_ref as T
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    tr = _oracle_trainer(latent)
     S = T.closed_form_teacher_state(embedding_dim=256)
     x = synth_sprites(batch, 321)
     eps = torch.randn(batch, latent)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        T.teacher_forward(x, S, training=True)
-    recon = tr.step(x, eps, 0.0, True)["recon"]
-    with torch.no_grad():
-        T.teacher_forward(recon, S, training=True)
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "sprites/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle, one hybrid step (VAE step + 2 teacher forwards, fp32, {cores} threads), batch {batch} latent {latent}, no warm-up"}
+    ts = []
+    for i in range(warm + steps):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(2 * i + 1, dropout, batch) if dropout > 0 else None)
+        recon = tr.step(x, eps, 0.0, True)["recon"]
+        with torch.no_grad():
+            T.teacher_forward(recon, S, training=True, masks=D.TeacherMasks(2 * i + 2, dropout, batch) if dropout > 0 else None)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts[warm:])[len(ts[warm:]) // 2]
+    return {"value": batch / med, "unit": "sprites/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle, full hybrid step (VAE step + 2 train-mode teacher forwards, dropout {dropout}, fp32, {cores} threads), "
+                      f"batch {batch} latent {latent}, {warm} warm-up + {steps} timed steps, median"}
 
 
-def cpu_baseline(batch: int, latent: int, steps: int):
-    """The oracle (CPU restatement, fp32, all host cores) on a bounded sample of the same workload."""
-    from oracle import vae_ref as R
-    # the GPU box gives one GPU's share of the host (16 cores); more threads than that only oversubscribes
-    cores = min(16, len(os.sched_getaffinity(0)))
+def cpu_baseline(batch: int, latent: int, steps: int, warm: int = 3):
+    """The oracle (CPU restatement, fp32, the box's host cores) on a bounded sample of the same workload (BASELINE.md §4:
+    3 warm-up + >= 10 timed steps, median)."""
+    cores = _host_cores()
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    P = {k: torch.randn(shp) * (0.02 if len(shp) > 1 else 0.0) + (1.0 if k.endswith(".1.weight") else 0.0)
-         for k, shp in R.param_shapes(latent).items()}
-    tr = R.OracleTrainer(P)
+    tr = _oracle_trainer(latent)
     x = synth_sprites(batch, 123)
     eps = torch.randn(batch, latent)
-    tr.step(x, eps, 0.0)  # warm-up
+    for _ in range(warm):
+        tr.step(x, eps, 0.0)
     ts = []
     for _ in range(steps):
         t0 = time.perf_counter()
@@ -99,7 +111,7 @@ def cpu_baseline(batch: int, latent: int, steps: int):
     med = sorted(ts)[len(ts) // 2]
     return {"value": batch / med, "unit": "sprites/s", "cores": cores, "kind": "port",
             "sample": f"CPU oracle (oracle/vae_ref.py OracleTrainer, fp32, {cores} threads), batch {batch} latent {latent}, "
-                      f"1 warm-up + {steps} timed full training steps, median"}
+                      f"{warm} warm-up + {steps} timed full training steps, median"}
 
 
 MIN_WARMUP_STEPS = 300
@@ -113,8 +125,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--latent", type=int, default=512)
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the main CPU-baseline leg (0 = the GPU leg's batch)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of each CPU-baseline leg (after 3 warm-up steps; median)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-warmup", type=int, default=MIN_WARMUP_STEPS, help="warm-up steps are topped up to this count (tests pass 0)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -125,6 +137,9 @@ def main():
                     help="operand format of the forward convs in the timed leg (fp8 = BASELINE config 5 mode; the headline number is fp16)")
     ap.add_argument("--fp8-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps in the fp8 operand mode, BASELINE config 5 (0 = skip)")
     ap.add_argument("--hybrid-steps", type=int, default=20, help="extra leg (N=1): full hybrid VAE+teacher steps, BASELINE config 3 (0 = skip)")
+    ap.add_argument("--config2-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps at batch 32 / latent 256, BASELINE config 2 (0 = skip)")
+    ap.add_argument("--dp-exchange", choices=["allreduce", "direct"], default="allreduce",
+                    help="N > 1: gradient exchange = RCCL all-reduce (default) or the direct all-to-all reduce-scatter + all-gather over all xGMI links")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,7 +167,7 @@ def main():
     grad_sync = None
     if world > 1:
         from lunaris_orion_amd.parallel import FlatGradSync
-        grad_sync = FlatGradSync(compress_fp16=args.dp_fp16)
+        grad_sync = FlatGradSync(compress_fp16=args.dp_fp16, mode=args.dp_exchange, time_exposed=True)
     pipeline = os.environ.get("LO_PIPELINE_OPT", "1") != "0"      # A/B knob; the pipelined optimizer step is the default
     st = VAEStepper(model, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
                     kl_weight=0.1, gradient_accumulation_steps=1, grad_sync=grad_sync, pipeline_optimizer=pipeline)
@@ -160,8 +175,10 @@ def main():
     pool = [synth_sprites(B, 1000 * rank + i).cuda() for i in range(4)]
 
     def run(n):
+        t = time.perf_counter()
         for i in range(n):
             st.step(pool[i % len(pool)], batch_idx=i)
+        return time.perf_counter() - t        # host time to ENQUEUE n steps (the queue is drained by the caller)
 
     # W untimed warm-up steps as asked, topped up to MIN_WARMUP_STEPS (same fixed count on every rank): the first ~0.5 s after start-up
     # (clock ramp, first-touch of the 1.5 GB workspace, RCCL channel set-up) run 15-20 % slower and made 50-step timings scatter
@@ -171,8 +188,10 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if grad_sync is not None:
+        grad_sync.reset_timing()
     t0 = time.perf_counter()
-    run(args.steps)
+    host_enqueue_s = run(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -183,6 +202,17 @@ def main():
         elapsed = t.item()
     met = st.metrics()
     assert met["grads_finite"] == 1.0 and np.isfinite(met["recon_loss"]), met
+    dp_info = None
+    if dist is not None:
+        # what actually ran: ranks of the process group and the device each one drove, bytes handed to the exchange per backward
+        # phase, and the time the optimizer's stream had to wait for the exchange (HIP events around FlatGradSync.finish())
+        ids = [None] * world
+        dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+                                     "exposed_ms": grad_sync.exposed_ms_per_step()})
+        dp_info = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": [d["device"] for d in ids],
+                   "device_names": sorted(set(d["name"] for d in ids)), "exchange": args.dp_exchange,
+                   "wire": "fp16" if args.dp_fp16 else "fp32", "bytes_per_phase": grad_sync.bytes_per_phase(),
+                   "exchange_exposed_ms": max(d["exposed_ms"] for d in ids)}
 
     out = None
     if rank == 0:
@@ -218,7 +248,9 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (tools/rocpd_extract.py traffic); null when absent
         roof["traffic"] = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r02_traffic.json", "r01_traffic.json")) if os.path.exists(pp))
+            tr = json.load(open(tpath))["kernels"]
+            roof["traffic_source"] = f"profiles/{os.path.basename(tpath)} (committed rocprofv3 PMC passes of this workload; not re-measured in this run)"
             key = next((k for k in tr if k in dom_name or dom_name.split("<")[0] in k), None)
             if key:
                 roof["traffic"] = tr[key]["hbm_bytes_per_launch"]
@@ -277,8 +309,11 @@ def main():
                        "global_batch": world * B, "latent_dim": args.latent,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof,
+            "host_enqueue_ms": 1e3 * host_enqueue_s / args.steps,     # host time per step spent enqueuing (launch-bound when >= ms_per_step)
             "final_metrics": {k: met[k] for k in ("recon_loss", "kl_loss", "grad_norm")},
         }
+        if world > 1:
+            out["data_parallel"] = dp_info
         if world == 1 and args.fp8_steps > 0 and args.precision == "fp16":
             # BASELINE config 5: the same VAE-only step with e4m3 operands in the forward convs; loss parity against the fp16 mode
             # from identical weights, inputs and noise (first step), then throughput
@@ -311,32 +346,85 @@ def main():
                 "fp8_first_step": {k: first["fp8"][k] for k in ("recon_loss", "kl_loss", "grad_norm")}}
             del m8, s8
             torch.cuda.empty_cache()
+        if world == 1 and args.config2_steps > 0:
+            # BASELINE config 2: batch 32, latent 256, VAE-only (teacher weight 0), one GPU
+            torch.manual_seed(42)
+            m2 = LunarisCoreVAE(latent_dim=256).to("cuda")
+            s2 = VAEStepper(m2, lr=1e-4, min_lr=1e-6, scheduler_t0=10, weight_decay=0.01, max_grad_norm=1.0, recon_weight=1.0,
+                            kl_weight=0.1, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
+            pool2 = [p_[:32].contiguous() for p_ in pool]
+            for i in range(100):
+                s2.step(pool2[i % len(pool2)], batch_idx=i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(args.config2_steps):
+                s2.step(pool2[i % len(pool2)], batch_idx=i)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t2) / args.config2_steps
+            out["config2_b32_l256"] = {"value": 32 / dt2, "unit": "sprites/s", "ms_per_step": 1e3 * dt2, "steps": args.config2_steps,
+                                       "workload": "VAE-only step (fwd+MSE/KL+bwd+clip+AdamW), batch 32, latent 256, fp16 MFMA operands / fp32 accumulate",
+                                       "recon_loss": s2.metrics()["recon_loss"]}
+            del m2, s2, pool2
+            torch.cuda.empty_cache()
         if world == 1 and args.hybrid_steps > 0:
             # BASELINE config 3: batch 64, latent 512, embedding_dim 256, feature_dim 128, teacher on (both teacher forwards of
-            # _process_batch, reward/advantage, gate + quality-head update); teacher dropout not applied
+            # _process_batch, reward/advantage, gate + quality-head update).  Headline of this leg: the reference's defaults,
+            # i.e. teacher dropout 0.1 in train mode (every teacher conv in full); the dropout-free fast path is reported beside it.
             from lunaris_orion_amd.teacher import LunarMoETeacher
             from lunaris_orion_amd.trainer import HybridStepper
             del st
             torch.cuda.empty_cache()
-            teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256).to("cuda").train()
-            hs = HybridStepper(model, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
-            for i in range(10):
-                hs.step(pool[i % len(pool)], batch_idx=i)
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            for i in range(args.hybrid_steps):
-                hs.step(pool[i % len(pool)], batch_idx=i)
-            torch.cuda.synchronize()
-            dth = (time.perf_counter() - th) / args.hybrid_steps
-            hm = hs.metrics()
-            out["config3_full_hybrid"] = {"value": B / dth, "unit": "sprites/s", "ms_per_step": 1e3 * dth, "steps": args.hybrid_steps,
-                                          "workload": f"full hybrid _process_batch: VAE step + 2 teacher forwards (feature_dim 128, 4 experts, "
-                                                      f"embedding_dim 256) + reward/advantage + gate/quality-head update, batch {B}, latent {args.latent}",
-                                          "quality_scores": hm["quality_scores"], "recon_loss": hm["recon_loss"]}
+
+            def hybrid_leg(p_drop, steps, prof_steps):
+                torch.manual_seed(42)
+                teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256, dropout_rate=p_drop).to("cuda").train()
+                hs = HybridStepper(model, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
+                for i in range(6):
+                    hs.step(pool[i % len(pool)], batch_idx=i)
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                for i in range(steps):
+                    hs.step(pool[i % len(pool)], batch_idx=i)
+                enq = time.perf_counter() - th
+                torch.cuda.synchronize()
+                dth = (time.perf_counter() - th) / steps
+                hm = hs.metrics()
+                leg = {"value": B / dth, "unit": "sprites/s", "ms_per_step": 1e3 * dth, "steps": steps, "host_enqueue_ms": 1e3 * enq / steps,
+                       "teacher_dropout": p_drop, "teacher_path": {0: "sparse shortcuts", 1: "dense", 2: "dropout (every conv in full)"}[teacher.last_path(B)],
+                       "quality_scores": hm["quality_scores"], "recon_loss": hm["recon_loss"]}
+                if prof_steps > 0:
+                    _lib.lib.lo_prof_enable(1)
+                    for i in range(prof_steps):
+                        hs.step(pool[i % len(pool)], batch_idx=i)
+                    torch.cuda.synchronize()
+                    rw = collect_profile(_lib.lib)
+                    _lib.lib.lo_prof_enable(0)
+                    tot = sum(r[0] for r in rw.values())
+                    # the teacher's full-resolution 3x3 convolutions (one kernel, lo_conv3x3_pp, under per-call-site profiler names)
+                    conv = [r for k, r in rw.items() if k.startswith("t_conv1") or k.startswith("t_conv2 (dense")]
+                    c_ms, c_n, c_fl = sum(r[0] for r in conv), sum(r[1] for r in conv), sum(r[2] for r in conv)
+                    if c_ms > 0:
+                        ach = c_fl / (c_ms * 1e-3) / 1e12
+                        leg["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
+                                           "traffic": None, "kernel": "lo_conv3x3_pp (teacher 3x3 convs 128->128 at 128x128)",
+                                           "launches_per_step": c_n / prof_steps, "avg_launch_ms": c_ms / max(c_n, 1),
+                                           "share_of_kernel_time": c_ms / tot, "kernel_ms_per_step": tot / prof_steps}
+                del hs, teacher
+                torch.cuda.empty_cache()
+                return leg
+            main_leg = hybrid_leg(0.1, args.hybrid_steps, 2)
+            fast_leg = hybrid_leg(0.0, args.hybrid_steps, 0)
+            main_leg["workload"] = (f"full hybrid _process_batch at the reference's defaults: VAE step + 2 train-mode teacher forwards (feature_dim 128, 4 experts, "
+                                    f"embedding_dim 256, teacher dropout 0.1 applied at all six sites) + reward/advantage + gate/quality-head update, batch {B}, latent {args.latent}")
+            main_leg["without_teacher_dropout"] = {k: fast_leg[k] for k in ("value", "ms_per_step", "teacher_dropout", "teacher_path", "host_enqueue_ms")}
+            main_leg["without_teacher_dropout"]["note"] = "LunarMoETeacher(dropout_rate=0): constant-field shortcuts valid; NOT the reference's default step"
+            out["config3_full_hybrid"] = main_leg
             if not args.no_cpu_baseline:
                 out["config3_full_hybrid"]["cpu_baseline"] = cpu_baseline_hybrid(args.latent)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.latent, args.cpu_steps)
+            # the oracle at this leg's shape and at config 1's shape (batch 8, latent 256); 3 warm-up + N timed, median
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch or B, args.latent, args.cpu_steps)
+            out["cpu_baseline_config1"] = cpu_baseline(8, 256, args.cpu_steps)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -201,7 +201,8 @@ class HybridStepper(VAEStepper):
     teacher(recon.detach()); reward / EMA baseline / advantage on the device (`lo_hybrid_reward`); the VAE objective
     with the detached mean advantage; VAE backward + clip + AdamW; teacher_loss backward for the only parameters that
     receive gradients in the reference (gate, quality_heads: SURVEY §3.2) + clip + AdamW on exactly those.
-    Teacher dropout is not applied (see lunaris_orion_amd/teacher.py)."""
+    Teacher dropout (the module's ``dropout_rate``, 0.1 like the reference unless constructed otherwise) is applied in both
+    teacher calls, each with its own call seed; the heads' backward replays the masks of the evaluated call."""
 
     def __init__(self, vae: LunarisCoreVAE, teacher, teacher_lr: float = 1e-4, quality_weight: float = 0.5, reward_scale: float = 0.1,
                  semantic_weight: float = 0.5, baseline_momentum: float = 0.9, run_dead_teacher_call: bool = True, **kw):

@@ -37,10 +37,16 @@ def _worker(rank, world, port, q):
     xs, es = shard_batch(x, rank, world), shard_batch(eps, rank, world)
     o = R.OracleTrainer(P).step(xs, es, 0.0, do_update=False)
     flat = torch.cat([g.flatten() for g in o["grads"].values()])
+    flat_direct = flat.clone()[:-1]          # odd length: the direct form's remainder path
     sync = FlatGradSync()
     sync(flat)
+    direct = FlatGradSync(mode="direct")
+    direct.begin(flat_direct)
+    direct.finish()
+    assert direct.bytes_per_phase() == [4 * flat_direct.numel()]
     # plain Python objects only (tensors through a spawn-context Queue need the producer to stay alive)
     res = {"sum": flat.double().sum().item(), "l2": flat.double().norm().item(),
+           "direct_vs_allreduce": (flat_direct - flat[:-1]).abs().max().item(),
            "lr": [cosine_warm_restarts_lr(1e-4, 1e-6, 10, 2, k) for k in range(40)]}
     if rank == 0:
         full = R.OracleTrainer(P).step(x, eps, 0.0, do_update=False)
@@ -66,6 +72,8 @@ def test_flat_grad_sync_equals_global_batch_gradient():
     assert out[0]["sum"] == out[1]["sum"] and out[0]["l2"] == out[1]["l2"]   # both ranks hold the same averaged gradient
     assert out[0]["rel"] <= 1e-5, out[0]["rel"]               # == single-process gradient at the global batch
     assert out[0]["lr"] == out[1]["lr"]
+    # the all-to-all reduce-scatter + all-gather form gives the same average (sum order differs: fp32 rounding only)
+    assert max(out[0]["direct_vs_allreduce"], out[1]["direct_vs_allreduce"]) <= 1e-7
 
 
 def test_shard_batch_partitions_without_overlap():

@@ -8,7 +8,8 @@ drop_last (:551-569), the step semantics of `_process_batch` (:838-954) includin
 names (:929-942), the checkpoint dictionary keys (:596-606), SIGINT -> checkpoint (:587-592).
 
 What differs, deliberately: with the teacher on (the default flags) `HybridStepper` runs the full `_process_batch`
-as the reference executes it, except that teacher dropout is not applied and `--feature_dim` must stay 128; with
+as the reference executes it, teacher dropout 0.1 included (`--teacher_dropout`, a builder flag, defaults to the reference's
+constructor default; 0 selects the dropout-free fast path), and `--feature_dim` must stay 128; with
 `--reward_scale 0 --quality_weight 0` (or `--vae_only`) the teacher is not run at all (its result cannot influence the
 VAE then) and the teacher-only metrics are reported as 0.  The reference's
 defects are not inherited: no tensorboard hard dependency, no DataLoader timeout assertion, per-epoch average
@@ -75,6 +76,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--generate_samples", type=int, default=0, help="decode this many prior samples to PNG when training ends (lunar_generate.py:278-291)")
     p.add_argument("--mfma_precision", choices=["fp16", "fp8"], default="fp16",
                    help="operand format of the VAE's forward convolutions: fp16 (parity-tested default) or fp8 = OCP e4m3 where Cin %% 128 == 0, fp16 backward")
+    p.add_argument("--teacher_dropout", type=float, default=0.1,
+                   help="dropout_rate of the teacher (the reference constructs it with its default 0.1, train_hybrid.py:400-404); 0 = dropout-free fast path")
     return p
 
 
@@ -136,10 +139,12 @@ def main(argv=None):
     teacher = None
     if teacher_on:
         from lunaris_orion_amd.teacher import LunarMoETeacher
-        teacher = LunarMoETeacher(num_experts=args.num_experts, feature_dim=args.feature_dim, embedding_dim=args.embedding_dim).to("cuda").train()
+        teacher = LunarMoETeacher(num_experts=args.num_experts, feature_dim=args.feature_dim, embedding_dim=args.embedding_dim,
+                                  dropout_rate=args.teacher_dropout).to("cuda").train()
         stepper = HybridStepper(vae, teacher, teacher_lr=args.teacher_lr, quality_weight=args.quality_weight, reward_scale=args.reward_scale,
                                 semantic_weight=args.semantic_weight, baseline_momentum=args.baseline_momentum, **common)
-        log.info("teacher on: LunarMoETeacher forward as executed by the reference (dropout is not applied in this build)")
+        log.info(f"teacher on: LunarMoETeacher forward as executed by the reference, dropout_rate {args.teacher_dropout} in train mode"
+                 + ("" if args.teacher_dropout > 0 else " (dropout-free fast path: constant-field shortcuts)"))
     else:
         stepper = VAEStepper(vae, **common)
     log.info(f"VAE Parameters - Total: {sum(p.numel() for p in vae.parameters()):,}")
