@@ -68,11 +68,19 @@ def split_indices(n: int, train_fraction: float = 0.9, generator: Optional[torch
     return perm[:n_train], perm[n_train:]
 
 
+def steps_per_epoch(n_train: int, batch: int, world: int = 1) -> int:
+    """Optimizer micro-batches per epoch and rank (the same on every rank)."""
+    return n_train // (world * batch)
+
+
 def epoch_batches(indices: np.ndarray, batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
                   rng: Optional[np.random.Generator] = None) -> Iterator[np.ndarray]:
-    """Index batches of one epoch for this rank: shuffle, stride by rank, `drop_last` (train_hybrid.py:563-570)."""
+    """Index batches of one epoch for this rank: shuffle, `drop_last` at the GLOBAL batch (train_hybrid.py:563-570), stride by
+    rank.  Every rank gets exactly ``steps_per_epoch(len(indices), batch, world)`` batches: the tail that does not fill one
+    more global batch of world * batch sprites is dropped BEFORE striding, so no rank can run one gradient exchange more
+    than the others (mismatched collectives hang)."""
     order = (rng.permutation(indices) if rng is not None else np.random.permutation(indices)) if shuffle else np.asarray(indices)
-    order = order[rank::world]
+    order = order[: steps_per_epoch(len(order), batch, world) * world * batch][rank::world]
     for b in range(len(order) // batch):
         yield np.sort(order[b * batch:(b + 1) * batch])      # sorted: sequential reads inside a shard
 

@@ -158,6 +158,12 @@ class FlatGradSync:
         if self.backend != "nccl":
             t.div_(self.world)
 
+    def max_small(self, t: torch.Tensor) -> None:
+        """Element-wise maximum over ranks, in place (control flags: e.g. "some rank received SIGINT")."""
+        if self.world == 1 and not self.force:
+            return
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     def __call__(self, flat_grads: torch.Tensor) -> None:
         """Average `flat_grads` in place across ranks; the result is ordered on the current stream."""
         self.begin(flat_grads)

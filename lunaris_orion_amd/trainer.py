@@ -64,6 +64,10 @@ class VAEStepper:
         self.opt_steps = 0
         self.last = None
         self._skipped_seen, self._scale_changed_at = 0, 0
+        # GradScaler policy without a host sync: the device's skipped-update counter is copied to pinned memory after every
+        # optimizer step (asynchronously) and looked at when the copy has landed, i.e. one or two steps later
+        self._skip_pinned = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._skip_event: Optional[torch.cuda.Event] = None
         self._presummed_begin: Optional[int] = None   # set by a backward that left the early part of the gradient norm in the scratch
 
     @property
@@ -88,8 +92,22 @@ class VAEStepper:
             self._clip_adamw(flat, lr, st, eng)
             if not self.pipeline_optimizer:
                 vae.mark_weights_changed()
+            self._observe_skipped_updates()
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
+
+    def _observe_skipped_updates(self) -> None:
+        """Runs the loss-scale policy every optimizer step (the reference's GradScaler.update(), train_hybrid.py:917-923) with no
+        host synchronisation: the skipped-update counter of the step just enqueued travels to pinned memory behind it; whichever
+        earlier copy has landed by now is evaluated.  The host runs a step or two ahead of the GPU, so an overflow is answered
+        after that many skipped updates — not after `--log_every` of them, as when only metrics() looked."""
+        if self._skip_event is not None and self._skip_event.query():
+            self._update_loss_scale(float(self._skip_pinned[0]))
+            self._skip_event = None
+        if self._skip_event is None:
+            self._skip_pinned.copy_(self.scratch[1027:1028], non_blocking=True)
+            self._skip_event = torch.cuda.Event()
+            self._skip_event.record()
 
     def _backward_and_exchange(self, eng, images: torch.Tensor, recon: torch.Tensor, st) -> None:
         """Native backward of the fused loss into ``self.grads`` (+ the data-parallel exchange, overlapped with it)."""
@@ -169,12 +187,13 @@ class VAEStepper:
         return out
 
     def _update_loss_scale(self, skipped_total: float) -> None:
-        """GradScaler policy on the host, applied whenever the scalars are read anyway (torch.cuda.amp.GradScaler, used by
-        train_hybrid.py:917-923): every update skipped for a non-finite gradient norm halves the fp16 loss scale; 2000
-        optimizer steps without one double it again, up to the initial 2**16."""
+        """GradScaler policy (torch.cuda.amp.GradScaler, used by train_hybrid.py:917-923), fed by _observe_skipped_updates after
+        every optimizer step and by metrics(): an observation that finds new skipped updates (non-finite gradient norm) halves the
+        fp16 loss scale ONCE — the updates skipped between two observations all ran at the same scale, so they are one overflow,
+        not several; 2000 optimizer steps without one double it again, up to the initial 2**16."""
         skipped = int(skipped_total)
         if skipped > self._skipped_seen:
-            self.vae.loss_scale = max(1.0, self.vae.loss_scale * 0.5 ** (skipped - self._skipped_seen))
+            self.vae.loss_scale = max(1.0, self.vae.loss_scale * 0.5)
             self._skipped_seen, self._scale_changed_at = skipped, self.opt_steps
         elif self.vae.loss_scale < 65536.0 and self.opt_steps - self._scale_changed_at >= 2000:
             self.vae.loss_scale = min(65536.0, self.vae.loss_scale * 2.0)
@@ -283,6 +302,7 @@ class HybridStepper(VAEStepper):
             self._clip_adamw(flat, lr, st, eng)
             if not self.pipeline_optimizer:
                 vae.mark_weights_changed()
+            self._observe_skipped_updates()
             # teacher: gate + quality heads only (train_hybrid.py:891-904, 914, 922)
             b, e = self.t_range
             _lib.check(_lib.lib.lo_teacher_heads_backward(h, t._flat.data_ptr(), ws.data_ptr(), tout["expert_weights"].data_ptr(),

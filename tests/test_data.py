@@ -53,6 +53,12 @@ def test_split_and_epoch_batches_follow_the_reference_loader():
         assert len(bs) == (92 // 2) // 8 and all(len(b) == 8 for b in bs)              # drop_last per rank
         seen += [i for b in bs for i in b]
     assert len(seen) == len(set(seen)) and set(seen) <= set(tr)                         # ranks see disjoint samples
+    # sizes that are NOT a multiple of world * batch: every rank must still get the same number of batches (a rank with one
+    # batch more would run one more gradient exchange than the others and hang the job)
+    from lunaris_orion_amd.data import steps_per_epoch
+    for n, batch, world in ((63, 16, 2), (127, 16, 2), (2 * 16 * 3 + 31, 16, 2), (1000, 7, 8), (8 * 7 - 1, 7, 8)):
+        counts = [len(list(epoch_batches(np.arange(n), batch, rank=r, world=world, rng=np.random.default_rng(5)))) for r in range(world)]
+        assert counts == [steps_per_epoch(n, batch, world)] * world, (n, batch, world, counts)
     fixed = list(epoch_batches(np.arange(20), 6, shuffle=False))
     assert [list(b) for b in fixed] == [list(range(0, 6)), list(range(6, 12)), list(range(12, 18))]
 

@@ -207,6 +207,59 @@ def test_phased_backward_equals_single_call():
         assert torch.equal(view, snap)
 
 
+def test_data_parallel_identity_through_the_product_backward():
+    """The DP identity for the HIP path: two ranks at per-rank batch 2 == one process at batch 4.  Both "ranks" run
+    the PRODUCT's three-phase backward one after the other on this GPU; a stand-in for FlatGradSync averages every range at
+    the moment the stepper hands it over (exactly what the RCCL all-reduce does with two ranks).  The averaged flat gradient
+    must equal the global-batch gradient (2e-3 relative per tensor, fp16 operands), and the update computed from it the
+    global-batch update."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    L, B = 256, 4
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    m, _ = _model(L)
+    st = VAEStepper(m, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    st.step(x, 0, eps)
+    torch.cuda.synchronize()
+    g_global, p_global = st.grads.clone(), m.flat_parameters().clone()
+    names = [k for k, _ in m.named_parameters()]
+
+    class TwoRankAverage:
+        """rank 0's ranges are kept; when rank 1 hands the same range over, both get the mean (begin), like an all-reduce(AVG)"""
+        world = 2
+
+        def __init__(self):
+            self.kept, self.handed = {}, 0
+
+        def begin(self, g):
+            key = (self.handed, g.numel())
+            self.handed += 1
+            if key in self.kept:
+                g.add_(self.kept[key]).mul_(0.5)
+            else:
+                self.kept[key] = g.clone()
+
+        def finish(self):
+            self.handed = 0
+
+        def average_small(self, t):
+            pass
+
+    sync = TwoRankAverage()
+    shards = []
+    for r in range(2):
+        mr, _ = _model(L)
+        sr = VAEStepper(mr, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0, grad_sync=sync)
+        sr.step(x[2 * r:2 * r + 2].contiguous(), 0, eps[2 * r:2 * r + 2].contiguous())
+        torch.cuda.synchronize()
+        shards.append((sr, mr))
+    sr, mr = shards[1]                               # the second rank holds the averaged gradient and the update made from it
+    for (o, n, shape), k in zip(m._layout, names):
+        a, b = sr.grads[o:o + n].double(), g_global[o:o + n].double()
+        assert (a - b).norm().item() <= 2e-3 * b.norm().item() + 1e-9, k
+    assert ((mr.flat_parameters() - p_global).abs().max().item()) <= 2e-5      # lr 1e-3 * Adam's unit step * 1e-2 slack
+
+
 def test_rccl_single_rank_group_path():
     """Exercise the torch.distributed(nccl = RCCL) calls of FlatGradSync on the GPU box with a one-rank group."""
     import subprocess
@@ -338,11 +391,37 @@ def test_overflowing_gradients_skip_the_update_and_halve_the_loss_scale():
     met = st.metrics()
     assert met["grads_finite"] == 0.0 and met["skipped_steps"] == 1.0
     assert torch.equal(m.flat_parameters(), before)            # update skipped
-    assert m.loss_scale == 2.0 ** 39                           # halved on the host
+    assert m.loss_scale == 2.0 ** 39                           # halved once (by metrics() or the per-step observation, not both)
     m.loss_scale = 65536.0
     st.step(x, 1, eps)
     met = st.metrics()
     assert met["grads_finite"] == 1.0 and met["skipped_steps"] == 1.0 and not torch.equal(m.flat_parameters(), before)
+
+
+def test_loss_scale_policy_runs_every_step_without_metrics():
+    """the GradScaler policy must not wait for metrics() (called once per --log_every): with a loss scale far beyond
+    the fp16 range the stepper halves it by itself within a few optimizer steps of each overflow, never by more than one
+    halving per observation, and training resumes once the gradients are finite."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    L, B = 256, 2
+    m, _ = _model(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    st = VAEStepper(m, lr=1e-3)
+    start = 2.0 ** 22                              # 64x above the default: the activation gradients overflow fp16
+    m.loss_scale = start
+    before = m.flat_parameters().clone()
+    scales = []
+    for i in range(60):
+        st.step(x, i, eps)
+        torch.cuda.synchronize()                   # lets the asynchronous observation land; metrics() is never called
+        scales.append(m.loss_scale)
+    assert scales[-1] < start and scales[-1] >= 1.0
+    ratios = {a / b for a, b in zip(scales[:-1], scales[1:])}
+    assert ratios <= {1.0, 2.0}, ratios            # one halving per observation at most
+    assert not torch.equal(m.flat_parameters(), before)        # updates resumed at a finite scale
+    met = st.metrics()
+    assert met["grads_finite"] == 1.0 and met["skipped_steps"] >= 1.0 and met["loss_scale"] == scales[-1]
 
 
 def test_backward_overwrites_every_gradient_element():

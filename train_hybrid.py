@@ -81,7 +81,7 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-from lunaris_orion_amd.data import SpriteFeeder, SpriteShards, epoch_batches   # noqa: E402
+from lunaris_orion_amd.data import SpriteFeeder, SpriteShards, epoch_batches, steps_per_epoch as _steps_per_epoch   # noqa: E402
 
 
 def main(argv=None):
@@ -170,7 +170,7 @@ def main(argv=None):
     perm = torch.randperm(len(data)).numpy()                 # random_split(:555)
     train_idx = perm[:n_train]
     per_rank = args.batch_size
-    steps_per_epoch = (n_train // world) // per_rank          # drop_last (:569)
+    steps_per_epoch = _steps_per_epoch(n_train, per_rank, world)    # drop_last (:569) at the global batch: identical on every rank
     log.info(f"Dataset initialized with {len(data)} samples; {steps_per_epoch} batches/epoch/rank")
 
     early = hostside.EarlyStopping(patience=args.early_stopping_patience)
@@ -202,7 +202,18 @@ def main(argv=None):
                 pth = hostside.save_comparison(out_dir / "eval_samples" / f"comparison_{global_step}_{time.strftime('%Y%m%d_%H%M%S')}.png", images, recon,
                                                tout["quality_scores"] if tout else None, tout["semantic_score"] if tout else None)
                 log.info(f"Saved comparison image {pth.name}")
-            if interrupted["flag"] or (args.max_steps and global_step >= args.max_steps):
+            stop = interrupted["flag"]
+            if grad_sync is not None:
+                # data parallel: SIGINT may reach one rank only, or the ranks at different micro-batches; a rank that leaves the loop
+                # alone strands the others in the next gradient exchange.  Agree on the flag (MAX over ranks) at a fixed point
+                # every rank reaches: each log step
+                stop = False
+                if global_step % args.log_every == 0 or b == steps_per_epoch - 1:
+                    t_stop = torch.tensor([1.0 if interrupted["flag"] else 0.0], dtype=torch.float32, device="cuda")
+                    grad_sync.max_small(t_stop)
+                    stop = bool(t_stop.item() > 0)
+            if stop or (args.max_steps and global_step >= args.max_steps):
+                interrupted["flag"] = interrupted["flag"] or stop
                 done = True
                 feeder.close()
                 break
