@@ -221,6 +221,7 @@ def test_data_parallel_identity_through_the_product_backward():
     st = VAEStepper(m, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
     st.step(x, 0, eps)
     torch.cuda.synchronize()
+    st.synchronize_parameters()
     g_global, p_global = st.grads.clone(), m.flat_parameters().clone()
     names = [k for k, _ in m.named_parameters()]
 
@@ -257,7 +258,12 @@ def test_data_parallel_identity_through_the_product_backward():
     for (o, n, shape), k in zip(m._layout, names):
         a, b = sr.grads[o:o + n].double(), g_global[o:o + n].double()
         assert (a - b).norm().item() <= 2e-3 * b.norm().item() + 1e-9, k
-    assert ((mr.flat_parameters() - p_global).abs().max().item()) <= 2e-5      # lr 1e-3 * Adam's unit step * 1e-2 slack
+    gn_dp, gn_global = sr.metrics()["grad_norm"], st.metrics()["grad_norm"]     # what clip + AdamW saw on the averaged buffer
+    assert abs(gn_dp - gn_global) <= 1e-3 * gn_global
+    # the update itself: Adam's first step is lr * g / (|g| + eps), so it amplifies rounding noise on near-zero elements;
+    # bounded by 2 lr everywhere and small on average
+    d = (mr.flat_parameters() - p_global).abs()
+    assert d.max().item() <= 2.0e-3 + 1e-9 and d.mean().item() <= 2e-4
 
 
 def test_rccl_single_rank_group_path():
