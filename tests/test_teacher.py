@@ -406,3 +406,36 @@ def test_teacher_head_gradients_with_dropout_match_autograd_of_oracle():
         gg = grads[off: off + t.numel()].view(t.shape).cpu()
         ref = S2[k].grad
         assert (gg - ref).norm().item() / (ref.norm().item() + 1e-12) <= 2e-2, k
+
+
+@pytest.mark.gpu
+def test_hybrid_steps_match_the_references_own_process_batch_with_dropout():
+    """Two full hybrid steps at the reference's DEFAULTS (teacher dropout 0.1, train mode) against the 12-metric trace the
+    reference's own `TrainingManager._process_batch` produced (oracle/make_golden.py::run_reference_loop: `train_hybrid.main()`
+    unmodified under the tensorboard / DataLoader-timeout shims, its dropout modules hooked to the masks of the call seeds
+    recorded in the fixture).  The native stepper draws the same masks from the same seed stream."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.trainer import HybridStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    g = np.load(os.path.join(GOLD, "hybrid_loop_L256_B2.npz"))
+    cols, trace, seeds = [str(c) for c in g["cols"]], g["trace"], [int(v) for v in g["call_seeds"]]
+    L, B, steps = (int(v) for v in g["meta"])
+    assert len(seeds) == 2 * steps and float(g["drop_p"]) == 0.1
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    vae = LunarisCoreVAE(L); vae.load_state_dict(R.closed_form_params(L)); vae = vae.to("cuda")
+    t = LunarMoETeacher(); t.load_state_dict(T.closed_form_teacher_state()); t = t.to("cuda").train()     # dropout_rate 0.1
+    t.set_dropout_stream(seeds[0], exact_next=True)
+    hs = HybridStepper(vae, t, gradient_accumulation_steps=1)
+    tol = {"recon_loss": ("rel", 2e-4), "kl_loss": ("rel", 2e-4), "vae_loss": ("rel", 1e-3), "pg_loss": ("abs", 5e-4), "advantage": ("abs", 5e-4)}
+    for s in range(steps):
+        hs.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
+        assert t.last_drop_seed == seeds[2 * s + 1] and t.last_path(B) == 2       # same stream as the fixture, dropout path
+        m = hs.metrics()
+        for j, c in enumerate(cols):
+            kind, lim = tol.get(c, ("abs", 3e-3))
+            err = abs(m[c] - trace[s, j]) / (abs(trace[s, j]) if kind == "rel" else 1.0)
+            assert err <= lim, (s, c, m[c], trace[s, j])
+    assert int(g["teacher_params_with_grad"]) == 28
+    np.testing.assert_allclose(t.gate[2].weight.detach().cpu().numpy()[:4, :8], g["gate_w_after"], atol=2e-4)
+    np.testing.assert_allclose(vae.encoder.fc_mu.bias.detach().cpu().numpy()[:16], g["vae_fc_mu_b_after"], atol=2e-4)
+    assert abs(hs.lr - float(g["lr_after"])) <= 1e-12
