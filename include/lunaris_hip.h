@@ -175,6 +175,12 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
                     int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                     float* flat_grads, void* stream);
 
+/* where lo_vae_forward left an intermediate tensor inside the workspace (fp16 NHWC; dims4 = B, H, W, C), for parity tests
+ * against the reference's hooked module outputs (lunar_generate.py:94-120, 168-190): which 0 = raw encoder conv output
+ * (stage s, k = 0 strided conv, 1 / 2 ResBlock convs), 1 = raw decoder transposed-conv output, 2 = encoder stage (ResBlock)
+ * output, 3 = decoder layer activation. */
+int lo_vae_debug_tensor(const LoVae* h, int which, int s, int k, size_t* byte_offset, int* dims4);
+
 /* ---- LunarMoETeacher.forward as executed (lunar_evaluator.py:408-462; feature_dim 128) ---------------------------- */
 typedef struct LoTeacher LoTeacher;
 int lo_teacher_create(int batch, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out);

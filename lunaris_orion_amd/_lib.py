@@ -89,6 +89,7 @@ SIGNATURES = {
     "lo_vae_backward_phase": (i32, [vp, i32, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),
     "lo_vae_linear_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lo_vae_phase1_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lo_vae_debug_tensor": (i32, [vp, i32, i32, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "lo_vae_stage4_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 

@@ -455,6 +455,19 @@ extern "C" size_t lo_vae_param_numel(const LoVae* h, int i) { return (i >= 0 && 
 extern "C" size_t lo_vae_flat_elems(const LoVae* h) { return h->flat_elems; }
 extern "C" size_t lo_vae_workspace_bytes(const LoVae* h) { return h->ws_bytes; }
 
+// where a forward left one of its intermediate tensors inside the workspace (fp16 NHWC [B][H][W][C]); for parity tests that
+// compare per-layer activations with the reference's hooked module outputs.  which: 0 = raw output (bias included) of encoder
+// conv (stage s, k = 0 strided conv / 1, 2 the ResBlock convs), 1 = raw output of transposed conv s of the decoder,
+// 2 = ResBlock output of encoder stage s (the stage output), 3 = activation (GroupNorm + Mish [+ skip]) of decoder layer s
+extern "C" int lo_vae_debug_tensor(const LoVae* h, int which, int s, int k, size_t* byte_offset, int* dims4) {
+  LO_REQUIRE(h && byte_offset && dims4 && s >= 0 && s < 4 && k >= 0 && k < 3, "lo_vae_debug_tensor: bad argument");
+  const ConvLayer* c = which == 0 ? &h->enc[s][k] : ((which == 1 || which == 3) ? &h->dec[s] : (which == 2 ? &h->enc[s][2] : nullptr));
+  LO_REQUIRE(c, "lo_vae_debug_tensor: unknown tensor kind %d", which);
+  *byte_offset = which == 2 ? h->o_eout[s] : (which == 3 ? c->o_a : c->o_v);
+  dims4[0] = h->B; dims4[1] = c->Ho; dims4[2] = c->Wo; dims4[3] = c->Cout;
+  return LO_OK;
+}
+
 #define WSP(T, off) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (off))
 #define PRM(i) (P + h->p_off[(i)])
 #define GRD(i) (G + h->p_off[(i)])

@@ -170,3 +170,37 @@ def test_teacher_train_batch64_sparse_equals_dense(tmp_path):
     for k, t in tol.items():
         d = (outs["0"][k] - outs["1"][k]).abs().max().item()
         assert d <= t * max(1.0, outs["1"][k].abs().max().item()), (k, d)
+
+
+def test_config2_shape_batch32_latent256():
+    """BASELINE config 2's exact shape (batch 32, latent 256, VAE-only): samples of the batch-32 forward equal the same samples
+    run as a batch of 2 (which test_vae_gpu checks against the oracle and the reference fixture), the losses are the means of
+    the returned tensors, the step is bitwise reproducible, and the batch-32 gradient is the mean of its batch-16 halves."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    B, L = 32, 256
+    x, eps = _inputs(B, L)
+    m = _vae(L)
+    with torch.no_grad():
+        recon, mu, logvar = m(x, eps)
+        r2, mu2, lv2 = m(x[30:32].contiguous(), eps[30:32].contiguous())
+    torch.cuda.synchronize()
+    assert (mu[30:32] - mu2).abs().max().item() <= 5e-3 and (logvar[30:32] - lv2).abs().max().item() <= 5e-3
+    assert (recon[30:32] - r2).abs().max().item() <= 5e-3
+
+    def grads(xs, es):
+        mm = _vae(L)
+        st = VAEStepper(mm, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
+        st.step(xs, 0, es)
+        met = st.metrics()
+        return [g.detach().double().clone() for g in st.parameter_grads()], met, [k for k, _ in mm.named_parameters()]
+    full, met, names = grads(x, eps)
+    again, _, _ = grads(x, eps)
+    assert all(torch.equal(a, b) for a, b in zip(full, again))
+    rl = torch.mean((recon.double() - x.double()) ** 2).item()
+    kl = (-0.5 * torch.mean(1 + logvar.double() - mu.double() ** 2 - logvar.double().exp())).item()
+    assert abs(met["recon_loss"] - rl) <= 1e-4 and abs(met["kl_loss"] - kl) <= 1e-4
+    h0, _, _ = grads(x[:16].contiguous(), eps[:16].contiguous())
+    h1, _, _ = grads(x[16:].contiguous(), eps[16:].contiguous())
+    for g, a, b, k in zip(full, h0, h1, names):
+        ref = 0.5 * (a + b)
+        assert (g - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-9, k

@@ -50,6 +50,61 @@ def test_forward_matches_oracle_and_golden(L):
     assert np.abs(mu.numpy() - g["mu"]).max() <= 5e-3
     assert np.abs(logvar.numpy() - g["logvar"]).max() <= 5e-3
     assert abs(rl.item() - g["trace"][0, 0]) <= 1e-4 and abs(kl.item() - g["trace"][0, 1]) <= 1e-4
+    # ... directly against the reference's sampled outputs: reconstruction, and the hooked per-layer module outputs
+    # (17 conv / transposed-conv outputs, the 4 ResBlock outputs) read back from the native workspace
+    assert np.abs(_sample(recon, "recon") - g["recon/samples"]).max() <= 5e-3
+    import ctypes as C
+
+    from lunaris_orion_amd import _lib
+    eng = m._engine(B)
+
+    def native(which, s, k):
+        off, dims = C.c_size_t(), (C.c_int * 4)()
+        _lib.check(_lib.lib.lo_vae_debug_tensor(eng.handle, which, s, k, C.byref(off), dims), "lo_vae_debug_tensor")
+        b, hh, ww, cc = list(dims)
+        n = b * hh * ww * cc
+        return eng.ws[off.value: off.value + 2 * n].view(torch.float16).view(b, hh, ww, cc).permute(0, 3, 1, 2).float().cpu().contiguous()
+    layers = []
+    for s in range(4):
+        layers += [(f"encoder.down{s + 1}.0", (0, s, 0)), (f"encoder.down{s + 1}.3.conv1.0", (0, s, 1)), (f"encoder.down{s + 1}.3.conv2.0", (0, s, 2)),
+                   (f"encoder.down{s + 1}.3", (2, s, 0)), (f"decoder.up{s + 1}.0", (1, s, 0))]
+    worst = (0.0, "")
+    for name, key in layers:
+        ref_s = g[f"act/{name}/samples"]
+        got = _sample(native(*key), "act/" + name)
+        err = np.abs(got - ref_s).max() / max(1.0, np.abs(ref_s).max())
+        worst = max(worst, (err, name))
+        assert err <= 1e-2, (name, err)            # fp16 storage (2^-11 relative) through up to 30 layers
+    print("worst per-layer activation error vs the reference's hooks", worst)
+
+
+def _sample(t, tag):
+    """The sampled positions of oracle/make_golden.py (closed form, recomputed here)."""
+    n = t.numel()
+    u = R.closed_form_uniform("sample." + tag, min(2048, n))
+    idx = ((u + 1.0) * 0.5 * n).long().clamp_(0, n - 1)
+    return t.detach().flatten()[idx].cpu().numpy()
+
+
+def test_gradients_match_the_golden_samples_of_the_reference():
+    """All 72 parameter gradients of the first step against the samples the REFERENCE's autograd produced (tests/golden,
+    `grad/*`): relative to the tensor's largest sampled magnitude."""
+    from lunaris_orion_amd.trainer import VAEStepper
+    for L in (256, 512):
+        g = np.load(os.path.join(GOLD, f"vae_L{L}_B2.npz"))
+        m, _ = _model(L)
+        x = R.normalise_sprites(R.closed_form_sprites(2)).cuda()
+        st = VAEStepper(m, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
+        st.step(x, 0, R.closed_form_eps(2, L, salt=0).cuda())
+        torch.cuda.synchronize()
+        worst = (0.0, "")
+        for (k, _p), gr in zip(m.named_parameters(), st.parameter_grads()):
+            ref_s = g[f"grad/{k}/samples"]
+            err = np.abs(_sample(gr, "grad/" + k) - ref_s).max() / (np.abs(ref_s).max() + 1e-12)
+            worst = max(worst, (err, k))
+            assert err <= 3e-2, (k, err)
+        print("latent", L, "worst sampled gradient error", worst)
+        assert abs(st.metrics()["grad_norm"] - float(g["grad_norm"])) <= 2e-3 * float(g["grad_norm"])
 
 
 def test_autograd_backward_matches_oracle():
