@@ -198,7 +198,7 @@ struct LoVae {
   size_t o_xflat, o_slab_head, o_eps, o_z, o_klp, o_mu, o_lv, o_yfc, o_h0;
   size_t o_msep, o_losses, o_coefs;
   // backward scratch
-  size_t o_G[6], o_skipg[3], o_P1, o_P2, o_wslab, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
+  size_t o_G[6], o_skipg[3], o_P1, o_P2, o_wslab, o_wslab_lin, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
   size_t o_packjobs;
   std::vector<LoPackJob> packjobs_host;   // kept alive: source of the asynchronous table upload
   int n_packjobs, pack_blocks;
@@ -367,11 +367,15 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     size_t b = lo_wgrad_slab_bytes(h->dec[s].gf);
     wslab = b > wslab ? b : wslab;
   }
-  {
-    size_t b = lo_wgrad_slab_bytes(h->g_head); wslab = b > wslab ? b : wslab;
-    b = lo_wgrad_slab_bytes(h->g_dfc); wslab = b > wslab ? b : wslab;
-  }
   h->o_wslab = ar.take(wslab);
+  // The two Linear weight gradients run on the MAIN stream while the decoder's conv weight gradients may still be running on
+  // the side stream: they get their own slab.  (Found by the buffer audit of round 2: at latent 512 / 256 both Linear
+  // gradients are written directly and never touch a slab, but at latent 64 / 128 lo_wgrad_nsplit() gives decoder.fc two
+  // pixel splits, and sharing o_wslab with the side stream was a write-write race on those shapes.)
+  {
+    size_t b = lo_wgrad_slab_bytes(h->g_head), b2 = lo_wgrad_slab_bytes(h->g_dfc);
+    h->o_wslab_lin = ar.take(b > b2 ? b : b2);
+  }
   h->o_fcw_part = ar.take((size_t)B * 8 * 1728 * 4);
   h->o_lc_part = ar.take((size_t)B * 64 * 867 * 4);
   h->o_dz = ar.take((size_t)B * L * 2);
@@ -934,7 +938,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   // ---- decoder.fc
   LO_TRY(lo_nhwc_to_nchw_f16(Ga, Gb, B, 64, 512, st));                       // Gb = dy of decoder.fc, [B][32768] c-major
   LO_TRY(lo_colsum_f16(Gb, GRD(h->idx_dfc_b), B, 32768, inv, st));
-  LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gb, WSP(float, h->o_wslab), GRD(h->idx_dfc_w), inv, st));
+  LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gb, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, st));
   LO_TRY(lo_conv_run(h->g_dfc_d, Gb, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
                      h->dfcd_split, st));
   LO_TRY(lo_splitk_reduce(WSP(float, h->o_slab_dz), nullptr, nullptr, WSP(f16, h->o_dz), B, L, h->dfcd_split, st));
@@ -944,7 +948,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
                        WSP(f16, h->o_dml), B, L, st));
   // ---- encoder heads
   LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, st));
-  LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab), GRD(h->idx_fc_mu_w), inv, st));
+  LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, st));
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
   }                   // ---------------- end of part A

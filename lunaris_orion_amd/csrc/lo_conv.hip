@@ -548,6 +548,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
       for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
       dst[o] = tot;
     }
+    if (a.gn_partial) __syncthreads();   // the section below reuses `red` (no caller sets both today; the barrier keeps that legal)
   }
   if (a.gn_partial) {
     // deterministic block reduction of the per-thread (sum, sumsq) of the two 4-channel halves of each chunk:
