@@ -375,10 +375,11 @@ def main():
             del st
             torch.cuda.empty_cache()
 
-            def hybrid_leg(p_drop, steps, prof_steps):
+            def hybrid_leg(p_drop, steps, prof_steps, precision="fp16"):
                 torch.manual_seed(42)
-                teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256, dropout_rate=p_drop).to("cuda").train()
-                hs = HybridStepper(model, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
+                teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256, dropout_rate=p_drop, mfma_precision=precision).to("cuda").train()
+                vae_m = model if precision == "fp16" else LunarisCoreVAE(latent_dim=args.latent, mfma_precision=precision).to("cuda")
+                hs = HybridStepper(vae_m, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
                 for i in range(6):
                     hs.step(pool[i % len(pool)], batch_idx=i)
                 torch.cuda.synchronize()
@@ -409,11 +410,24 @@ def main():
                                            "traffic": None, "kernel": "lo_conv3x3_pp (teacher 3x3 convs 128->128 at 128x128)",
                                            "launches_per_step": c_n / prof_steps, "avg_launch_ms": c_ms / max(c_n, 1),
                                            "share_of_kernel_time": c_ms / tot, "kernel_ms_per_step": tot / prof_steps}
-                del hs, teacher
+                leg["teacher_loss"], leg["kl_loss"] = hm["teacher_loss"], hm["kl_loss"]
+                del hs, teacher, vae_m
                 torch.cuda.empty_cache()
                 return leg
             main_leg = hybrid_leg(0.1, args.hybrid_steps, 2)
             fast_leg = hybrid_leg(0.0, args.hybrid_steps, 0)
+            if args.fp8_steps > 0 and "config5_fp8_forward" in out:
+                # BASELINE config 5 on the full hybrid step: e4m3 operands in the VAE's forward convs (Cin % 128 == 0) AND in the
+                # teacher's 24 full-resolution 3x3 convs per forward (where the FLOPs of this step are); same seeds as the fp16 leg
+                f8 = hybrid_leg(0.1, args.hybrid_steps, 2, precision="fp8")
+                f8["workload"] = ("full hybrid step as config3_full_hybrid (teacher dropout 0.1), e4m3 operands in the teacher's 3x3 convolutions and in the "
+                                  "VAE's forward convs with Cin % 128 == 0; fp16 backward, fp32 statistics")
+                f8["vs_fp16_same_seeds"] = {k: abs(f8[k] - main_leg[k]) for k in ("quality_scores", "recon_loss", "kl_loss", "teacher_loss")}
+                if "roofline" in f8:
+                    f8["roofline"]["peak"] = 5000.0           # dense fp8 MFMA peak (MI355X_MICROARCH.md)
+                    f8["roofline"]["frac"] = f8["roofline"]["achieved"] / 5000.0
+                    f8["roofline"]["kernel"] = "lo_conv3x3_pp<f8> (teacher 3x3 convs, e4m3 operands)"
+                out["config5_fp8_forward"]["full_hybrid"] = f8
             main_leg["workload"] = (f"full hybrid _process_batch at the reference's defaults: VAE step + 2 train-mode teacher forwards (feature_dim 128, 4 experts, "
                                     f"embedding_dim 256, teacher dropout 0.1 applied at all six sites) + reward/advantage + gate/quality-head update, batch {B}, latent {args.latent}")
             main_leg["without_teacher_dropout"] = {k: fast_leg[k] for k in ("value", "ms_per_step", "teacher_dropout", "teacher_path", "host_enqueue_ms")}

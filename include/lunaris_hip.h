@@ -61,6 +61,11 @@ int lo_quantize_act_f8(const void* x16, void* x8, size_t n, void* stream);
 int lo_pack_weight_f8_for(int kind, int B, int H, int W, int Cin, int Cout, const void* wp16, void* wp8, float* wscale, void* stream);
 int lo_conv_forward_f8(int kind, int B, int H, int W, int Cin, int Cout, const void* in8, const void* wp8, const float* wscale,
                        const float* bias, const void* add_src, void* out, float* gn_partial, int* mt_out, void* stream);
+/* The fused-tap 3x3 stride-1 convolution of the teacher (lunar_evaluator.py:242-243,249-250: Conv2d k3 p1 + LeakyReLU(0.2), and
+ * the per-channel sums its BatchNorm needs) on fp16 or e4m3 operands; H, W % 16 == 0, Cin % 64 == 0 (fp8: % 128), Cout % 128 == 0,
+ * Cin <= 128.  bn_partial (may be NULL): [B*(H/16)*(W/16)][Cout][2] = (sum, sum of squares) of the stored values per pixel tile. */
+int lo_conv3x3_fused_tap_forward(int B, int H, int W, int Cin, int Cout, int fp8, const void* in, const void* wp, const float* wscale,
+                                 const float* bias, int leaky_relu, void* out, float* bn_partial, void* stream);
 /* Linear with split-K: y[M,N] (fp32 and/or fp16) = x[M,K] Wp[N,K]^T + bias.  slab: nsplit*M*N floats. */
 int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab, int nsplit,
                      float* out32, void* out16, void* stream);
@@ -184,6 +189,11 @@ int lo_vae_debug_tensor(const LoVae* h, int which, int s, int k, size_t* byte_of
 /* ---- LunarMoETeacher.forward as executed (lunar_evaluator.py:408-462; feature_dim 128) ---------------------------- */
 typedef struct LoTeacher LoTeacher;
 int lo_teacher_create(int batch, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out);
+/* flags: LO_TEACHER_FP8_CONV = the 24 full-resolution 3x3 convolutions of the dropout path (train mode, dropout_p > 0) take OCP
+ * e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4; activations e4m3(8 x), one weight scale per output channel), fp16 outputs,
+ * fp32 BatchNorm statistics; everything else unchanged (BASELINE config 5).  The default path and eval mode stay fp16. */
+#define LO_TEACHER_FP8_CONV 1u
+int lo_teacher_create_ex(int batch, int num_experts, int feature_dim, int embedding_dim, unsigned flags, LoTeacher** out);
 void lo_teacher_destroy(LoTeacher* h);
 /* state table in the reference's state_dict order (351 entries at the defaults); float tensors (parameters, BatchNorm
  * running statistics) live in ONE flat fp32 buffer at these element offsets; offset -1 = integer buffer kept by the host */

@@ -38,6 +38,7 @@ SIGNATURES = {
     "lo_quantize_act_f8": (i32, [vp, vp, sz, vp]),
     "lo_pack_weight_f8_for": (i32, [i32] * 6 + [vp, vp, f32p, vp]),
     "lo_conv_forward_f8": (i32, [i32] * 6 + [vp, vp, f32p, f32p, vp, vp, f32p, C.POINTER(C.c_int), vp]),
+    "lo_conv3x3_fused_tap_forward": (i32, [i32] * 6 + [vp, vp, f32p, f32p, i32, vp, f32p, vp]),
     "lo_linear_splitk": (i32, [i32, i32, i32, vp, vp, f32p, f32p, i32, f32p, vp, vp]),
     "lo_wgrad_slab_bytes_for": (sz, [i32] * 6),
     "lo_conv_wgrad": (i32, [i32] * 6 + [vp, vp, f32p, f32p, flt, vp]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     "lo_selfattn2d_backward": (i32, [f32p] * 18 + [i32, i32, i32, vp]),
     "lo_clip_adamw_step": (i32, [f32p, f32p, f32p, f32p, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),
     "lo_teacher_create": (i32, [i32, i32, i32, i32, C.POINTER(C.c_void_p)]),
+    "lo_teacher_create_ex": (i32, [i32, i32, i32, i32, C.c_uint, C.POINTER(C.c_void_p)]),
     "lo_teacher_destroy": (None, [vp]),
     "lo_teacher_num_tensors": (i32, [vp]),
     "lo_teacher_tensor_name": (C.c_char_p, [vp, i32]),

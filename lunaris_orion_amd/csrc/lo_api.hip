@@ -59,6 +59,18 @@ extern "C" int lo_conv_forward_f8(int kind, int B, int H, int W, int Cin, int Co
   if (mt_out) *mt_out = lo_conv_mt(g);
   return lo_conv_run_f8(g, (const uint8_t*)in8, (const uint8_t*)wp8, wscale, bias, (const f16*)add_src, (f16*)out, gn_partial, S(stream));
 }
+// the teacher's 3x3 stride-1 convolution kernel (lo_conv3x3_pp) with its epilogue: bias, optional LeakyReLU(0.2), optional
+// BatchNorm partial sums [B * (H/16) * (W/16)][Cout][2]; operands fp16 (fp8 == 0: in / wp as for lo_conv_forward) or e4m3
+// (fp8 != 0: in / wp / wscale as for lo_conv_forward_f8)
+extern "C" int lo_conv3x3_fused_tap_forward(int B, int H, int W, int Cin, int Cout, int fp8, const void* in, const void* wp, const float* wscale,
+                                            const float* bias, int leaky_relu, void* out, float* bn_partial, void* stream) {
+  LO_REQUIRE(in && wp && out && (!fp8 || wscale), "lo_conv3x3_fused_tap_forward: null argument");
+  LoGeom g;
+  LO_TRY(lo_make_geom(&g, LO_CONV3_S1, B, H, W, Cin, Cout));
+  LoConvExtra ex{leaky_relu ? 1 : 0, bn_partial};
+  if (fp8) return lo_conv3_run_pp_f8(g, (const uint8_t*)in, (const uint8_t*)wp, wscale, bias, (f16*)out, S(stream), &ex);
+  return lo_conv3_run_pp_xf(g, (const f16*)in, nullptr, nullptr, 0, (const f16*)wp, bias, (f16*)out, S(stream), &ex);
+}
 extern "C" int lo_linear_splitk(int M, int K, int N, const void* x, const void* wp, const float* bias, float* slab,
                                 int nsplit, float* out32, void* out16, void* stream) {
   LoGeom g;

@@ -38,6 +38,7 @@ struct Conv3Args {
   const f16* xc;
   const f16* kx;       // [nlev][6][Cin] fp16
   int nlev;
+  const float* f8_scale;   // lo_conv3x3_pp<..., F8>: [Cout] dequantisation factor (weight row scale / activation scale); in / w are e4m3 bytes
   LoGeom g;
 #ifdef LO_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/conv3_stamp.cpp): [workgroup][wave][16] shader-clock stamps
@@ -328,8 +329,16 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 //   A ring stage is overwritten (issue in M(s), interval >= 2s+1) after barrier 2s, which group 1 reaches only after the
 //   lgkmcnt(0) that retires its reads of step s-1 -- the last readers of that stage.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int TH, int TW, bool XF>
+// F8: both operands are OCP e4m3 bytes (a.in / a.w point at bytes): a patch / weight row is still 128 bytes = 128 channels, a
+// step is (tap, 128-channel block) and costs ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16x16 block instead of two fp16 MFMAs
+// (same LDS bytes per step, twice the K, half the MFMA cycles per FLOP); a lane's fragment is the aligned 32-byte pair of chunks
+// (2 fq, 2 fq + 1) of its row -- the swizzle keys are even, so the pair stays adjacent.  The epilogue multiplies by
+// f8_scale[n] before the bias.  (Teacher 3x3 convolutions of the dropout path in fp8 mode, BASELINE config 5.)
+template <int BN, int TH, int TW, bool XF, bool F8 = false>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
+  static_assert(!(XF && F8), "the transform on load works on fp16 patches");
+  constexpr int ES = F8 ? 1 : 2;              // bytes per operand element
+  constexpr int CB = 128 / ES;                // channels per 128-byte row = channel block of one step
   constexpr int NW = 8, NTHR = 512, NSB = 4, D = 3;
   static_assert(TW == 16, "one 16-pixel fragment per tile row");
   constexpr int BM = TH * TW;
@@ -369,13 +378,16 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const int n_img = pt_i / tiles_img, t_img = pt_i - n_img * tiles_img;
   const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
   const int n0 = nt_i * BN;
-  const int KCB = Cin / 64;
+  const int KCB = Cin / CB;
   const int nsteps = 9 * KCB;
   const int Ktot = 9 * Cin;
-  const f16* zpage = reinterpret_cast<const f16*>(lo_zero_page3);
+  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page3);
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* xcb = reinterpret_cast<const unsigned char*>(a.xc);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
   const uint32_t dyc = g.dyc[0], dxc = g.dxc[0];
 
-  int p_src[PI];
+  int p_src[PI];       // BYTE offsets from here on
   unsigned p_xc = 0;   // XF: bit i = piece i of this lane comes from the compact rows buffer
 #pragma unroll
   for (int i = 0; i < PI; ++i) {
@@ -383,9 +395,9 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int py = pp / PW, px = pp - py * PW;
     int iy = y0 - 1 + py, ix = x0 - 1 + px;
     bool ok = pp < NPIX && px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    p_src[i] = ok ? ((n_img * H + iy) * W + ix) * Cin + ((pos ^ lo_swz3(pp)) * 8) : -1;
+    p_src[i] = ok ? (((n_img * H + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16) : -1;
     if (XF && ok && iy < 8) {
-      p_src[i] = ((n_img * 8 + iy) * W + ix) * Cin + ((pos ^ lo_swz3(pp)) * 8);
+      p_src[i] = (((n_img * 8 + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16);
       p_xc |= 1u << i;
     }
   }
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
     int row = (wave * IB + i) * 8 + (lane >> 3), pos = lane & 7;
-    b_src[i] = (n0 + row) * Ktot + ((pos ^ lo_swz3(row)) * 8);
+    b_src[i] = ((n0 + row) * Ktot) * ES + ((pos ^ lo_swz3(row)) * 16);
   }
   auto issue_patch_piece = [&](int buf, int cb, int piece) __attribute__((always_inline)) {
     // wave-uniform: nothing is issued for a piece past this wave's share or past the last channel block (the vmcnt waits
@@ -403,8 +415,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       int off = -1;
 #pragma unroll
       for (int i = 0; i < PI; ++i) if (i == piece) off = p_src[i];
-      const f16* base = (XF && ((p_xc >> piece) & 1u)) ? a.xc : a.in;
-      const f16* src = off >= 0 ? base + (off + cb * 64) : zpage;
+      const unsigned char* base = (XF && ((p_xc >> piece) & 1u)) ? xcb : inb;
+      const unsigned char* src = off >= 0 ? base + (off + cb * 128) : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_patch + buf * PATCH_BYTES + q * 1024), 16, 0, 0);
     }
@@ -412,10 +424,10 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   auto issue_b = [&](int stage, int step) __attribute__((always_inline)) {
     const bool live = step < nsteps;          // past the end: same instruction count from the zero page (keeps vmcnt uniform)
     const int cb = step / 9, tap = step - cb * 9;
-    const int koff = tap * Cin + cb * 64;
+    const int koff = (tap * Cin) * ES + cb * 128;
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const f16* src = live ? a.w + (b_src[i] + koff) : zpage;
+      const unsigned char* src = live ? wb + (b_src[i] + koff) : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_b + stage * B_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
     }
@@ -424,7 +436,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const int fr = lane & 15, fq = lane >> 4;
   const int pp00 = (wm * MI + 1) * PW + fr + 1;            // patch pixel of fragment 0 at tap offset (0, 0)
   const int R0 = wn * WN + fr;
-  const int w00 = R0 * 128 + ((fq ^ lo_swz3(R0)) * 16);    // weight fragment (ni = 0, kk = 0) inside a ring stage
+  const int fch = F8 ? 2 * fq : fq;                        // first 16-byte chunk of this lane's fragment (F8: the pair fch, fch + 1)
+  const int w00 = R0 * 128 + ((fch ^ lo_swz3(R0)) * 16);   // weight fragment (ni = 0, kk = 0) inside a ring stage
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -489,18 +502,20 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     //      ring stage was last read in R(step - 1) and retired before the barrier that ended it
     const int dy = (int)((dyc >> (2 * tap)) & 3u) - 1, dx = (int)((dxc >> (2 * tap)) & 3u) - 1;
     const int pp = pp00 + dy * PW + dx;
-    const int v0 = (cb & 1) * PATCH_BYTES + pp * 128 + ((fq ^ lo_swz3(pp)) * 16);
+    const int v0 = (cb & 1) * PATCH_BYTES + pp * 128 + ((fch ^ lo_swz3(pp)) * 16);
     const int v1 = v0 ^ 64;
     const int u0 = rs * B_BYTES + w00;
     const int u1 = u0 ^ 64;
+    // fp16: [kk] = the two 32-wide k sub-steps (chunks fq and fq + 4);  F8: [0] / [1] = the low / high 16 bytes of the one
+    // 32-byte fragment (chunks 2 fq and 2 fq + 1)
     f16x8 wf[2][NI], xf[2][MI];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[kk][ni] = *reinterpret_cast<const f16x8*>(s_b + (kk ? u1 : u0) + ni * 2048);
+      for (int ni = 0; ni < NI; ++ni) wf[kk][ni] = *reinterpret_cast<const f16x8*>(s_b + (F8 ? u0 + 16 * kk : (kk ? u1 : u0)) + ni * 2048);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        xf[kk][mi] = *reinterpret_cast<const f16x8*>(s_patch + (((kk + mi) & 1) ? v1 : v0) + mi * (PW * 128));
+        xf[kk][mi] = *reinterpret_cast<const f16x8*>(s_patch + (F8 ? ((mi & 1) ? v1 : v0) + 16 * kk : (((kk + mi) & 1) ? v1 : v0)) + mi * (PW * 128));
     }
     issue_b(ws, step + D);
     issue_patch_piece((cb + 1) & 1, cb + 1, tap);
@@ -515,13 +530,28 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #endif
     // ---- M(step)
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (F8) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int ni = 0; ni < NI; ++ni) {
+        const i32x4 wl = __builtin_bit_cast(i32x4, wf[0][ni]), wh = __builtin_bit_cast(i32x4, wf[1][ni]);
+        const i32x8 w8 = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int mi = 0; mi < MI; ++mi) {
+          const i32x4 xl = __builtin_bit_cast(i32x4, xf[0][mi]), xh = __builtin_bit_cast(i32x4, xf[1][mi]);
+          const i32x8 x8 = {xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+          // formats 0 / 0 = e4m3 x e4m3; block scales 0x7f = 2^0
+          acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, x8, acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      }
+    } else {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][ni], xf[kk][mi], acc[ni][mi], 0, 0, 0);
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][ni], xf[kk][mi], acc[ni][mi], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     if (grp == 0) LO_VMCNT(2 * IB);              // step+1 landed; steps +2, +3 may be in flight
 #ifdef LO_STAMPS
@@ -561,10 +591,12 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int nl = wn * WN + ni * 16 + fq * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + nl);
+    f32x4 sv = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (F8) sv = *reinterpret_cast<const f32x4*>(a.f8_scale + n0 + nl);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       int ml = wm * WM + mi * 16 + fr;
-      f32x4 v = acc[ni][mi] + bv;
+      f32x4 v = F8 ? acc[ni][mi] * sv + bv : acc[ni][mi] + bv;
       f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       *reinterpret_cast<f16x4*>(so + ml * OPITCH + nl * 2) = h;
     }
@@ -702,7 +734,7 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
                  float* gn_partial, hipStream_t st, const LoConvExtra* ex) {
   int th, tw, bn, nw;
   LO_REQUIRE(conv3_tile(g, &th, &tw, &bn, &nw), "lo_conv3_run: geometry not supported by the fused-tap kernel");
-  Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, g};
+  Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, nullptr, g};
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif
@@ -733,7 +765,7 @@ int lo_conv3_run_pp_xf(const LoGeom& g, const f16* in, const f16* xc, const f16*
                        f16* out, hipStream_t st, const LoConvExtra* ex) {
   LO_REQUIRE(lo_conv3_pp_applies(g), "lo_conv3_run_pp_xf: geometry not supported");
   LO_REQUIRE(nlev >= 0 && nlev <= 2 && (nlev == 0 || (xc && kx)), "lo_conv3_run_pp_xf: bad transform arguments");
-  Conv3Args a{in, wp, bias, nullptr, out, nullptr, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, xc, kx, nlev, g};
+  Conv3Args a{in, wp, bias, nullptr, out, nullptr, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, xc, kx, nlev, nullptr, g};
 #ifdef LO_STAMPS
   a.stamps = nullptr;
 #endif
@@ -744,5 +776,28 @@ int lo_conv3_run_pp_xf(const LoGeom& g, const f16* in, const f16* xc, const f16*
   if (nlev) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, true>), dim3(tiles), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
   LO_LAUNCH_CHECK("conv3x3_pp_xf");
+  return LO_OK;
+}
+
+// e4m3 operands (in8 = e4m3(x * LO_F8_ACT_SCALE) NHWC bytes, w8 = packed weights as e4m3 with one scale per output channel,
+// wscale = that scale / LO_F8_ACT_SCALE: lo_pack_f8_one) on the 16x16-pixel fused-tap kernel; fp16 output, same epilogues.
+bool lo_conv3_pp_f8_applies(const LoGeom& g) {
+  return lo_conv3_pp_applies(g) && g.Cin % 128 == 0;
+}
+int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, f16* out,
+                       hipStream_t st, const LoConvExtra* ex) {
+  LO_REQUIRE(lo_conv3_pp_f8_applies(g), "lo_conv3_run_pp_f8: geometry not supported");
+  LO_REQUIRE(in8 && w8 && wscale && out, "lo_conv3_run_pp_f8: null argument");
+  Conv3Args a{reinterpret_cast<const f16*>(in8), reinterpret_cast<const f16*>(w8), bias, nullptr, out, nullptr, ex ? ex->bn_partial : nullptr,
+              ex ? ex->act : 0, nullptr, nullptr, 0, wscale, g};
+#ifdef LO_STAMPS
+  a.stamps = nullptr;
+#endif
+  const int tiles = g.B * (g.Hin / 16) * (g.Win / 16) * (g.Cout / 128);
+  double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
+  double bytes = (double)g.B * g.Hin * g.Win * (g.Cin + 2.0 * g.Cout) + 9.0 * g.Cin * g.Cout;
+  LoProfScope _p("lo_conv3x3_pp<f8>", flops, bytes, st);
+  hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false, true>), dim3(tiles), dim3(512), 0, st, a);
+  LO_LAUNCH_CHECK("conv3x3_pp_f8");
   return LO_OK;
 }

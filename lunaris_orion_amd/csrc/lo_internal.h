@@ -31,6 +31,9 @@ int lo_conv_bn_rows(const LoGeom& g);
 bool lo_conv3_pp_applies(const LoGeom& g);
 int lo_conv3_run_pp_xf(const LoGeom& g, const f16* in, const f16* xc, const f16* kx, int nlev, const f16* wp, const float* bias,
                        f16* out, hipStream_t st, const LoConvExtra* ex);   // BatchNorm partial rows written by lo_conv_run(..., ex) for this geometry
+bool lo_conv3_pp_f8_applies(const LoGeom& g);
+int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, f16* out,
+                       hipStream_t st, const LoConvExtra* ex);
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                  float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr);
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);

@@ -176,6 +176,7 @@ struct BnApplyArgs {
   int C, dst_pitch, dst_off, mode, rows_per_block;
   const float* cvec;
   int ss_stride;   // floats between the (scale, shift) tables of consecutive samples: 0 = one table (BatchNorm), 2*C = per sample (BatchNorm + Dropout2d)
+  uint8_t* y8;     // fp8 mode: e4m3(y * LO_F8_ACT_SCALE) copy of y ([pix][C], no pitch), the operand of the next 3x3 convolution; or null
 };
 __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   __shared__ float s_red[256 * 8];
@@ -238,6 +239,11 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
           acc[j] += (float)o[j];
         }
         *reinterpret_cast<f16x8*>(a.y + (row0 + rr) * a.dst_pitch + a.dst_off + c0) = o;
+        if (a.y8) {
+          const u32x2 q = {lo_pack4_fp8((float)o[0] * LO_F8_ACT_SCALE, (float)o[1] * LO_F8_ACT_SCALE, (float)o[2] * LO_F8_ACT_SCALE, (float)o[3] * LO_F8_ACT_SCALE),
+                           lo_pack4_fp8((float)o[4] * LO_F8_ACT_SCALE, (float)o[5] * LO_F8_ACT_SCALE, (float)o[6] * LO_F8_ACT_SCALE, (float)o[7] * LO_F8_ACT_SCALE)};
+          *reinterpret_cast<u32x2*>(a.y8 + (row0 + rr) * C + c0) = q;
+        }
       }
     }
   }
@@ -660,8 +666,10 @@ __global__ __launch_bounds__(256) void lo_t_cat_bn_drop_kernel(f16* __restrict__
 // proj_drop: full-resolution conv2 input = Dropout(proj(att)) (lunar_evaluator.py:224-225).  proj(att) is the compact tensor
 // projc [B][1024][128] on image rows 0..7 and fp16(proj.bias) everywhere else (what the dense 1x1 conv stores for a zero
 // attention row).  Element index (b*HW + pix)*128 + c.
+// out8 != null (fp8 mode): the tensor is written as e4m3(value * LO_F8_ACT_SCALE) bytes instead of fp16 (conv2 is its only reader).
 __global__ __launch_bounds__(256) void lo_t_projdrop_kernel(const f16* __restrict__ projc, const float* __restrict__ pbias,
-                                                            f16* __restrict__ out, size_t nchunk, LoDropSite ds, uint32_t thr, float inv_keep) {
+                                                            f16* __restrict__ out, uint8_t* __restrict__ out8, size_t nchunk, LoDropSite ds,
+                                                            uint32_t thr, float inv_keep) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8-channel chunk of pixel i >> 4
   if (i >= nchunk) return;
   const int c0 = (int)(i & 15) * 8;
@@ -677,7 +685,13 @@ __global__ __launch_bounds__(256) void lo_t_projdrop_kernel(const f16* __restric
   const uint32_t keep = lo_drop_keep8(ds, (uint32_t)(i * 8), thr);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? (f16)((float)v[j] * inv_keep) : (f16)0.f;
-  *reinterpret_cast<f16x8*>(out + i * 8) = o;
+  if (out8) {
+    const u32x2 q = {lo_pack4_fp8((float)o[0] * LO_F8_ACT_SCALE, (float)o[1] * LO_F8_ACT_SCALE, (float)o[2] * LO_F8_ACT_SCALE, (float)o[3] * LO_F8_ACT_SCALE),
+                     lo_pack4_fp8((float)o[4] * LO_F8_ACT_SCALE, (float)o[5] * LO_F8_ACT_SCALE, (float)o[6] * LO_F8_ACT_SCALE, (float)o[7] * LO_F8_ACT_SCALE)};
+    *reinterpret_cast<u32x2*>(out8 + i * 8) = q;
+  } else {
+    *reinterpret_cast<f16x8*>(out + i * 8) = o;
+  }
 }
 
 // ---- fused block tail -------------------------------------------------------------------------------------------
@@ -1077,6 +1091,9 @@ struct LoTeacher {
   size_t o_xc[2], o_kx[8];    // compact rows of x_l (ping-pong), transform constants [3][6][128] fp16 per expert (contiguous)
   size_t o_xc3, o_poolpe;     // compact rows of x_3 of every expert [E][B][1024][128]; pool partials [E][B][64][128]
   size_t o_ssb;               // per-sample (scale, shift) of a BatchNorm followed by Dropout2d: [B][128][2]
+  // fp8 mode (LO_TEACHER_FP8_CONV; dropout path only): e4m3 weights + row scales of the 24 3x3 convs, e4m3 activations
+  bool fp8;
+  size_t o_w8[8][3][2], o_ws8[8][3][2], o_feat8, o_x8[2], o_proj8;
   size_t ws_bytes;
   bool att_zeroed;
   const void* att_zeroed_ws;
@@ -1098,7 +1115,11 @@ static size_t t_idx(const LoTeacher* h, const std::string& k) {
 #define LO_TAGGED(tag, call) do { g_lo_prof_tag = (tag); int _r = (call); g_lo_prof_tag = nullptr; if (_r != LO_OK) return _r; } while (0)
 
 extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int embedding_dim, LoTeacher** out) {
+  return lo_teacher_create_ex(B, num_experts, feature_dim, embedding_dim, 0u, out);
+}
+extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int embedding_dim, unsigned flags, LoTeacher** out) {
   LO_REQUIRE(out && B >= 1, "lo_teacher_create: bad argument");
+  LO_REQUIRE((flags & ~(unsigned)LO_TEACHER_FP8_CONV) == 0, "lo_teacher_create_ex: unknown flag bits 0x%x", flags);
   LO_REQUIRE(feature_dim == 128, "lo_teacher_create: feature_dim %d is not built (only the CLI default 128)", feature_dim);
   LO_REQUIRE(num_experts >= 1 && num_experts <= 8, "lo_teacher_create: num_experts %d out of range", num_experts);
   LO_REQUIRE(embedding_dim >= 1 && embedding_dim <= 512, "lo_teacher_create: embedding_dim %d out of range", embedding_dim);
@@ -1207,6 +1228,13 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
       h->o_wu[e][l] = take((size_t)1024 * 128 * 2); h->o_ub[e][l] = take(1024 * 4); h->o_wz[e][l] = take((size_t)128 * 1088 * 2);
     }
   h->o_ssb = take((size_t)B * 128 * 2 * 4);
+  h->fp8 = (flags & LO_TEACHER_FP8_CONV) != 0 && lo_conv3_pp_f8_applies(h->g3);
+  if (h->fp8) {
+    for (int e = 0; e < num_experts; ++e)
+      for (int l = 0; l < 3; ++l)
+        for (int c = 0; c < 2; ++c) { h->o_w8[e][l][c] = take((size_t)128 * 9 * 128); h->o_ws8[e][l][c] = take(128 * 4); }
+    h->o_feat8 = take(px * 128); h->o_x8[0] = take(px * 128); h->o_x8[1] = take(px * 128); h->o_proj8 = take(px * 128);
+  }
   h->ws_bytes = off;
   *out = h;
   return LO_OK;
@@ -1231,6 +1259,9 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
       LO_TRYT(lo_pack_weight(TP(p + ".conv1.0.weight"), TW(f16, h->o_wp3[e][l][0]), h->g3, st));
       LO_TRYT(lo_pack_weight(TP(p + ".conv2.0.weight"), TW(f16, h->o_wp3[e][l][1]), h->g3, st));
+      if (h->fp8)
+        for (int c = 0; c < 2; ++c)
+          LO_TRYT(lo_pack_f8_one(h->g3, TW(f16, h->o_wp3[e][l][c]), TW(uint8_t, h->o_w8[e][l][c]), TW(float, h->o_ws8[e][l][c]), st));
       LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.qkv.weight"), TW(f16, h->o_wqkv[e][l]), (size_t)384 * 128, st));
       LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.proj.weight"), TW(f16, h->o_wproj[e][l]), (size_t)128 * 128, st));
       hipLaunchKernelGGL(lo_t_cvec_kernel, dim3(6), dim3(128), 0, st, TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"),
@@ -1268,9 +1299,10 @@ static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, co
   return LO_OK;
 }
 static int t_bn_apply(LoTeacher* h, const f16* raw, const float* ls, const f16* identity, f16* y, int C, int dst_pitch, int dst_off,
-                      int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr, bool per_sample = false) {
+                      int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr, bool per_sample = false,
+                      uint8_t* y8 = nullptr) {
   BnApplyArgs a{raw, per_sample ? TW(float, h->o_ssb) : TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode,
-                T_HW / 64, cvec, per_sample ? 2 * C : 0};
+                T_HW / 64, cvec, per_sample ? 2 * C : 0, y8};
   LoProfScope _p(mode ? "lo_bn_apply (block tail)" : "lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode == 1 ? 3 : 2), st);
   hipLaunchKernelGGL(lo_bn_apply_kernel, dim3(64, h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("bn_apply");
@@ -1364,26 +1396,32 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     LO_TRYT(lo_conv_run(h->gfus, TW(f16, h->o_cat), TW(f16, h->o_wfus_fold), TW(float, h->o_bfus_fold), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
   }
   LO_TRYT(t_bn_finalize(h, bnp, (int)(px / lo_conv_tile_m(h->gfus)), 128, fe + ".fusion.2", P, ws, training, st));
-  LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_feat), 128, 128, 0, 0, TW(float, h->o_poolp), ws, st));
+  const bool f8 = drop && h->fp8;       // e4m3 operands in the 24 3x3 convolutions of the dropout path
+  LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_feat), 128, 128, 0, 0, TW(float, h->o_poolp), ws, st, nullptr, false,
+                     f8 ? TW(uint8_t, h->o_feat8) : nullptr));
   LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
   // ---- experts (lunar_evaluator.py:260-275, 422-428)
   const int mt3 = lo_conv_bn_rows(h->g3);   // BatchNorm partial rows of the conv1 epilogue (igemm: M tiles; fused-tap kernel: pixel tiles)
   for (int e = 0; e < h->E; ++e) {
     const f16* xin = TW(f16, h->o_feat);
+    const uint8_t* xin8 = f8 ? TW(uint8_t, h->o_feat8) : nullptr;
     for (int l = 0; l < 3; ++l) {
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
       f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
+      uint8_t* xout8 = f8 ? TW(uint8_t, h->o_x8[l & 1]) : nullptr;
       if (drop) {
         // ---- dropout path: both 3x3 convs in full, the attention still folded (only 543 positions of its output are ever
         //      non-zero BEFORE proj_drop; Dropout2d is a per-sample channel scale that rides on the BatchNorm table)
         const bool pp = lo_conv3_pp_applies(h->g3);
-        auto conv3 = [&](const char* tag, const f16* in, const f16* w, const float* bias, f16* out) -> int {
-          if (pp) { LO_TAGGED(tag, lo_conv3_run_pp_xf(h->g3, in, nullptr, nullptr, 0, w, bias, out, st, &ex)); }
+        auto conv3 = [&](const char* tag, const f16* in, const uint8_t* in8, int which, const float* bias, f16* out) -> int {
+          const f16* w = TW(f16, h->o_wp3[e][l][which]);
+          if (f8) { LO_TAGGED(tag, lo_conv3_run_pp_f8(h->g3, in8, TW(uint8_t, h->o_w8[e][l][which]), TW(float, h->o_ws8[e][l][which]), bias, out, st, &ex)); }
+          else if (pp) { LO_TAGGED(tag, lo_conv3_run_pp_xf(h->g3, in, nullptr, nullptr, 0, w, bias, out, st, &ex)); }
           else { LO_TAGGED(tag, lo_conv_run(h->g3, in, w, bias, nullptr, out, nullptr, nullptr, 1, st, nullptr, &ex)); }
           return LO_OK;
         };
         const int rows3 = pp ? B * 64 : mt3;
-        LO_TRYT(conv3("t_conv1 (dense, dropout path)", xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), TW(f16, h->o_rawA)));
+        LO_TRYT(conv3(f8 ? "t_conv1 (dense, dropout path, e4m3)" : "t_conv1 (dense, dropout path)", xin, xin8, 0, TP(p + ".conv1.0.bias"), TW(f16, h->o_rawA)));
         LO_TRYT(t_bn_finalize(h, bnp, rows3, 128, p + ".conv1.2", P, ws, training, st));
         LO_TRYT(drop2d(LO_DS_BLOCK(e, l, 0)));
         {
@@ -1403,15 +1441,17 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * 128, st);
           const size_t nchunk = px * 16;
           hipLaunchKernelGGL(lo_t_projdrop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
-                             TW(f16, h->o_proj), nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
+                             TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
         }
         LO_LAUNCH_CHECK("t_projdrop");
-        LO_TRYT(conv3("t_conv2 (dense, dropout path)", TW(f16, h->o_proj), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), TW(f16, h->o_rawB)));
+        LO_TRYT(conv3(f8 ? "t_conv2 (dense, dropout path, e4m3)" : "t_conv2 (dense, dropout path)", TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, 1,
+                      TP(p + ".conv2.0.bias"), TW(f16, h->o_rawB)));
         LO_TRYT(t_bn_finalize(h, bnp, rows3, 128, p + ".conv2.2", P, ws, training, st));
         LO_TRYT(drop2d(LO_DS_BLOCK(e, l, 3)));
         LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 1, (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st,
-                           nullptr, true));
+                           nullptr, true, l < 2 ? xout8 : nullptr));
         xin = xout;
+        xin8 = xout8;
         continue;
       }
       if (h->fuse_tail) {

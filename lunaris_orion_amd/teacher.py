@@ -79,7 +79,8 @@ class _TeacherEngine:
 
     def __init__(self, model: "LunarMoETeacher", batch: int):
         h = C.c_void_p()
-        _lib.check(_lib.lib.lo_teacher_create(batch, model.num_experts, model.feature_dim, model.embedding_dim, C.byref(h)), "lo_teacher_create")
+        _lib.check(_lib.lib.lo_teacher_create_ex(batch, model.num_experts, model.feature_dim, model.embedding_dim,
+                                                 1 if model.mfma_precision == "fp8" else 0, C.byref(h)), "lo_teacher_create_ex")
         self.handle = h
         self.ws = torch.empty(_lib.lib.lo_teacher_workspace_bytes(h), dtype=torch.uint8, device=model._flat.device)
         self.packed_version = -1
@@ -98,8 +99,13 @@ class _TeacherEngine:
 
 class LunarMoETeacher(nn.Module):
     def __init__(self, num_experts=4, feature_dim=128, dropout_rate=0.1, rel_pos_size=8, use_checkpointing=True,
-                 expert_layers=3, intermediate_dim=256, embedding_dim=64):
+                 expert_layers=3, intermediate_dim=256, embedding_dim=64, mfma_precision: str = "fp16"):
         super().__init__()
+        # mfma_precision (an addition of this build): "fp16" (default, parity-tested) or "fp8" = OCP e4m3 operands in the 24
+        # full-resolution 3x3 convolutions of the train-mode dropout path (BASELINE config 5); eval mode is fp16 either way
+        if mfma_precision not in ("fp16", "fp8"):
+            raise ValueError(f"mfma_precision must be 'fp16' or 'fp8', got {mfma_precision!r}")
+        self.mfma_precision = mfma_precision
         if feature_dim != 128 or expert_layers != 3 or intermediate_dim != 256 or rel_pos_size != 8:
             raise NotImplementedError("only feature_dim=128, expert_layers=3, intermediate_dim=256, rel_pos_size=8 (the CLI defaults) are built")
         self.num_experts, self.feature_dim, self.dropout_rate = num_experts, feature_dim, dropout_rate

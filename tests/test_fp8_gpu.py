@@ -210,3 +210,82 @@ def test_fp8_mode_loss_parity_at_batch64_latent512():
     print("B=64 / L=512 fp8 vs fp16: d recon_loss", d_rec, "d kl_loss", d_kl, first)
     assert 0 < d_rec <= 3e-3 and d_kl <= 3e-3
     assert abs(first["fp8"]["grad_norm"] - first["fp16"]["grad_norm"]) <= 2e-2 * first["fp16"]["grad_norm"]
+
+
+@pytest.mark.parametrize("B,H", [(2, 128), (3, 32)])
+def test_teacher_fused_tap_conv_fp8_matches_fp16_kernel_on_dequantised_operands(B, H):
+    """The teacher's 3x3 128->128 convolution kernel (lo_conv3x3_pp) on e4m3 operands against the SAME kernel in fp16 on the
+    dequantised operands (same products; fp32 accumulation order differs), LeakyReLU + BatchNorm partial sums included, and the
+    quantisation error against the fp32 convolution."""
+    lib = LIB()
+    Cin = Cout = 128
+    x = h16(F.leaky_relu(_rand(B, Cin, H, H, seed=11), 0.2))
+    w = _rand(Cout, Cin, 3, 3, seed=12, scale=(Cin * 9) ** -0.5)
+    bias = _rand(Cout, seed=13, scale=0.1)
+    ref32 = F.leaky_relu(F.conv2d(x, w, bias, padding=1), 0.2)
+    xin = to_nhwc_h(x)
+    n = lib.lib.lo_packed_weight_elems_for(KIND_S1, B, H, H, Cin, Cout)
+    wp = torch.empty(n, dtype=torch.float16, device="cuda")
+    lib.check(lib.lib.lo_pack_weight_for(KIND_S1, B, H, H, Cin, Cout, w.contiguous().cuda().data_ptr(), wp.data_ptr(), lib.stream_ptr()), "pack")
+    x8 = torch.empty(xin.numel(), dtype=torch.uint8, device="cuda")
+    w8 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ws = torch.full((Cout,), float("nan"), dtype=torch.float32, device="cuda")
+    lib.check(lib.lib.lo_quantize_act_f8(xin.data_ptr(), x8.data_ptr(), xin.numel(), lib.stream_ptr()), "quantize")
+    lib.check(lib.lib.lo_pack_weight_f8_for(KIND_S1, B, H, H, Cin, Cout, wp.data_ptr(), w8.data_ptr(), ws.data_ptr(), lib.stream_ptr()), "pack8")
+    tiles = B * (H // 16) * (H // 16)
+    bd = bias.cuda()
+    outs, parts = {}, {}
+    xdq = (_decode(x8) / ACT_SCALE).half().view_as(xin).cuda()
+    wdq = (_decode(w8).view(Cout, -1) * (ws.cpu() * ACT_SCALE)[:, None]).half().view(-1).cuda()
+    for tag, fp8, a_in, a_w in (("fp8", 1, x8, w8), ("fp16", 0, xdq, wdq)):
+        out = torch.full((B, H, H, Cout), float("nan"), dtype=torch.float16, device="cuda")
+        part = torch.full((tiles, Cout, 2), float("nan"), dtype=torch.float32, device="cuda")
+        lib.check(lib.lib.lo_conv3x3_fused_tap_forward(B, H, H, Cin, Cout, fp8, a_in.data_ptr(), a_w.data_ptr(), ws.data_ptr(), bd.data_ptr(), 1,
+                                                       out.data_ptr(), part.data_ptr(), lib.stream_ptr()), "fused_tap " + tag)
+        sync()
+        outs[tag], parts[tag] = from_nhwc(out), part.cpu()
+    got, ref = outs["fp8"], outs["fp16"]
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 3e-3 * max(1.0, ref.abs().max().item())
+    tot = parts["fp8"].double().sum(dim=0)
+    assert torch.allclose(tot[:, 0], got.double().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, 1], (got.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    rel = ((got - ref32).norm() / ref32.norm()).item()
+    print(f"teacher conv B={B} H={H}: fp8 vs fp32 relative L2 error {rel:.4f}")
+    assert rel <= 6e-2, rel
+
+
+def test_teacher_fp8_mode_matches_the_fp16_mode_on_the_same_dropout_masks():
+    """LunarMoETeacher(mfma_precision="fp8"), train mode with the default dropout 0.1: the 24 full-resolution 3x3 convs on e4m3
+    operands against the fp16 mode with the same call seed (same masks) and against the CPU oracle.  Tolerances: those of the fp16
+    parity tests (scores 2e-3, embeddings 2e-2) -- measured 1e-4 / 8e-4: the per-element e4m3 error (3.7 % relative L2 per conv)
+    averages out over K = 1152 products, BatchNorm renormalises every conv output and the heads see 16384-pixel means."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from oracle import dropout_ref as D
+    from oracle import teacher_ref as T
+    B, seed = 2, 0x1234567890ABCDEF
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    outs = {}
+    for prec in ("fp16", "fp8"):
+        m = LunarMoETeacher(mfma_precision=prec); m.load_state_dict(S); m = m.to("cuda").train()
+        m.set_dropout_stream(seed, exact_next=True)
+        o = m(x.cuda())
+        sync()
+        assert m.last_path(B) == 2
+        outs[prec] = {k: v.cpu() for k, v in o.items() if v is not None}
+    assert not torch.equal(outs["fp8"]["style_embedding"], outs["fp16"]["style_embedding"])      # the mode changes the arithmetic
+    with torch.no_grad():
+        ref, _ = T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(seed, 0.1, B))
+    tol = {"quality_scores": 2e-3, "semantic_score": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2}
+    for k, t in tol.items():
+        d16 = (outs["fp8"][k] - outs["fp16"][k]).abs().max().item()
+        dref = (outs["fp8"][k] - ref[k]).abs().max().item()
+        print("teacher fp8", k, "vs fp16", d16, "vs oracle", dref)
+        assert d16 <= t and dref <= t, (k, d16, dref)
+    # eval mode is fp16 either way
+    a = LunarMoETeacher(mfma_precision="fp8"); a.load_state_dict(S); a = a.to("cuda").eval()
+    b = LunarMoETeacher(); b.load_state_dict(S); b = b.to("cuda").eval()
+    assert torch.equal(a(x.cuda())["quality_scores"], b(x.cuda())["quality_scores"])
+    with pytest.raises(ValueError):
+        LunarMoETeacher(mfma_precision="int4")
