@@ -220,7 +220,7 @@ __device__ __forceinline__ int lo_xcd_remap(int bid, int total) {
 // NSTAGE LDS stages, NSTAGE-1 K steps in flight behind a counted s_waitcnt vmcnt + one raw s_barrier per K step.
 // F8: both operands are OCP e4m3 bytes (in / w point at bytes, every element offset below is scaled by ES), BK = 128 elements
 // so a tile row is the same 128 bytes as the fp16 BK = 64 row, and one K step is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per
-// 16x16 block (lane holds row lane&15, k = 32*(lane>>4) .. +31: two adjacent 16-byte chunks; unit block scales) - twice the
+// 16x16 block (lane holds row lane&15 and 32 bytes of k: chunks fq and fq + 4 of the row; unit block scales) - twice the
 // K per byte moved and per MFMA cycle.  The epilogue multiplies by f8_scale[phase][n] before the bias.
 template <int BM, int BN, int BK, int NSTAGE, bool SPLITK, bool F8 = false>
 __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
     for (int cf = 0; cf < CPF; ++cf) {
-      const int chunk = F8 ? kk * 8 + fq * 2 + cf : kk * 4 + fq;
+      // F8: the lane's 32-byte fragment = chunks (fq, fq + 4) of the 128-byte row, the same two reads as the fp16 k sub-steps (the
+      // adjacent pair (2 fq, 2 fq + 1) would touch only every other 16-byte slot per read: 2-way bank conflicts); both operands
+      // go through this chunk -> k map, so the product is unchanged
+      const int chunk = F8 ? kk * 8 + cf * 4 + fq : kk * 4 + fq;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         int R = wm * WM + mi * 16 + fr;

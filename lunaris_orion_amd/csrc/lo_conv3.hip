@@ -331,9 +331,11 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 // ---------------------------------------------------------------------------------------------
 // F8: both operands are OCP e4m3 bytes (a.in / a.w point at bytes): a patch / weight row is still 128 bytes = 128 channels, a
 // step is (tap, 128-channel block) and costs ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16x16 block instead of two fp16 MFMAs
-// (same LDS bytes per step, twice the K, half the MFMA cycles per FLOP); a lane's fragment is the aligned 32-byte pair of chunks
-// (2 fq, 2 fq + 1) of its row -- the swizzle keys are even, so the pair stays adjacent.  The epilogue multiplies by
-// f8_scale[n] before the bias.  (Teacher 3x3 convolutions of the dropout path in fp8 mode, BASELINE config 5.)
+// (same LDS bytes per step, twice the K, half the MFMA cycles per FLOP).  A lane's 32-byte fragment is the pair of 16-byte
+// chunks (fq, fq + 4) of its row -- the SAME two reads as the fp16 k sub-steps, so the conflict-free bank pattern carries over
+// (the natural pair (2 fq, 2 fq + 1) touches only every other 16-byte slot per read: 2-way conflicts, measured 289 us per teacher
+// conv against 236 with this form); which k a byte is multiplied as does not matter as long as both operands agree, and they do:
+// both images are read through the same chunk -> k map.  The epilogue multiplies by f8_scale[n] before the bias.  (Teacher 3x3 convolutions of the dropout path in fp8 mode, BASELINE config 5.)
 template <int BN, int TH, int TW, bool XF, bool F8 = false>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   static_assert(!(XF && F8), "the transform on load works on fp16 patches");
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const int fr = lane & 15, fq = lane >> 4;
   const int pp00 = (wm * MI + 1) * PW + fr + 1;            // patch pixel of fragment 0 at tap offset (0, 0)
   const int R0 = wn * WN + fr;
-  const int fch = F8 ? 2 * fq : fq;                        // first 16-byte chunk of this lane's fragment (F8: the pair fch, fch + 1)
+  const int fch = fq;                                      // 16-byte chunk of this lane's fragment at kk = 0 (kk = 1: fq + 4)
   const int w00 = R0 * 128 + ((fch ^ lo_swz3(R0)) * 16);   // weight fragment (ni = 0, kk = 0) inside a ring stage
 
   f32x4 acc[NI][MI];
@@ -506,16 +508,15 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     const int v1 = v0 ^ 64;
     const int u0 = rs * B_BYTES + w00;
     const int u1 = u0 ^ 64;
-    // fp16: [kk] = the two 32-wide k sub-steps (chunks fq and fq + 4);  F8: [0] / [1] = the low / high 16 bytes of the one
-    // 32-byte fragment (chunks 2 fq and 2 fq + 1)
+    // fp16: [kk] = the two 32-wide k sub-steps (chunks fq and fq + 4);  F8: [0] / [1] = the two halves of the one 32-byte fragment
     f16x8 wf[2][NI], xf[2][MI];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[kk][ni] = *reinterpret_cast<const f16x8*>(s_b + (F8 ? u0 + 16 * kk : (kk ? u1 : u0)) + ni * 2048);
+      for (int ni = 0; ni < NI; ++ni) wf[kk][ni] = *reinterpret_cast<const f16x8*>(s_b + (kk ? u1 : u0) + ni * 2048);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        xf[kk][mi] = *reinterpret_cast<const f16x8*>(s_patch + (F8 ? ((mi & 1) ? v1 : v0) + 16 * kk : (((kk + mi) & 1) ? v1 : v0)) + mi * (PW * 128));
+        xf[kk][mi] = *reinterpret_cast<const f16x8*>(s_patch + (((kk + mi) & 1) ? v1 : v0) + mi * (PW * 128));
     }
     issue_b(ws, step + D);
     issue_patch_piece((cb + 1) & 1, cb + 1, tap);
