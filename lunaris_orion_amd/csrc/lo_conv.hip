@@ -880,7 +880,11 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   const LoGeom& g = a.g;
   static char name[64];
   snprintf(name, sizeof(name), "lo_igemm_nt<%d,%d,%d>%s", BM, BN, BK, a.nsplit > 1 ? "/splitK" : "");  // same text for every call of this instantiation
-  LoProfScope _p(name, geom_flops(g), geom_bytes(g), st);
+  // algorithmic bytes of the FUSED op: operands + output once, plus what its epilogue must read by definition: the residual
+  // / skip gradient it adds (add_src) and the producing layer's raw conv output for the fused GroupNorm-backward reduction
+  // (gb_v), each the size of the output
+  const double out_bytes = 2.0 * (double)g.B * g.Hout * g.Wout * g.Cout;
+  LoProfScope _p(name, geom_flops(g), geom_bytes(g) + (a.add_src ? out_bytes : 0.0) + (a.gb_v ? out_bytes : 0.0), st);
   dim3 grid(((a.M + BM - 1) / BM) * (g.Cout / BN) * (a.nsplit > 1 ? a.nsplit : g.n_phase));
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);

@@ -314,10 +314,15 @@ def test_selfattention2d_forward_backward(B, C, H):
                               sd["value_conv.weight"], sd["value_conv.bias"], sd["gamma"])
     with torch.no_grad():
         got = m.cuda()(x.cuda()).cpu()
-    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # forward: the 1x1 projections run on the exact fp32 matrix instruction, QK^T and PV on fp16 MFMA operands with fp32
+    # accumulation and an online fp32 softmax -> stated tolerance 4e-3 of the output range (fp16 keeps 11 significant bits;
+    # measured <= 1.5e-3).  The fp32 VALU kernels (LO_ATTN_FP32=1, 2e-5) are checked in a subprocess below.
+    err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print("selfattn2d", (B, C, H), "forward error / range", err)
+    assert err <= 4e-3, err
     if (B, C, H) == (2, 64, 8):
         g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfattn2d.npz"))
-        assert np.abs(got.numpy() - g["y"]).max() <= 2e-5 * max(1.0, np.abs(g["y"]).max())
+        assert np.abs(got.numpy() - g["y"]).max() <= 4e-3 * max(1.0, np.abs(g["y"]).max())
     # backward: every gradient against autograd of the oracle restatement (fp32 both sides)
     xr = x.clone().requires_grad_(True)
     Pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -333,3 +338,30 @@ def test_selfattention2d_forward_backward(B, C, H):
     for k in ref_g:
         scale = max(1e-3, ref_g[k].abs().max().item())
         assert (got_g[k] - ref_g[k]).abs().max().item() <= 2e-4 * scale + 1e-6, (k, (got_g[k] - ref_g[k]).abs().max().item(), scale)
+
+
+def test_selfattention2d_fp32_kernels_strict_parity():
+    """LO_ATTN_FP32=1: the two-pass fp32 VALU kernels (first-round form) keep the 2e-5 module-level parity; the knob is read
+    once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import vae_ref as R
+from lunaris_orion_amd.vae import SelfAttention2d
+C, B, H = 128, 2, 16
+m = SelfAttention2d(C)
+sd = {k: (R.closed_form_tensor("attn." + k, tuple(v.shape)) if v.dim() > 1 else R.closed_form_tensor("attn." + k, tuple(v.shape)) * 0 + 0.05) for k, v in m.state_dict().items()}
+sd["gamma"] = torch.tensor([0.7]); m.load_state_dict(sd)
+x = R.closed_form_tensor("attn.x", (B, C, H, H)) * 8.0
+ref = R.self_attention_2d(x, sd["query_conv.weight"], sd["query_conv.bias"], sd["key_conv.weight"], sd["key_conv.bias"], sd["value_conv.weight"], sd["value_conv.bias"], sd["gamma"])
+with torch.no_grad():
+    got = m.cuda()(x.cuda()).cpu()
+assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+print("ATTN_FP32_OK")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, LO_ATTN_FP32="1"))
+    assert "ATTN_FP32_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -2,6 +2,7 @@
 """Micro-benchmark of one implicit-GEMM op through the C ABI (tuning aid; also the target of rocprofv3 --pmc runs).
 
   python tools/op_bench.py --op conv|wgrad --kind 0 --B 64 --H 32 --Cin 128 --Cout 128 --iters 20
+  python tools/op_bench.py --op attn --B 64 --H 8 --Cin 512        (SelfAttention2d forward on a [B, Cin, H, H] map)
 """
 import argparse
 import ctypes as C
@@ -29,6 +30,34 @@ def main():
     B, H, Cin, Cout, kind = a.B, a.H, a.Cin, a.Cout, a.kind
     Ho = H if kind in (0, 3, 6) else (H // 2 if kind in (1, 5) else 2 * H)
     st = _lib.stream_ptr()
+    if a.op == "attn":
+        # SelfAttention2d forward (lunar_generate.py:56-78): roofline line of the fused kernel.  FLOPs = QK^T + PV (the three
+        # 1x1 projections are separate launches and are timed with it; their FLOPs are counted too)
+        Cc, N, D = Cin, H * H, Cin // 8
+        xa = torch.randn(B, Cc, N, device="cuda")
+        ws = [torch.randn(D, Cc, device="cuda") * Cc ** -0.5, torch.zeros(D, device="cuda"), torch.randn(D, Cc, device="cuda") * Cc ** -0.5,
+              torch.zeros(D, device="cuda"), torch.randn(Cc, Cc, device="cuda") * Cc ** -0.5, torch.zeros(Cc, device="cuda"), torch.full((1,), 0.7, device="cuda")]
+        q, k = torch.empty(B, D, N, device="cuda"), torch.empty(B, D, N, device="cuda")
+        v, out = torch.empty(B, Cc, N, device="cuda"), torch.empty(B, Cc, N, device="cuda")
+        fl_core = 2.0 * B * N * N * (D + Cc)
+        fl_proj = 2.0 * B * N * Cc * (2 * D + Cc)
+
+        def run_attn():
+            _lib.check(lib.lo_selfattn2d_forward(xa.data_ptr(), *[t.data_ptr() for t in ws], q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Cc, N, st))
+        for _ in range(3):
+            run_attn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run_attn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        byts = 4.0 * B * N * (2.0 * D + 3.0 * Cc)
+        print(f"attn B={B} C={Cc} N={N}: {ms * 1e3:.1f} us/call (3 projections + fused attention)  {(fl_core + fl_proj) / ms / 1e9:.2f} TFLOP/s "
+              f"= {(fl_core + fl_proj) / ms / 1e9 / 2500.0:.4f} of the dense fp16 MFMA peak;  {byts / ms / 1e6:.1f} GB/s of q/k/v/x/out traffic = {byts / ms / 1e6 / 8000.0:.4f} of HBM peak")
+        return
     x = (torch.randn(B, H, H, Cin, device="cuda") * 0.5).half()
     if a.op == "conv":
         n = lib.lo_packed_weight_elems_for(kind, B, H, H, Cin, Cout)
