@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
           o[j] = (f16)v;
           acc[j] += (float)o[j];
         }
-        *reinterpret_cast<f16x8*>(a.y + (row0 + rr) * a.dst_pitch + a.dst_off + c0) = o;
+        if (a.y) *reinterpret_cast<f16x8*>(a.y + (row0 + rr) * a.dst_pitch + a.dst_off + c0) = o;   // y == null: pooling sums only
         if (a.y8) {
           const u32x2 q = {lo_pack4_fp8((float)o[0] * LO_F8_ACT_SCALE, (float)o[1] * LO_F8_ACT_SCALE, (float)o[2] * LO_F8_ACT_SCALE, (float)o[3] * LO_F8_ACT_SCALE),
                            lo_pack4_fp8((float)o[4] * LO_F8_ACT_SCALE, (float)o[5] * LO_F8_ACT_SCALE, (float)o[6] * LO_F8_ACT_SCALE, (float)o[7] * LO_F8_ACT_SCALE)};
@@ -1448,8 +1448,11 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
                       TP(p + ".conv2.0.bias"), TW(f16, h->o_rawB)));
         LO_TRYT(t_bn_finalize(h, bnp, rows3, 128, p + ".conv2.2", P, ws, training, st));
         LO_TRYT(drop2d(LO_DS_BLOCK(e, l, 3)));
-        LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, xout, 128, 128, 0, 1, (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st,
-                           nullptr, true, l < 2 ? xout8 : nullptr));
+        // the last block's output feeds nothing but the global average pool: a statistics-only call skips its tail, a full call
+        // only sums it (no 268 MB store)
+        if (l < 2 || !stats_only)
+          LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), xin, l < 2 ? xout : nullptr, 128, 128, 0, 1,
+                             (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st, nullptr, true, l < 2 ? xout8 : nullptr));
         xin = xout;
         xin8 = xout8;
         continue;
