@@ -137,6 +137,7 @@ def main():
                     help="operand format of the forward convs in the timed leg (fp8 = BASELINE config 5 mode; the headline number is fp16)")
     ap.add_argument("--fp8-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps in the fp8 operand mode, BASELINE config 5 (0 = skip)")
     ap.add_argument("--hybrid-steps", type=int, default=20, help="extra leg (N=1): full hybrid VAE+teacher steps, BASELINE config 3 (0 = skip)")
+    ap.add_argument("--highend-steps", type=int, default=3, help="extra leg (N=1): full hybrid steps of the README High-End recipe, --feature_dim 512 (0 = skip)")
     ap.add_argument("--config2-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps at batch 32 / latent 256, BASELINE config 2 (0 = skip)")
     ap.add_argument("--dp-exchange", choices=["allreduce", "direct"], default="allreduce",
                     help="N > 1: gradient exchange = RCCL all-reduce (default) or the direct all-to-all reduce-scatter + all-gather over all xGMI links")
@@ -375,14 +376,14 @@ def main():
             del st
             torch.cuda.empty_cache()
 
-            def hybrid_leg(p_drop, steps, prof_steps, precision="fp16"):
+            def hybrid_leg(p_drop, steps, prof_steps, precision="fp16", feature_dim=128, warm=6):
                 torch.manual_seed(42)
-                teacher = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256, dropout_rate=p_drop, mfma_precision=precision).to("cuda").train()
+                teacher = LunarMoETeacher(num_experts=4, feature_dim=feature_dim, embedding_dim=256, dropout_rate=p_drop, mfma_precision=precision).to("cuda").train()
                 vae_m = LunarisCoreVAE(latent_dim=args.latent, mfma_precision=precision).to("cuda")    # same seed: same initial weights in every leg
                 hs = HybridStepper(vae_m, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
                 hs.step(pool[0], batch_idx=0)
                 first = hs.metrics()                       # first step from identical weights / sprites / mask stream: comparable across legs
-                for i in range(1, 6):
+                for i in range(1, warm):
                     hs.step(pool[i % len(pool)], batch_idx=i)
                 torch.cuda.synchronize()
                 th = time.perf_counter()
@@ -404,7 +405,7 @@ def main():
                     _lib.lib.lo_prof_enable(0)
                     tot = sum(r[0] for r in rw.values())
                     # the teacher's full-resolution 3x3 convolutions (one kernel, lo_conv3x3_pp, under per-call-site profiler names)
-                    conv = [r for k, r in rw.items() if k.startswith("t_conv1") or k.startswith("t_conv2 (dense")]
+                    conv = [r for k, r in rw.items() if k.startswith("t_conv1") or k.startswith("t_conv2 (dense") or k.startswith("t_conv2 (generic")]
                     c_ms, c_n, c_fl = sum(r[0] for r in conv), sum(r[1] for r in conv), sum(r[2] for r in conv)
                     if c_ms > 0:
                         ach = c_fl / (c_ms * 1e-3) / 1e12
@@ -435,6 +436,15 @@ def main():
             main_leg["without_teacher_dropout"] = {k: fast_leg[k] for k in ("value", "ms_per_step", "teacher_dropout", "teacher_path", "host_enqueue_ms")}
             main_leg["without_teacher_dropout"]["note"] = "LunarMoETeacher(dropout_rate=0): constant-field shortcuts valid; NOT the reference's default step"
             out["config3_full_hybrid"] = main_leg
+            if args.highend_steps > 0:
+                # README.md:102-118 "High-End" recipe: batch 64, latent 512, embedding 256, feature_dim 512 (2 TFLOP per image and teacher
+                # forward: 262 TFLOP per step), teacher dropout 0.1; generic full-resolution teacher path
+                he = hybrid_leg(0.1, args.highend_steps, 1, feature_dim=512, warm=2)
+                he["workload"] = (f"README High-End recipe: full hybrid _process_batch, batch {B}, latent {args.latent}, embedding_dim 256, feature_dim 512, 4 experts, "
+                                  "teacher dropout 0.1 (generic full-resolution teacher path, fp16 operands)")
+                if "roofline" in he:
+                    he["roofline"]["kernel"] = "lo_conv3x3_pp / lo_igemm_nt (teacher 3x3 convs 128->512 and 512->512 at 128x128)"
+                out["readme_high_end_feature_dim512"] = he
             if not args.no_cpu_baseline:
                 out["config3_full_hybrid"]["cpu_baseline"] = cpu_baseline_hybrid(args.latent)
         if world == 1 and not args.no_cpu_baseline:

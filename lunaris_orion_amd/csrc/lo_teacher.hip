@@ -177,6 +177,8 @@ struct BnApplyArgs {
   const float* cvec;
   int ss_stride;   // floats between the (scale, shift) tables of consecutive samples: 0 = one table (BatchNorm), 2*C = per sample (BatchNorm + Dropout2d)
   uint8_t* y8;     // fp8 mode: e4m3(y * LO_F8_ACT_SCALE) copy of y ([pix][C], no pitch), the operand of the next 3x3 convolution; or null
+  const float* id_ss;   // mode 1: the identity branch is BatchNorm(identity) with this (scale, shift) table [C][2] (ExpertBlock.shortcut
+                        // = Conv1x1 + BatchNorm when in_channels != out_channels, lunar_evaluator.py:254-257); null: identity as stored
 };
 __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   __shared__ float s_red[256 * 8];
@@ -184,12 +186,14 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
   const int C = a.C, CC = C >> 3;
   const int cc = tid % CC, slot = tid / CC, nslot = 256 / CC;
   const int c0 = cc * 8;
-  float sc[8], sh[8], lsv[8], acc[8];
+  float sc[8], sh[8], lsv[8], acc[8], isc[8], ish[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sc[j] = a.ss[(size_t)n * a.ss_stride + (c0 + j) * 2];
     sh[j] = a.ss[(size_t)n * a.ss_stride + (c0 + j) * 2 + 1];
     lsv[j] = a.mode >= 1 ? a.ls[c0 + j] : 1.f;
+    isc[j] = a.id_ss ? a.id_ss[(c0 + j) * 2] : 1.f;
+    ish[j] = a.id_ss ? a.id_ss[(c0 + j) * 2 + 1] : 0.f;
     acc[j] = 0.f;
   }
   const size_t row0 = (size_t)n * T_HW + (size_t)blk * a.rows_per_block;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void lo_bn_apply_kernel(BnApplyArgs a) {
         for (int j = 0; j < 8; ++j) {
           float v = (float)h[u][j] * sc[j] + sh[j];
           if (a.mode >= 1) {
-            v = v * lsv[j] + (float)idv[u][j];
+            v = v * lsv[j] + ((float)idv[u][j] * isc[j] + ish[j]);
             v = v > 0.f ? v : 0.2f * v;
           }
           o[j] = (f16)v;
@@ -419,6 +423,86 @@ __global__ __launch_bounds__(256) void lo_t_attn_kernel(const f16* __restrict__ 
     f16* dst = att + ((size_t)b * T_HW + p) * 128 + head * 16;
     *reinterpret_cast<f16x8*>(dst) = o0;
     *reinterpret_cast<f16x8*>(dst + 8) = o1;
+  }
+}
+
+// The same attention for any feature_dim F = 8 * HD (generic path, feature_dim != 128): qkv [B][16384][3F] fp16 (channel =
+// t*F + head*HD + d), output on the compact rows attc [B][1024][F] (positions >= 543 are never written and stay zero).
+// thr != 0: attn_drop on the probabilities, element index ((b*543 + p)*8 + head)*32 + key of site ds (lunar_evaluator.py:212).
+template <int HD>
+__global__ __launch_bounds__(256) void lo_t_attn_generic_kernel(const f16* __restrict__ qkv, f16* __restrict__ attc, int B, LoDropSite ds,
+                                                                uint32_t thr, float inv_keep) {
+  constexpr int F = 8 * HD, NV = HD / 8;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int per_b = 512 + 31;
+  if (wave_g >= B * per_b) return;
+  const int b = wave_g / per_b, p = wave_g - b * per_b;
+  const int chunk = p < 512 ? p : 511;
+  const int qtok = p < 512 ? 32 * p : 32 * 511 + (p - 511);
+  const int head = lane >> 3, part = lane & 7;
+  const f16* base = qkv + (size_t)b * T_HW * (3 * F);
+  f16x8 qv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) qv[i] = *reinterpret_cast<const f16x8*>(base + (size_t)qtok * (3 * F) + head * HD + 8 * i);
+  float sc[4];
+  const float scale = HD == 16 ? 0.25f : (HD == 32 ? 0.17677669529663687f : 0.125f);   // head_dim ** -0.5
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16* kp = base + (size_t)(32 * chunk + part * 4 + k) * (3 * F) + F + head * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const f16x8 kv = *reinterpret_cast<const f16x8*>(kp + 8 * i);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) s += (float)qv[i][d] * (float)kv[d];
+    }
+    sc[k] = s * scale;                // the relative-position term is constant along the keys: no effect on the softmax
+  }
+  float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float e[4], l = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { e[k] = __expf(sc[k] - m); l += e[k]; }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) l += __shfl_xor(l, o, 64);
+  float pw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pw[k] = e[k] / l;
+  if (thr) {
+    const uint32_t i0 = ((uint32_t)(b * 543 + p) * 8u + (uint32_t)head) * 32u + (uint32_t)part * 4u;
+    const uint32_t w0 = lo_drop_word(ds, i0 >> 1), w1 = lo_drop_word(ds, (i0 >> 1) + 1);
+    pw[0] = (w0 & 0xFFFFu) >= thr ? pw[0] * inv_keep : 0.f;
+    pw[1] = (w0 >> 16) >= thr ? pw[1] * inv_keep : 0.f;
+    pw[2] = (w1 & 0xFFFFu) >= thr ? pw[2] * inv_keep : 0.f;
+    pw[3] = (w1 >> 16) >= thr ? pw[3] * inv_keep : 0.f;
+  }
+  float acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16* vp = base + (size_t)(32 * chunk + part * 4 + k) * (3 * F) + 2 * F + head * HD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const f16x8 vv = *reinterpret_cast<const f16x8*>(vp + 8 * i);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[8 * i + d] += pw[k] * (float)vv[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < HD; ++d)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) acc[d] += __shfl_xor(acc[d], o, 64);
+  if (part == 0) {
+    f16* dst = attc + ((size_t)b * 1024 + p) * F + head * HD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f16x8 o8;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) o8[d] = (f16)acc[8 * i + d];
+      *reinterpret_cast<f16x8*>(dst + 8 * i) = o8;
+    }
   }
 }
 
@@ -667,22 +751,24 @@ __global__ __launch_bounds__(256) void lo_t_cat_bn_drop_kernel(f16* __restrict__
 // projc [B][1024][128] on image rows 0..7 and fp16(proj.bias) everywhere else (what the dense 1x1 conv stores for a zero
 // attention row).  Element index (b*HW + pix)*128 + c.
 // out8 != null (fp8 mode): the tensor is written as e4m3(value * LO_F8_ACT_SCALE) bytes instead of fp16 (conv2 is its only reader).
+// lgc8 = log2(C / 8): C = 128 / 256 / 512 channels per pixel.  thr = 0: no dropout (every element kept, inv_keep = 1): the plain
+// expansion of the compact tensor that the generic (feature_dim != 128) path uses in eval mode.
 __global__ __launch_bounds__(256) void lo_t_projdrop_kernel(const f16* __restrict__ projc, const float* __restrict__ pbias,
                                                             f16* __restrict__ out, uint8_t* __restrict__ out8, size_t nchunk, LoDropSite ds,
-                                                            uint32_t thr, float inv_keep) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8-channel chunk of pixel i >> 4
+                                                            uint32_t thr, float inv_keep, int lgc8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8-channel chunk i & (C/8 - 1) of pixel i >> lgc8
   if (i >= nchunk) return;
-  const int c0 = (int)(i & 15) * 8;
-  const size_t gp = i >> 4;
+  const int c0 = (int)(i & ((1u << lgc8) - 1)) * 8;
+  const size_t gp = i >> lgc8;
   const int pix = (int)(gp & (T_HW - 1));
   const size_t b = gp >> 14;
   f16x8 v, o;
-  if (pix < 1024) v = *reinterpret_cast<const f16x8*>(projc + (b * 1024 + pix) * 128 + c0);
+  if (pix < 1024) v = *reinterpret_cast<const f16x8*>(projc + ((b * 1024 + pix) << (lgc8 + 3)) + c0);
   else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (f16)pbias[c0 + j];
   }
-  const uint32_t keep = lo_drop_keep8(ds, (uint32_t)(i * 8), thr);
+  const uint32_t keep = thr ? lo_drop_keep8(ds, (uint32_t)(i * 8), thr) : 0xFFu;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? (f16)((float)v[j] * inv_keep) : (f16)0.f;
   if (out8) {
@@ -838,6 +924,7 @@ struct HeadsArgs {
   float *quality, *weights, *style_out, *prompt_out, *sem_out;   // [B][4], [B][E], [B][emb], [B][emb], [B][1]
   float* raw_q;                  // [B][E][4] pre-weighting quality logits (kept for the backward)
   int B, E, I, emb;
+  int F;                         // feature_dim: width of the experts' pooled features (the gate always sees the extractor's 128)
   // nn.Dropout after the hidden LeakyReLU of the gate and of every head (lunar_evaluator.py:353-397); thr = 0: off
   uint32_t thr; float inv_keep;
   LoDropSite ds_gate, ds_q[8], ds_sem, ds_style, ds_prompt;
@@ -848,20 +935,22 @@ __device__ void t_dropout(float* h, int n, int row, LoDropSite ds, uint32_t thr,
   for (int o = tid; o < n; o += 256) h[o] = lo_drop_keep(ds, (uint32_t)(row * n + o), thr) ? h[o] * inv_keep : 0.f;
   __syncthreads();
 }
-__device__ void t_layernorm(const float* x, const float* w, const float* b, float* y, float* scratch, int tid) {
-  // 128 features; threads 0..127
-  float v = tid < 128 ? x[tid] : 0.f;
-  float s = lo_wave_sum(v);
+#define T_FMAX 512   // largest feature_dim
+__device__ void t_layernorm(const float* x, const float* w, const float* b, float* y, float* scratch, int tid, int F) {
+  // F <= 512 features, 256 threads: two elements per thread; fixed-order wave + cross-wave sums
+  float v0 = tid < F ? x[tid] : 0.f, v1 = tid + 256 < F ? x[tid + 256] : 0.f;
+  float s = lo_wave_sum(v0 + v1);
   if ((tid & 63) == 0) scratch[tid >> 6] = s;
   __syncthreads();
-  float mean = (scratch[0] + scratch[1]) / 128.f;
+  const float mean = (((scratch[0] + scratch[1]) + scratch[2]) + scratch[3]) / (float)F;
   __syncthreads();
-  float d = tid < 128 ? v - mean : 0.f;
-  float q = lo_wave_sum(d * d);
+  const float d0 = tid < F ? v0 - mean : 0.f, d1 = tid + 256 < F ? v1 - mean : 0.f;
+  float q = lo_wave_sum(d0 * d0 + d1 * d1);
   if ((tid & 63) == 0) scratch[tid >> 6] = q;
   __syncthreads();
-  float var = (scratch[0] + scratch[1]) / 128.f;
-  if (tid < 128) y[tid] = d / sqrtf(var + LN_EPS) * w[tid] + b[tid];
+  const float rstd = 1.f / sqrtf((((scratch[0] + scratch[1]) + scratch[2]) + scratch[3]) / (float)F + LN_EPS);
+  if (tid < F) y[tid] = d0 * rstd * w[tid] + b[tid];
+  if (tid + 256 < F) y[tid + 256] = d1 * rstd * w[tid + 256] + b[tid + 256];
   __syncthreads();
 }
 __device__ void t_linear(const float* x, int nin, const float* w, const float* b, float* y, int nout, int lrelu, int tid) {
@@ -873,8 +962,8 @@ __device__ void t_linear(const float* x, int nin, const float* w, const float* b
   __syncthreads();
 }
 __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
-  __shared__ float xin[128], xn[128], h1[256], o2[512], wts[8], ql[8][4], scratch[8], comb[128];
-  const int tid = threadIdx.x, n = blockIdx.x;
+  __shared__ float xin[T_FMAX], xn[T_FMAX], h1[256], o2[512], wts[8], ql[8][4], scratch[8], comb[T_FMAX];
+  const int tid = threadIdx.x, n = blockIdx.x, F = a.F;
   // gate
   if (tid < 128) xin[tid] = a.pooled_f[n * 128 + tid];
   __syncthreads();
@@ -888,20 +977,20 @@ __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
     for (int e = 0; e < a.E; ++e) { wts[e] /= l; a.weights[n * a.E + e] = wts[e]; }
   }
   __syncthreads();
-  if (tid < 128) comb[tid] = 0.f;
+  for (int c = tid; c < F; c += 256) comb[c] = 0.f;
   __syncthreads();
   for (int e = 0; e < a.E; ++e) {
-    if (tid < 128) { xin[tid] = a.pooled_e[((size_t)e * a.B + n) * 128 + tid]; comb[tid] += wts[e] * xin[tid]; }
+    for (int c = tid; c < F; c += 256) { xin[c] = a.pooled_e[((size_t)e * a.B + n) * F + c]; comb[c] += wts[e] * xin[c]; }
     __syncthreads();
-    t_layernorm(xin, a.q[e].ln_w, a.q[e].ln_b, xn, scratch, tid);
-    t_linear(xn, 128, a.q[e].w1, a.q[e].b1, h1, a.I / 4, 1, tid);
+    t_layernorm(xin, a.q[e].ln_w, a.q[e].ln_b, xn, scratch, tid, F);
+    t_linear(xn, F, a.q[e].w1, a.q[e].b1, h1, a.I / 4, 1, tid);
     t_dropout(h1, a.I / 4, n, a.ds_q[e], a.thr, a.inv_keep, tid);
     t_linear(h1, a.I / 4, a.q[e].w2, a.q[e].b2, o2, 4, 0, tid);
     if (tid < 4) { ql[e][tid] = o2[tid]; a.raw_q[((size_t)n * a.E + e) * 4 + tid] = o2[tid]; }
     __syncthreads();
     if (e == 0) {
-      t_layernorm(xin, a.sem.ln_w, a.sem.ln_b, xn, scratch, tid);
-      t_linear(xn, 128, a.sem.w1, a.sem.b1, h1, a.I / 2, 1, tid);
+      t_layernorm(xin, a.sem.ln_w, a.sem.ln_b, xn, scratch, tid, F);
+      t_linear(xn, F, a.sem.w1, a.sem.b1, h1, a.I / 2, 1, tid);
       t_dropout(h1, a.I / 2, n, a.ds_sem, a.thr, a.inv_keep, tid);
       t_linear(h1, a.I / 2, a.sem.w2, a.sem.b2, o2, 1, 0, tid);
       if (tid == 0) a.sem_out[n] = 1.f / (1.f + __expf(-o2[0]));
@@ -917,8 +1006,8 @@ __global__ __launch_bounds__(256) void lo_t_heads_kernel(HeadsArgs a) {
   for (int which = 0; which < 2; ++which) {
     const HeadW& hw = which ? a.prompt : a.style;
     float* dst = which ? a.prompt_out : a.style_out;
-    t_layernorm(comb, hw.ln_w, hw.ln_b, xn, scratch, tid);
-    t_linear(xn, 128, hw.w1, hw.b1, h1, a.I / 2, 1, tid);
+    t_layernorm(comb, hw.ln_w, hw.ln_b, xn, scratch, tid, F);
+    t_linear(xn, F, hw.w1, hw.b1, h1, a.I / 2, 1, tid);
     t_dropout(h1, a.I / 2, n, which ? a.ds_prompt : a.ds_style, a.thr, a.inv_keep, tid);
     t_linear(h1, a.I / 2, hw.w2, hw.b2, o2, a.emb, 0, tid);
     for (int o = tid; o < a.emb; o += 256) dst[(size_t)n * a.emb + o] = o2[o];
@@ -941,13 +1030,13 @@ struct HeadsBwdArgs {
   size_t o_g_w1, o_g_b1, o_g_w2, o_g_b2;            // offsets inside a row
   size_t o_q[8][6];                                 // ln_w, ln_b, w1, b1, w2, b2
   float scale;                                      // -(quality_weight/accum) / (B*4)
-  int B, E, I;
+  int B, E, I, F;
   uint32_t thr; float inv_keep;                     // the forward's dropout (same call seed): gate and quality-head hidden layers
   LoDropSite ds_gate, ds_q[8];
 };
 __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
-  __shared__ float x[128], xh[128], ln[128], a1[256], h1[256], dz[8], dw[8], dq[8][4], dh[256], da[256], scratch[8], wts[8];
-  const int tid = threadIdx.x, n = blockIdx.x;
+  __shared__ float x[128], xh[T_FMAX], ln[T_FMAX], a1[256], h1[256], dz[8], dw[8], dq[8][4], dh[256], da[256], scratch[8], wts[8];
+  const int tid = threadIdx.x, n = blockIdx.x, F = a.F;
   float* row = a.rows + (size_t)n * a.row_len;
   if (tid < a.E) wts[tid] = a.weights[n * a.E + tid];
   __syncthreads();
@@ -997,22 +1086,24 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
   const int H = a.I / 4;
   for (int e = 0; e < a.E; ++e) {
     const HeadW& hw = a.q[e];
-    float v = tid < 128 ? a.pooled_e[((size_t)e * a.B + n) * 128 + tid] : 0.f;
-    float s = lo_wave_sum(v);
+    const float v0 = tid < F ? a.pooled_e[((size_t)e * a.B + n) * F + tid] : 0.f;
+    const float v1 = tid + 256 < F ? a.pooled_e[((size_t)e * a.B + n) * F + tid + 256] : 0.f;
+    float s = lo_wave_sum(v0 + v1);
     if ((tid & 63) == 0) scratch[tid >> 6] = s;
     __syncthreads();
-    float mean = (scratch[0] + scratch[1]) / 128.f;
+    const float mean = (((scratch[0] + scratch[1]) + scratch[2]) + scratch[3]) / (float)F;
     __syncthreads();
-    float d = tid < 128 ? v - mean : 0.f;
-    float qv = lo_wave_sum(d * d);
+    const float d0 = tid < F ? v0 - mean : 0.f, d1 = tid + 256 < F ? v1 - mean : 0.f;
+    float qv = lo_wave_sum(d0 * d0 + d1 * d1);
     if ((tid & 63) == 0) scratch[tid >> 6] = qv;
     __syncthreads();
-    float rstd = 1.f / sqrtf((scratch[0] + scratch[1]) / 128.f + LN_EPS);
-    if (tid < 128) { xh[tid] = d * rstd; ln[tid] = xh[tid] * hw.ln_w[tid] + hw.ln_b[tid]; }
+    const float rstd = 1.f / sqrtf((((scratch[0] + scratch[1]) + scratch[2]) + scratch[3]) / (float)F + LN_EPS);
+    if (tid < F) { xh[tid] = d0 * rstd; ln[tid] = xh[tid] * hw.ln_w[tid] + hw.ln_b[tid]; }
+    if (tid + 256 < F) { xh[tid + 256] = d1 * rstd; ln[tid + 256] = xh[tid + 256] * hw.ln_w[tid + 256] + hw.ln_b[tid + 256]; }
     __syncthreads();
     if (tid < H) {
       float acc = hw.b1[tid];
-      for (int i = 0; i < 128; ++i) acc += hw.w1[tid * 128 + i] * ln[i];
+      for (int i = 0; i < F; ++i) acc += hw.w1[tid * F + i] * ln[i];
       a1[tid] = acc;
       h1[tid] = acc > 0.f ? acc : 0.2f * acc;
     }
@@ -1026,12 +1117,12 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
     }
     if (tid < 4) row[a.o_q[e][5] + tid] = dq[e][tid];
     __syncthreads();
-    for (int idx = tid; idx < H * 128; idx += 256) row[a.o_q[e][2] + idx] = da[idx >> 7] * ln[idx & 127];
-    if (tid < 128) {
+    for (int idx = tid; idx < H * F; idx += 256) row[a.o_q[e][2] + idx] = da[idx / F] * ln[idx % F];
+    for (int c = tid; c < F; c += 256) {
       float t = 0.f;
-      for (int i = 0; i < H; ++i) t += hw.w1[i * 128 + tid] * da[i];
-      row[a.o_q[e][0] + tid] = t * xh[tid];   // d LayerNorm weight
-      row[a.o_q[e][1] + tid] = t;             // d LayerNorm bias
+      for (int i = 0; i < H; ++i) t += hw.w1[i * F + c] * da[i];
+      row[a.o_q[e][0] + c] = t * xh[c];   // d LayerNorm weight
+      row[a.o_q[e][1] + c] = t;           // d LayerNorm bias
     }
     __syncthreads();
   }
@@ -1069,6 +1160,9 @@ __global__ void lo_hybrid_reward_kernel(const float* __restrict__ quality, const
 // ---------------------------------------------------------------------------------------------
 struct LoTeacher {
   int B, E, I, emb, layers;
+  int F;                      // feature_dim: 128 (fast paths below) or 256 / 512 (generic path: every tensor at full resolution)
+  LoGeom g3a, g3b, gqF, gsc, gpc;   // generic path: conv 128->F, conv F->F, qkv F->3F, shortcut 128->F (1x1), proj on the compact rows
+  size_t o_wsc[8], o_sc, o_ss_sc, o_attc;   // packed shortcut weights per expert, raw shortcut output, its (scale, shift), compact attention rows
   std::vector<std::string> names;
   std::unordered_map<std::string, size_t> index;   // names[i] -> i
   std::vector<size_t> off, numel;
@@ -1120,11 +1214,13 @@ extern "C" int lo_teacher_create(int B, int num_experts, int feature_dim, int em
 extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int embedding_dim, unsigned flags, LoTeacher** out) {
   LO_REQUIRE(out && B >= 1, "lo_teacher_create: bad argument");
   LO_REQUIRE((flags & ~(unsigned)LO_TEACHER_FP8_CONV) == 0, "lo_teacher_create_ex: unknown flag bits 0x%x", flags);
-  LO_REQUIRE(feature_dim == 128, "lo_teacher_create: feature_dim %d is not built (only the CLI default 128)", feature_dim);
+  LO_REQUIRE(feature_dim == 128 || feature_dim == 256 || feature_dim == 512,
+             "lo_teacher_create: feature_dim %d is not built (128 = the CLI default, 256, 512 = the README's High-End recipe)", feature_dim);
+  const int F = feature_dim;
   LO_REQUIRE(num_experts >= 1 && num_experts <= 8, "lo_teacher_create: num_experts %d out of range", num_experts);
   LO_REQUIRE(embedding_dim >= 1 && embedding_dim <= 512, "lo_teacher_create: embedding_dim %d out of range", embedding_dim);
   LoTeacher* h = new LoTeacher();
-  h->B = B; h->E = num_experts; h->I = 256; h->emb = embedding_dim; h->layers = 3;
+  h->B = B; h->E = num_experts; h->I = 256; h->emb = embedding_dim; h->layers = 3; h->F = F;
   h->att_zeroed = false; h->att_zeroed_ws = nullptr;
   h->last_p = 0.f; h->last_seed = 0; h->last_path = -1;
   // ---- state table in the reference's state_dict order (lunar_evaluator.py; checked against the oracle in tests)
@@ -1144,22 +1240,24 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
   for (int e = 0; e < num_experts; ++e)
     for (int l = 0; l < 3; ++l) {
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
-      add(p + ".layer_scale", 128);
-      conv(p + ".conv1.0", 128, 128, 3); bn(p + ".conv1.2", 128);
+      const int cin = l == 0 ? 128 : F;
+      add(p + ".layer_scale", F);
+      conv(p + ".conv1.0", F, cin, 3); bn(p + ".conv1.2", F);
       add(p + ".attention.rel_pos_h", 64); add(p + ".attention.rel_pos_w", 64); add(p + ".attention.last_spatial_shapes", 2);
-      conv(p + ".attention.qkv", 384, 128, 1); conv(p + ".attention.proj", 128, 128, 1);
-      conv(p + ".conv2.0", 128, 128, 3); bn(p + ".conv2.2", 128);
+      conv(p + ".attention.qkv", 3 * F, F, 1); conv(p + ".attention.proj", F, F, 1);
+      conv(p + ".conv2.0", F, F, 3); bn(p + ".conv2.2", F);
+      if (cin != F) { conv(p + ".shortcut.0", F, cin, 1); bn(p + ".shortcut.1", F); }   // ExpertBlock.shortcut (lunar_evaluator.py:254-257)
     }
   lin("gate.2", 256, 128); lin("gate.5", num_experts, 256);
   for (int e = 0; e < num_experts; ++e) {
     std::string p = "quality_heads." + std::to_string(e);
-    add(p + ".2.weight", 128); add(p + ".2.bias", 128); lin(p + ".3", 64, 128); lin(p + ".6", 4, 64);
+    add(p + ".2.weight", F); add(p + ".2.bias", F); lin(p + ".3", 64, F); lin(p + ".6", 4, 64);
   }
   const char* hn[3] = {"semantic_head", "style_net", "prompt_net"};
   const int ho[3] = {1, embedding_dim, embedding_dim};
   for (int k = 0; k < 3; ++k) {
     std::string p = hn[k];
-    add(p + ".2.weight", 128); add(p + ".2.bias", 128); lin(p + ".3", 128, 128); lin(p + ".6", ho[k], 128);
+    add(p + ".2.weight", F); add(p + ".2.bias", F); lin(p + ".3", 128, F); lin(p + ".6", ho[k], 128);
   }
   for (size_t i = 0; i < h->names.size(); ++i) h->index[h->names[i]] = i;
   size_t o = 0;
@@ -1181,22 +1279,33 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
   h->o_raw32 = take(px * 32 * 2); h->o_dw = take(px * 32 * 2);
   for (int b = 0; b < 3; ++b) h->o_br[b] = take(px * 64 * 2);
   h->o_cat = take(px * 192 * 2);
-  h->o_feat = take(px * 128 * 2); h->o_x0 = take(px * 128 * 2); h->o_x1 = take(px * 128 * 2);
-  h->o_rawA = take(px * 128 * 2); h->o_bnA = take(px * 128 * 2); h->o_qkv = take(px * 384 * 2);
-  h->o_att = take(px * 128 * 2); h->o_proj = take(px * 128 * 2); h->o_rawB = take(px * 128 * 2);
-  h->o_bnp = take((size_t)B * 128 * 128 * 2 * 4 + 65536);   // rows <= B*128, C <= 128
-  h->o_bnpre = take(64 * 128 * 2 * 4);
-  h->o_ss = take(192 * 2 * 4 + 256);
-  h->o_poolp = take((size_t)B * 64 * 128 * 4);
+  h->o_feat = take(px * 128 * 2); h->o_x0 = take(px * F * 2); h->o_x1 = take(px * F * 2);
+  h->o_rawA = take(px * F * 2); h->o_bnA = take(px * F * 2); h->o_qkv = take(px * 3 * F * 2);
+  h->o_att = take(px * 128 * 2); h->o_proj = take(px * F * 2); h->o_rawB = take(px * F * 2);
+  h->o_bnp = take((size_t)(px / 64) * F * 2 * 4 + 65536);   // BatchNorm partial rows: one per >= 64-pixel tile, C <= F
+  h->o_bnpre = take((size_t)64 * F * 2 * 4);
+  h->o_ss = take((size_t)(2 * T_FMAX + 2 * 192 + 64) * 4);   // [C <= 512][2], then the feature extractor's private 32-channel table
+  h->o_poolp = take((size_t)B * 64 * F * 4);
   h->o_pool_f = take((size_t)B * 128 * 4);
-  h->o_pool_e = take((size_t)num_experts * B * 128 * 4);
+  h->o_pool_e = take((size_t)num_experts * B * F * 4);
   h->o_rawq = take((size_t)B * num_experts * 4 * 4);
   for (int e = 0; e < num_experts; ++e)
     for (int l = 0; l < 3; ++l) {
-      for (int c = 0; c < 2; ++c) h->o_wp3[e][l][c] = take((size_t)128 * 9 * 128 * 2);
-      h->o_wqkv[e][l] = take((size_t)384 * 128 * 2);
-      h->o_wproj[e][l] = take((size_t)128 * 128 * 2);
+      for (int c = 0; c < 2; ++c) h->o_wp3[e][l][c] = take((size_t)F * 9 * F * 2);
+      h->o_wqkv[e][l] = take((size_t)3 * F * F * 2);
+      h->o_wproj[e][l] = take((size_t)F * F * 2);
     }
+  if (F != 128) {
+    LO_TRYT(lo_make_geom(&h->g3a, LO_CONV3_S1, B, 128, 128, 128, F));
+    LO_TRYT(lo_make_geom(&h->g3b, LO_CONV3_S1, B, 128, 128, F, F));
+    LO_TRYT(lo_make_geom(&h->gqF, LO_LINEAR, B, 128, 128, F, 3 * F));
+    LO_TRYT(lo_make_geom(&h->gsc, LO_LINEAR, B, 128, 128, 128, F));
+    LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, F, F));
+    for (int e = 0; e < num_experts; ++e) h->o_wsc[e] = take((size_t)F * 128 * 2);
+    h->o_sc = take(px * F * 2);
+    h->o_ss_sc = take((size_t)F * 2 * 4);
+    h->o_attc = take((size_t)B * 1024 * F * 2);
+  }
   for (int b = 0; b < 3; ++b) h->o_wpw[b] = take((size_t)64 * 32 * 2);
   h->o_wfus = take((size_t)128 * 192 * 2);
   h->o_wfus_fold = take((size_t)128 * 192 * 2);
@@ -1213,7 +1322,7 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
   h->o_projc = take(cpx * 128 * 2); h->o_rawBc = take(cpx * 128 * 2);
   {
     const char* ft = getenv("LO_T_FUSE_TAIL");
-    h->fuse_tail = h->sparse && !(ft && atoi(ft) == 0) && lo_conv3_pp_applies(h->g3);
+    h->fuse_tail = F == 128 && h->sparse && !(ft && atoi(ft) == 0) && lo_conv3_pp_applies(h->g3);
   }
   for (int k = 0; k < 2; ++k) h->o_xc[k] = take(cpx * 128 * 2);
   h->o_xc3 = take((size_t)num_experts * cpx * 128 * 2);
@@ -1227,8 +1336,8 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
       h->o_cvec[e][l] = take(6 * 128 * 4);
       h->o_wu[e][l] = take((size_t)1024 * 128 * 2); h->o_ub[e][l] = take(1024 * 4); h->o_wz[e][l] = take((size_t)128 * 1088 * 2);
     }
-  h->o_ssb = take((size_t)B * 128 * 2 * 4);
-  h->fp8 = (flags & LO_TEACHER_FP8_CONV) != 0 && lo_conv3_pp_f8_applies(h->g3);
+  h->o_ssb = take((size_t)B * F * 2 * 4);
+  h->fp8 = (flags & LO_TEACHER_FP8_CONV) != 0 && F == 128 && lo_conv3_pp_f8_applies(h->g3);
   if (h->fp8) {
     for (int e = 0; e < num_experts; ++e)
       for (int l = 0; l < 3; ++l)
@@ -1254,9 +1363,19 @@ extern "C" size_t lo_teacher_workspace_bytes(const LoTeacher* h) { return h->ws_
 extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* stream) {
   LO_REQUIRE(h && P && ws, "lo_teacher_pack: null argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int F = h->F;
   for (int e = 0; e < h->E; ++e)
     for (int l = 0; l < 3; ++l) {
       std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
+      if (F != 128) {
+        // generic path: plain operand copies, nothing folded
+        LO_TRYT(lo_pack_weight(TP(p + ".conv1.0.weight"), TW(f16, h->o_wp3[e][l][0]), l == 0 ? h->g3a : h->g3b, st));
+        LO_TRYT(lo_pack_weight(TP(p + ".conv2.0.weight"), TW(f16, h->o_wp3[e][l][1]), h->g3b, st));
+        LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.qkv.weight"), TW(f16, h->o_wqkv[e][l]), (size_t)3 * F * F, st));
+        LO_TRYT(lo_cast_f32_f16(TP(p + ".attention.proj.weight"), TW(f16, h->o_wproj[e][l]), (size_t)F * F, st));
+        if (l == 0) LO_TRYT(lo_cast_f32_f16(TP(p + ".shortcut.0.weight"), TW(f16, h->o_wsc[e]), (size_t)F * 128, st));
+        continue;
+      }
       LO_TRYT(lo_pack_weight(TP(p + ".conv1.0.weight"), TW(f16, h->o_wp3[e][l][0]), h->g3, st));
       LO_TRYT(lo_pack_weight(TP(p + ".conv2.0.weight"), TW(f16, h->o_wp3[e][l][1]), h->g3, st));
       if (h->fp8)
@@ -1300,9 +1419,9 @@ static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, co
 }
 static int t_bn_apply(LoTeacher* h, const f16* raw, const float* ls, const f16* identity, f16* y, int C, int dst_pitch, int dst_off,
                       int mode, float* pool_partial, void* ws, hipStream_t st, const float* cvec = nullptr, bool per_sample = false,
-                      uint8_t* y8 = nullptr) {
+                      uint8_t* y8 = nullptr, const float* id_ss = nullptr) {
   BnApplyArgs a{raw, per_sample ? TW(float, h->o_ssb) : TW(float, h->o_ss), ls, identity, y, pool_partial, C, dst_pitch, dst_off, mode,
-                T_HW / 64, cvec, per_sample ? 2 * C : 0, y8};
+                T_HW / 64, cvec, per_sample ? 2 * C : 0, y8, id_ss};
   LoProfScope _p(mode ? "lo_bn_apply (block tail)" : "lo_bn_apply", 0, 2.0 * h->B * T_HW * C * (mode == 1 ? 3 : 2), st);
   hipLaunchKernelGGL(lo_bn_apply_kernel, dim3(64, h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("bn_apply");
@@ -1348,6 +1467,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
     LO_HIP(hipMemsetAsync(TW(void, h->o_Z), 0, (size_t)B * 1024 * 1088 * 2, st));    // rows >= 543 of every sample stay zero
     LO_HIP(hipMemsetAsync(TW(void, h->o_qin), 0, (size_t)h->qrows * 128 * 2, st));
+    if (h->F != 128) LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * h->F * 2, st));   // rows >= 543 of every sample stay zero
     h->att_zeroed = true; h->att_zeroed_ws = ws;
   }
   float* bnp = TW(float, h->o_bnp);
@@ -1361,7 +1481,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   }
   LO_LAUNCH_CHECK("t_conv1");
   // the depthwise convs read BN(conv1) through its (scale, shift): kept in a private slot, the shared one is reused below
-  float* ss32 = TW(float, h->o_ss) + 2 * 192;
+  float* ss32 = TW(float, h->o_ss) + 2 * T_FMAX + 2 * 192;
   LO_TRYT(t_bn_finalize(h, bnp, B * 128, 32, fe + ".conv1.2", P, ws, training, st, 1, 1, nullptr, ss32));
   const char* brs[3] = {"edge_branch", "color_branch", "detail_branch"};
   for (int b = 0; b < 3; ++b) {
@@ -1401,8 +1521,69 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
                      f8 ? TW(uint8_t, h->o_feat8) : nullptr));
   LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
   // ---- experts (lunar_evaluator.py:260-275, 422-428)
+  if (h->F != 128) {
+    // generic path (feature_dim 256 / 512, README High-End recipe): every tensor at full resolution; the attention keeps the
+    // reference's "only 543 positions are ever written" behaviour through compact rows (attc / projc) + one expansion pass,
+    // which is also where proj_drop is applied
+    const int F = h->F;
+    h->last_path = drop ? 2 : 1;
+    const int lgc8 = F == 256 ? 5 : 6;
+    for (int e = 0; e < h->E; ++e) {
+      const f16* xin = TW(f16, h->o_feat);
+      for (int l = 0; l < 3; ++l) {
+        std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
+        const LoGeom& g1 = l == 0 ? h->g3a : h->g3b;
+        f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
+        const float* id_ss = nullptr;
+        if (l == 0) {
+          // shortcut = BatchNorm(Conv1x1(x)) (in_channels 128 != out_channels F): raw output + its (scale, shift), applied in the tail
+          LoConvExtra exs{0, bnp};
+          LO_TAGGED("t_shortcut (igemm)", lo_conv_run(h->gsc, xin, TW(f16, h->o_wsc[e]), TP(p + ".shortcut.0.bias"), nullptr, TW(f16, h->o_sc), nullptr, nullptr, 1, st, nullptr, &exs));
+          LO_TRYT(t_bn_finalize(h, bnp, lo_conv_bn_rows(h->gsc), F, p + ".shortcut.1", P, ws, training, st, 1, 1, nullptr, TW(float, h->o_ss_sc)));
+          id_ss = TW(float, h->o_ss_sc);
+        }
+        LO_TAGGED("t_conv1 (generic)", lo_conv_run(g1, xin, TW(f16, h->o_wp3[e][l][0]), TP(p + ".conv1.0.bias"), nullptr, TW(f16, h->o_rawA), nullptr, nullptr, 1, st, nullptr, &ex));
+        LO_TRYT(t_bn_finalize(h, bnp, lo_conv_bn_rows(g1), F, p + ".conv1.2", P, ws, training, st));
+        if (drop) {
+          hipLaunchKernelGGL(lo_t_drop2d_ss_kernel, dim3((B * F + 255) / 256), dim3(256), 0, st, TW(float, h->o_ss), TW(float, h->o_ssb), B, F,
+                             site(LO_DS_BLOCK(e, l, 0)), thr, inv_keep);
+          LO_LAUNCH_CHECK("t_drop2d_ss");
+        }
+        LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawA), nullptr, nullptr, TW(f16, h->o_bnA), F, F, 0, 0, nullptr, ws, st, nullptr, drop));
+        LO_TAGGED("t_qkv (igemm)", lo_conv_run(h->gqF, TW(f16, h->o_bnA), TW(f16, h->o_wqkv[e][l]), TP(p + ".attention.qkv.bias"), nullptr, TW(f16, h->o_qkv), nullptr, nullptr, 1, st));
+        {
+          LoProfScope _p("lo_t_attn (generic)", 0, 0, st);
+          const dim3 grid((B * 543 + 3) / 4);
+          const LoDropSite dsa = site(LO_DS_BLOCK(e, l, 1));
+          if (F == 256) hipLaunchKernelGGL((lo_t_attn_generic_kernel<32>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
+          else hipLaunchKernelGGL((lo_t_attn_generic_kernel<64>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
+        }
+        LO_LAUNCH_CHECK("t_attn_generic");
+        LO_TAGGED("t_proj (igemm)", lo_conv_run(h->gpc, TW(f16, h->o_attc), TW(f16, h->o_wproj[e][l]), TP(p + ".attention.proj.bias"), nullptr, TW(f16, h->o_projc), nullptr, nullptr, 1, st));
+        {
+          LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * F, st);
+          const size_t nchunk = px * (F / 8);
+          hipLaunchKernelGGL(lo_t_projdrop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
+                             TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep, lgc8);
+        }
+        LO_LAUNCH_CHECK("t_projdrop");
+        LO_TAGGED("t_conv2 (generic)", lo_conv_run(h->g3b, TW(f16, h->o_proj), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), nullptr, TW(f16, h->o_rawB), nullptr, nullptr, 1, st, nullptr, &ex));
+        LO_TRYT(t_bn_finalize(h, bnp, lo_conv_bn_rows(h->g3b), F, p + ".conv2.2", P, ws, training, st));
+        if (drop) {
+          hipLaunchKernelGGL(lo_t_drop2d_ss_kernel, dim3((B * F + 255) / 256), dim3(256), 0, st, TW(float, h->o_ss), TW(float, h->o_ssb), B, F,
+                             site(LO_DS_BLOCK(e, l, 3)), thr, inv_keep);
+          LO_LAUNCH_CHECK("t_drop2d_ss");
+        }
+        if (l < 2 || !stats_only)
+          LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), l == 0 ? TW(f16, h->o_sc) : xin, l < 2 ? xout : nullptr, F, F, 0, 1,
+                             (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st, nullptr, drop, nullptr, id_ss));
+        xin = xout;
+      }
+      if (!stats_only) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * F, F, ws, st));
+    }
+  }
   const int mt3 = lo_conv_bn_rows(h->g3);   // BatchNorm partial rows of the conv1 epilogue (igemm: M tiles; fused-tap kernel: pixel tiles)
-  for (int e = 0; e < h->E; ++e) {
+  for (int e = 0; e < (h->F == 128 ? h->E : 0); ++e) {
     const f16* xin = TW(f16, h->o_feat);
     const uint8_t* xin8 = f8 ? TW(uint8_t, h->o_feat8) : nullptr;
     for (int l = 0; l < 3; ++l) {
@@ -1441,7 +1622,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * 128, st);
           const size_t nchunk = px * 16;
           hipLaunchKernelGGL(lo_t_projdrop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
-                             TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
+                             TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep, 4);
         }
         LO_LAUNCH_CHECK("t_projdrop");
         LO_TRYT(conv3(f8 ? "t_conv2 (dense, dropout path, e4m3)" : "t_conv2 (dense, dropout path)", TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, 1,
@@ -1546,7 +1727,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   a.sem = headw("semantic_head"); a.style = headw("style_net"); a.prompt = headw("prompt_net");
   a.quality = quality; a.weights = weights; a.style_out = style; a.prompt_out = prompt; a.sem_out = semantic;
   a.raw_q = TW(float, h->o_rawq);
-  a.B = B; a.E = h->E; a.I = h->I; a.emb = h->emb;
+  a.B = B; a.E = h->E; a.I = h->I; a.emb = h->emb; a.F = h->F;
   a.thr = thr; a.inv_keep = inv_keep;
   a.ds_gate = site(LO_DS_GATE); a.ds_sem = site(LO_DS_SEM); a.ds_style = site(LO_DS_STYLE); a.ds_prompt = site(LO_DS_PROMPT);
   for (int e = 0; e < h->E; ++e) a.ds_q[e] = site(LO_DS_QUALITY(e));
@@ -1603,7 +1784,7 @@ extern "C" int lo_teacher_heads_backward(LoTeacher* h, const float* P, void* ws,
   }
   a.rows = rows; a.row_len = b1 - b0;
   a.scale = -coef / ((float)h->B * 4.f);
-  a.B = h->B; a.E = h->E; a.I = h->I;
+  a.B = h->B; a.E = h->E; a.I = h->I; a.F = h->F;
   a.thr = h->last_p > 0.f ? (uint32_t)lrintf(h->last_p * 65536.f) : 0u;
   if (h->last_p > 0.f && a.thr == 0) a.thr = 1;
   a.inv_keep = h->last_p > 0.f ? 1.0f / (1.0f - h->last_p) : 1.0f;

@@ -17,7 +17,9 @@ constant-field shortcuts of the p = 0 path do not survive ``proj_drop``); eval m
 shortcut path.  The gate / quality-head gradients of ``teacher_loss`` are ``lo_teacher_heads_backward``
 (driven by ``trainer.HybridStepper``).
 
-Limits (stated, enforced): ``feature_dim == 128`` (the CLI default), ``feature_maps`` is always ``None``.
+``feature_dim``: 128 (the CLI default: folded attention + constant-field shortcuts when no dropout is active) or 256 / 512 (the
+README's High-End recipe, /root/reference/README.md:102-118: a generic path with every tensor at full resolution and the
+``ExpertBlock.shortcut`` Conv1x1 + BatchNorm of the first block, lunar_evaluator.py:254-257).  ``feature_maps`` is always ``None``.
 """
 from __future__ import annotations
 
@@ -106,8 +108,11 @@ class LunarMoETeacher(nn.Module):
         if mfma_precision not in ("fp16", "fp8"):
             raise ValueError(f"mfma_precision must be 'fp16' or 'fp8', got {mfma_precision!r}")
         self.mfma_precision = mfma_precision
-        if feature_dim != 128 or expert_layers != 3 or intermediate_dim != 256 or rel_pos_size != 8:
-            raise NotImplementedError("only feature_dim=128, expert_layers=3, intermediate_dim=256, rel_pos_size=8 (the CLI defaults) are built")
+        if feature_dim not in (128, 256, 512) or expert_layers != 3 or intermediate_dim != 256 or rel_pos_size != 8:
+            raise NotImplementedError("built: feature_dim 128 (the CLI default), 256 or 512 (README High-End recipe) with expert_layers=3, "
+                                      "intermediate_dim=256, rel_pos_size=8 (the CLI defaults)")
+        if feature_dim != 128 and mfma_precision != "fp16":
+            raise NotImplementedError("the fp8 operand mode covers feature_dim 128 only")
         self.num_experts, self.feature_dim, self.dropout_rate = num_experts, feature_dim, dropout_rate
         self.rel_pos_size, self.use_checkpointing, self.expert_layers = rel_pos_size, use_checkpointing, expert_layers
         self.intermediate_dim, self.embedding_dim = intermediate_dim, embedding_dim

@@ -35,7 +35,7 @@ def test_unsupported_feature_dim_is_refused_loudly(tmp_path):
     sys.path.insert(0, ROOT)
     import train_hybrid
     with pytest.raises(SystemExit) as e:
-        train_hybrid.main(["--data_dir", str(tmp_path), "--feature_dim", "512"])
+        train_hybrid.main(["--data_dir", str(tmp_path), "--feature_dim", "384"])
     assert "feature_dim" in str(e.value)
 
 

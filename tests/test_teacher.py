@@ -26,7 +26,13 @@ def test_module_state_dict_matches_reference_layout():
     assert float(m.experts[0][0].layer_scale.mean()) == pytest.approx(0.1)
     assert float(m.gate[2].bias.abs().max()) == 0.0 and float(m.feature_extractor.conv1[2].weight.min()) == 1.0
     with pytest.raises(NotImplementedError):
-        LunarMoETeacher(feature_dim=512)
+        LunarMoETeacher(feature_dim=384)
+    # README High-End recipe (feature_dim 512, embedding_dim 256): 62 936 405 parameters, first blocks get a shortcut
+    big = LunarMoETeacher(num_experts=4, feature_dim=512, embedding_dim=256)
+    shp = T.teacher_param_shapes(feature_dim=512, embedding_dim=256)
+    assert list(big.state_dict().keys()) == list(shp.keys())
+    assert all(tuple(v.shape) == tuple(shp[k]) for k, v in big.state_dict().items())
+    assert sum(p.numel() for p in big.parameters()) == 62_936_405 and "experts.0.0.shortcut.0.weight" in shp
 
 
 @pytest.mark.gpu
@@ -439,3 +445,87 @@ def test_hybrid_steps_match_the_references_own_process_batch_with_dropout():
     np.testing.assert_allclose(t.gate[2].weight.detach().cpu().numpy()[:4, :8], g["gate_w_after"], atol=2e-4)
     np.testing.assert_allclose(vae.encoder.fc_mu.bias.detach().cpu().numpy()[:16], g["vae_fc_mu_b_after"], atol=2e-4)
     assert abs(hs.lr - float(g["lr_after"])) <= 1e-12
+
+
+# ---- feature_dim 256 / 512 (README High-End recipe) -------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,B", [(256, 2), (512, 1)])
+def test_wide_teacher_forward_matches_reference_fixture_and_oracle(F, B):
+    """LunarMoETeacher(feature_dim=F, embedding_dim=256): eval mode and train mode with the default dropout (injected masks)
+    against the fixture the REFERENCE produced (tests/golden/teacher_F{F}_B{B}.npz) and the CPU oracle; BatchNorm running
+    statistics of the shortcut / conv layers included.  Same tolerances as feature_dim 128."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from oracle import dropout_ref as D
+    g = np.load(os.path.join(GOLD, f"teacher_F{F}_B{B}.npz"))
+    assert [int(v) for v in g["meta"]] == [B, 4, F, 256]
+    seed, p = int(g["drop_seed"]), float(g["drop_p"])
+    S = T.closed_form_teacher_state(feature_dim=F, embedding_dim=256)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}
+    for training in (False, True):
+        m = LunarMoETeacher(num_experts=4, feature_dim=F, embedding_dim=256)
+        m.load_state_dict(S)
+        m = m.to("cuda")
+        m.train(training)
+        m.set_dropout_stream(seed, exact_next=True)
+        out = m(x.cuda())
+        torch.cuda.synchronize()
+        tag = "train" if training else "eval"
+        assert m.last_path(B) == (2 if training else 1)
+        with torch.no_grad():
+            ref, new_stats = T.teacher_forward(x, S, training=training, masks=D.TeacherMasks(seed, p, B) if training else None)
+        for k, t in tol.items():
+            got = out[k].cpu()
+            d = (got - ref[k]).abs().max().item()
+            print(f"F={F} {tag}", k, d)
+            assert d <= t, (tag, k, d)
+            assert np.abs(got.numpy() - g[f"{tag}/{k}"]).max() <= t, (tag, k)
+        if training:
+            sd = m.state_dict()
+            for k in ("experts.0.0.shortcut.1.running_var", "experts.3.2.conv2.2.running_var", "experts.1.1.conv1.2.running_mean"):
+                ref_s = g["train/" + k]
+                assert np.abs(sd[k].cpu().numpy() - ref_s).max() <= 2e-3 * max(1.0, np.abs(ref_s).max()), k
+            assert int(sd["experts.2.0.shortcut.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.gpu
+def test_wide_teacher_head_gradients_and_hybrid_step():
+    """feature_dim 256: gate / quality-head gradients (LayerNorm over 256 features) vs autograd of the oracle with the same
+    dropout masks, then one full hybrid step through HybridStepper."""
+    import ctypes as C
+
+    from lunaris_orion_amd import _lib
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.trainer import HybridStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    from oracle import dropout_ref as D
+    F, B, seed, p = 256, 2, 0x0F0F0F0F12345678, 0.1
+    S = T.closed_form_teacher_state(feature_dim=F, embedding_dim=256)
+    m = LunarMoETeacher(feature_dim=F, embedding_dim=256); m.load_state_dict(S); m = m.to("cuda").train()
+    m.set_dropout_stream(seed, exact_next=True)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    out = m(x.cuda())
+    h, ws, _ = m._engine(B)
+    b, e = C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.lib.lo_teacher_grad_range(h, C.byref(b), C.byref(e)))
+    rows = torch.empty(B * (e.value - b.value), device="cuda")
+    grads = torch.zeros_like(m._flat)
+    _lib.check(_lib.lib.lo_teacher_heads_backward(h, m._flat.data_ptr(), ws.data_ptr(), out["expert_weights"].data_ptr(), 0.5,
+                                                  rows.data_ptr(), grads.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    S2 = {k: (v.clone().requires_grad_(True) if (k.startswith("gate.") or k.startswith("quality_heads.")) else v) for k, v in S.items()}
+    o, _ = T.teacher_forward(x, S2, training=True, masks=D.TeacherMasks(seed, p, B))
+    (0.5 * (-o["quality_scores"].mean())).backward()
+    for k, t in m._named_state():
+        if not (k.startswith("gate.") or k.startswith("quality_heads.")):
+            continue
+        off = (t.data_ptr() - m._flat.data_ptr()) // 4
+        gg = grads[off: off + t.numel()].view(t.shape).cpu()
+        ref = S2[k].grad
+        assert (gg - ref).norm().item() / (ref.norm().item() + 1e-12) <= 2e-2, k
+    L = 256
+    vae = LunarisCoreVAE(L); vae.load_state_dict(R.closed_form_params(L)); vae = vae.to("cuda")
+    hs = HybridStepper(vae, m, gradient_accumulation_steps=1)
+    hs.step(x.cuda(), 0, R.closed_form_eps(B, L, 0).cuda())
+    met = hs.metrics()
+    assert np.isfinite(list(met.values())).all() and met["grads_finite"] == 1.0 and 0.3 < met["quality_scores"] < 0.7

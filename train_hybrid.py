@@ -9,7 +9,7 @@ names (:929-942), the checkpoint dictionary keys (:596-606), SIGINT -> checkpoin
 
 What differs, deliberately: with the teacher on (the default flags) `HybridStepper` runs the full `_process_batch`
 as the reference executes it, teacher dropout 0.1 included (`--teacher_dropout`, a builder flag, defaults to the reference's
-constructor default; 0 selects the dropout-free fast path), and `--feature_dim` must stay 128; with
+constructor default; 0 selects the dropout-free fast path); `--feature_dim` 128 (default), 256 or 512 (README High-End recipe); with
 `--reward_scale 0 --quality_weight 0` (or `--vae_only`) the teacher is not run at all (its result cannot influence the
 VAE then) and the teacher-only metrics are reported as 0.  The reference's
 defects are not inherited: no tensorboard hard dependency, no DataLoader timeout assertion, per-epoch average
@@ -91,8 +91,8 @@ def main(argv=None):
     if args.force_cpu:
         raise SystemExit("--force_cpu: this build has no CPU path (the CPU oracle under oracle/ is test infrastructure only)")
     teacher_on = args.reward_scale != 0.0 or args.quality_weight != 0.0
-    if teacher_on and args.feature_dim != 128:
-        raise SystemExit("--feature_dim != 128 is not built yet (the teacher kernels are instantiated for the CLI default 128)")
+    if teacher_on and args.feature_dim not in (128, 256, 512):
+        raise SystemExit(f"--feature_dim {args.feature_dim} is not built: 128 (default), 256 and 512 (README High-End recipe) are")
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
