@@ -753,9 +753,10 @@ __global__ __launch_bounds__(256) void lo_t_cat_bn_drop_kernel(f16* __restrict__
 // out8 != null (fp8 mode): the tensor is written as e4m3(value * LO_F8_ACT_SCALE) bytes instead of fp16 (conv2 is its only reader).
 // lgc8 = log2(C / 8): C = 128 / 256 / 512 channels per pixel.  thr = 0: no dropout (every element kept, inv_keep = 1): the plain
 // expansion of the compact tensor that the generic (feature_dim != 128) path uses in eval mode.
+template <int lgc8>
 __global__ __launch_bounds__(256) void lo_t_projdrop_kernel(const f16* __restrict__ projc, const float* __restrict__ pbias,
                                                             f16* __restrict__ out, uint8_t* __restrict__ out8, size_t nchunk, LoDropSite ds,
-                                                            uint32_t thr, float inv_keep, int lgc8) {
+                                                            uint32_t thr, float inv_keep) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8-channel chunk i & (C/8 - 1) of pixel i >> lgc8
   if (i >= nchunk) return;
   const int c0 = (int)(i & ((1u << lgc8) - 1)) * 8;
@@ -1563,8 +1564,12 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         {
           LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * F, st);
           const size_t nchunk = px * (F / 8);
-          hipLaunchKernelGGL(lo_t_projdrop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
-                             TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep, lgc8);
+          if (lgc8 == 5)
+            hipLaunchKernelGGL((lo_t_projdrop_kernel<5>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
+                               TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
+          else
+            hipLaunchKernelGGL((lo_t_projdrop_kernel<6>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
+                               TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
         }
         LO_LAUNCH_CHECK("t_projdrop");
         LO_TAGGED("t_conv2 (generic)", lo_conv_run(h->g3b, TW(f16, h->o_proj), TW(f16, h->o_wp3[e][l][1]), TP(p + ".conv2.0.bias"), nullptr, TW(f16, h->o_rawB), nullptr, nullptr, 1, st, nullptr, &ex));
@@ -1621,8 +1626,8 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         {
           LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * 128, st);
           const size_t nchunk = px * 16;
-          hipLaunchKernelGGL(lo_t_projdrop_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
-                             TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep, 4);
+          hipLaunchKernelGGL((lo_t_projdrop_kernel<4>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
+                             TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
         }
         LO_LAUNCH_CHECK("t_projdrop");
         LO_TRYT(conv3(f8 ? "t_conv2 (dense, dropout path, e4m3)" : "t_conv2 (dense, dropout path)", TW(f16, h->o_proj), f8 ? TW(uint8_t, h->o_proj8) : nullptr, 1,
