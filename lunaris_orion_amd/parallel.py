@@ -77,7 +77,7 @@ class FlatGradSync:
             torch.mul(g, self.wire_scale, out=wire)
         buf = wire if wire is not None else g
         self._phase_bytes.append(buf.numel() * buf.element_size())
-        if self.mode == "direct" and self.world > 1:
+        if self.mode == "direct" and (self.world > 1 or self.force):
             self._pending.append((self._begin_direct(buf), wire, g))
             return
         work = dist.all_reduce(buf, op=self._op(), group=self.group, async_op=True)

@@ -146,6 +146,9 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and "cpu_baseline" not in d and "config3_full_hybrid" not in d
     assert d["roofline"]["launches_per_step"] > 0
+    dp = d["data_parallel"]                      # what ran: ranks, devices, bytes handed over per backward phase, exposed exchange time
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and len(dp["devices"]) == 2 and dp["exchange"] == "allreduce"
+    assert len(dp["bytes_per_phase"]) == 3 and dp["exchange_exposed_ms"] is not None and d["host_enqueue_ms"] > 0
 
 
 @pytest.mark.gpu
