@@ -130,6 +130,25 @@ def flat_offsets(named_params: "OrderedDict[str, torch.Tensor]", flat: torch.Ten
     return {k: (p.data_ptr() - base) // 4 for k, p in named_params.items()}
 
 
+_DEFAULT_TEACHER: dict = {}
+
+
+def _default_teacher(args):
+    """(state_dict, named parameters, initial lr) of a default-initialised CPU teacher for the run's flags; built once per shape
+    without touching the global RNG stream."""
+    a = args if isinstance(args, dict) else {}
+    key = (int(a.get("num_experts", 4)), int(a.get("feature_dim", 128)), int(a.get("embedding_dim", 64)))
+    if key not in _DEFAULT_TEACHER:
+        from .teacher import LunarMoETeacher
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(int(a.get("seed", 42)))
+            m = LunarMoETeacher(num_experts=key[0], feature_dim=key[1], embedding_dim=key[2])
+        _DEFAULT_TEACHER[key] = ({k: v.detach().clone() for k, v in m.state_dict().items()},
+                                 OrderedDict((k, p.detach()) for k, p in m.named_parameters()))
+    sd, tp = _DEFAULT_TEACHER[key]
+    return sd, tp, float(a.get("teacher_lr", 1e-4))
+
+
 def checkpoint_dict(stepper, vae, teacher, global_step: int, best_loss: float, args: dict) -> dict:
     """The reference's checkpoint dictionary (train_hybrid.py:594-605) from the native state.  Extra key
     `lunaris_amd_extra` (ignored by the reference) keeps what the reference loses on resume: the reward baseline and the
@@ -160,6 +179,18 @@ def checkpoint_dict(stepper, vae, teacher, global_step: int, best_loss: float, a
                                                        stepper.betas, stepper.eps, stepper.weight_decay)
         ck["teacher_scheduler"] = scheduler_state_dict(stepper.t0, 2, stepper.min_lr, stepper.teacher_base_lr, stepper.opt_steps, t_lr)
         extra["reward_state"] = stepper.reward_state.detach().cpu().clone()
+    else:
+        # VAE-only run (teacher never built): the reference's `_load_checkpoint` still calls `teacher_optimizer.load_state_dict`
+        # and `teacher_scheduler.load_state_dict` (train_hybrid.py:808-822) and gives up on a dict without parameter groups, so
+        # write the state of a freshly constructed teacher: default-initialised weights, one parameter group over all of its
+        # parameters with no moments yet, the scheduler at step 0
+        t0_, tp, t_lr = _default_teacher(args)
+        ck["teacher_state_dict"] = t0_
+        ck["teacher_optimizer"] = adamw_state_dict(tp, torch.zeros(1), torch.zeros(1), {k: 0 for k in tp}, 0, getattr(stepper, "teacher_base_lr", 1e-4),
+                                                   float(args.get("teacher_lr", 1e-4)) if isinstance(args, dict) else 1e-4, stepper.betas, stepper.eps,
+                                                   stepper.weight_decay)
+        ck["teacher_scheduler"] = scheduler_state_dict(stepper.t0, 2, stepper.min_lr, float(args.get("teacher_lr", 1e-4)) if isinstance(args, dict) else 1e-4, 0, t_lr)
+        extra["teacher_untrained"] = True
     extra["loss_scale"] = float(vae.loss_scale)          # the reference's GradScaler state is not checkpointed either side: keep ours
     ck["lunaris_amd_extra"] = extra
     return ck

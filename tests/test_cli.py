@@ -76,6 +76,16 @@ def test_cli_end_to_end_on_gpu(tmp_path):
     steps = 2 * (int(0.9 * 24) // 4)
     assert int(float(opt.state_dict()["state"][0]["step"])) == steps and sch.last_epoch == steps
     assert float(opt.state_dict()["state"][5]["exp_avg_sq"].abs().sum()) > 0
+    # a VAE-only checkpoint still carries a structurally valid (untrained) teacher, so that the reference's `_load_checkpoint`
+    # (train_hybrid.py:798-822: teacher state, teacher_optimizer.load_state_dict, teacher_scheduler.load_state_dict) goes through
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    t = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=64)
+    assert len(ck["teacher_state_dict"]) == 351 and not t.load_state_dict(ck["teacher_state_dict"], strict=True).missing_keys
+    topt = torch.optim.AdamW(t.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
+    tsch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(topt, T_0=10, T_mult=2, eta_min=1e-6)
+    topt.load_state_dict(ck["teacher_optimizer"])
+    tsch.load_state_dict(ck["teacher_scheduler"])
+    assert len(topt.state_dict()["param_groups"][0]["params"]) == 252 and tsch.last_epoch == 0
     # resume: two more epochs continue from the saved step count and write a comparison image + decoded samples
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
                         "--vae_only", "--batch_size", "4", "--gradient_accumulation_steps", "1", "--num_epochs", "1", "--log_every", "1",
@@ -105,6 +115,28 @@ def test_cli_hybrid_end_to_end_on_gpu(tmp_path):
     # teacher optimizer state exists exactly for the 28 tensors that receive gradients in the reference (gate, quality heads)
     assert len(ck["teacher_optimizer"]["state"]) == 28 and len(ck["teacher_optimizer"]["param_groups"][0]["params"]) == 252
     assert "reward_state" in ck["lunaris_amd_extra"]
+    log = (out / "training.log").read_text()
+    assert "dropout_rate 0.1 in train mode" in log          # the reference's default: teacher dropout applied
+
+
+@pytest.mark.gpu
+def test_cli_hybrid_readme_high_end_flags_on_gpu(tmp_path):
+    """README High-End recipe flags at a tiny batch: --feature_dim 256 / --embedding_dim 256 (the 512 variant is the same code
+    path, tested at module level), and --teacher_dropout 0 selecting the dropout-free teacher."""
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_data(str(data), n=12)
+    for extra, n_state in ((["--feature_dim", "256", "--embedding_dim", "256"], 379), (["--teacher_dropout", "0"], 351)):
+        out = tmp_path / ("out" + str(n_state))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
+                            "--batch_size", "2", "--gradient_accumulation_steps", "1", "--num_epochs", "1", "--log_every", "1",
+                            "--max_steps", "2"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        import torch
+        ck = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
+        assert len(ck["teacher_state_dict"]) == n_state     # 351 + 4 experts x 7 shortcut entries (Conv1x1 weight / bias, BatchNorm 5)
+        log = (out / "training.log").read_text()
+        assert ("dropout-free fast path" in log) == (extra[0] == "--teacher_dropout")
 
 
 @pytest.mark.gpu

@@ -529,3 +529,41 @@ def test_wide_teacher_head_gradients_and_hybrid_step():
     hs.step(x.cuda(), 0, R.closed_form_eps(B, L, 0).cuda())
     met = hs.metrics()
     assert np.isfinite(list(met.values())).all() and met["grads_finite"] == 1.0 and 0.3 < met["quality_scores"] < 0.7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3])
+def test_teacher_dropout_odd_batch_sizes(B):
+    """Train mode with the default dropout at a single sprite and an odd batch (mask indexing, per-sample tables) vs the oracle."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from oracle import dropout_ref as D
+    seed = 0x00C0FFEE00C0FFEE + B
+    S = T.closed_form_teacher_state()
+    m = LunarMoETeacher(); m.load_state_dict(S); m = m.to("cuda").train()
+    m.set_dropout_stream(seed, exact_next=True)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    out = m(x.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref, _ = T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(seed, 0.1, B))
+    for k, t in {"quality_scores": 2e-3, "expert_weights": 2e-3, "semantic_score": 2e-3, "style_embedding": 2e-2}.items():
+        assert (out[k].cpu() - ref[k]).abs().max().item() <= t, k
+
+
+@pytest.mark.gpu
+def test_statistics_only_call_with_dropout_has_the_side_effects_of_forward():
+    """`_process_batch`'s dead first teacher call under the reference's default dropout: same mask stream -> the BatchNorm running
+    statistics a statistics-only call leaves are bitwise those of the full forward (it skips only the last tails, pooling, heads)."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(2)).cuda()
+    states = []
+    for stats_only in (False, True):
+        t = LunarMoETeacher(); t.load_state_dict(S); t = t.to("cuda").train()
+        t.set_dropout_stream(77, exact_next=True)
+        t.update_statistics_only(x) if stats_only else t(x)
+        torch.cuda.synchronize()
+        assert t.last_path(2) == 2
+        states.append({k: v.detach().cpu().clone() for k, v in t.state_dict().items()})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
