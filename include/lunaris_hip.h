@@ -87,7 +87,7 @@ int lo_gn_mish_backward(const void* dy, const void* v, const void* other, const 
 
 /* first conv Conv2d(3,64,k3,s2,p1) on fp32 NCHW images (lunar_generate.py:95) and its weight gradient */
 int lo_first_conv_forward(const float* x, const float* w, const float* bias, void* v, float* gn_partial, int B, void* stream);
-int lo_first_conv_wgrad_op(const float* x, const void* dv, float* partial /*B*8*1728*/, float* dw, int B, float scale, void* stream);
+int lo_first_conv_wgrad_op(const float* x, const void* dv, float* partial /*B*16*1728*/, float* dw, int B, float scale, void* stream);
 /* final conv Conv2d(32,3,k3,p1)+tanh (+MSE partial sums, B*64 floats) (lunar_generate.py:192,227-228; train_hybrid.py:859) */
 int lo_final_conv_forward(const void* a4, const float* w, const float* bias, const float* target, float* recon,
                           float* mse_partial, int B, void* stream);

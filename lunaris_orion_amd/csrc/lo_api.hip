@@ -222,9 +222,16 @@ struct LoVae {
   bool forward_done, loss_done;
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
-  hipEvent_t ev_dv[2], ev_join, ev_pre, ev_cast, ev_pack;
-  bool cast_pending;          // the Linear-layer fp16 copies are being refreshed on the side stream (lo_vae_pack)
-  bool pack_pending;          // ... and so are the packed conv weights (first consumer: the second conv of the encoder)
+  hipEvent_t ev_dv[2], ev_join, ev_pre;
+  // Operand refresh on the side stream in five levels, one event each, recorded in this order (waiting for a level implies the
+  // lower ones): 1 packed convs of encoder stages 1..3; 2 encoder stage 4 (parameters + packs); 3 the encoder heads (fc_mu /
+  // fc_logvar: parameters + fp16 copy); 4 decoder.fc + decoder convs; 5 the transposed Linear copies only the backward reads
+  hipEvent_t ev_lvl[6];
+  bool lvl_pending[6];
+  // pipelined optimizer step: levels 2..5 (AdamW of 97 % of the parameters + their operand refresh) are ENQUEUED by the next
+  // forward once its first stage has run -- see lo_vae_optimizer_step
+  struct { bool pending; float* P; const float* G; float* M; float* V; void* ws; const float* norm; float lr, beta1, beta2, eps, wd; int step; } defer;
+  int n_packjobs_s4, pack_blocks_s4, n_packjobs8_s4, pack_blocks8_s4;   // job-table prefix up to and including encoder stage 4
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
   bool overlap;
   float* norm_scratch;   // lo_vae_set_gradnorm_scratch: where a single-call backward leaves the early part of the gradient norm
@@ -388,7 +395,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     size_t b = lo_wgrad_slab_bytes(h->g_head), b2 = lo_wgrad_slab_bytes(h->g_dfc);
     h->o_wslab_lin = ar.take(b > b2 ? b : b2);
   }
-  h->o_fcw_part = ar.take((size_t)B * 8 * 1728 * 4);
+  h->o_fcw_part = ar.take((size_t)B * 16 * 1728 * 4);
   h->o_lc_part = ar.take((size_t)B * 64 * 867 * 4);
   h->o_dz = ar.take((size_t)B * L * 2);
   h->o_dml = ar.take((size_t)B * 2 * L * 2);
@@ -421,8 +428,9 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   }
   h->ws_bytes = ar.off;
   h->side = nullptr;
-  h->cast_pending = false;
-  h->pack_pending = false;
+  for (int l = 0; l < 6; ++l) h->lvl_pending[l] = false;
+  h->defer.pending = false;
+  h->n_packjobs_s4 = h->pack_blocks_s4 = h->n_packjobs8_s4 = h->pack_blocks8_s4 = 0;
   h->norm_scratch = nullptr;
   h->overlap = getenv("LO_NO_OVERLAP") == nullptr;
   // GroupNorm-backward reduction fused into the producing data-gradient epilogue (+1.4 % on the step; LO_GNB_FUSE=0 runs the
@@ -432,26 +440,38 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   // in 24 runs; 0 with this form) -- the determinism tests of tests/test_fullsize_gpu.py and test_vae_gpu.py guard it
   h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
   if (h->overlap) {
-    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+    // The side stream carries work that has slack (weight gradients, the tail of the optimizer step, operand refresh); the
+    // caller's stream carries the dependent chain that decides the step time.  Lowest queue priority for the side stream: when both
+    // have workgroups ready, the dispatcher serves the chain first and the side work fills what it leaves (LO_SIDE_PRIO=0: default
+    // priority, the round-1 behaviour).  Timeline before (tools/timeline.py): the first GroupNorm pass of a step took 302 us instead of
+    // 17 beside the side stream's AdamW, data-gradient launches 55-65 us instead of 36-44 beside the weight gradients.
+    static const int side_prio = getenv("LO_SIDE_PRIO") ? atoi(getenv("LO_SIDE_PRIO")) : 1;
+    int prio_least = 0, prio_greatest = 0;
+    bool ok;
+    if (side_prio && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest)
+      ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least) == hipSuccess;
+    else
+      ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)
       ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_cast, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess;
+    for (int l = 1; l < 6 && ok; ++l) ok = hipEventCreateWithFlags(&h->ev_lvl[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); h->overlap = false; }   // no GPU in this process (CPU-side planning only)
   }
   *out = h;
   return LO_OK;
 }
 
+static int vae_flush_deferred(LoVae* h, hipStream_t after_main);
 extern "C" void lo_vae_destroy(LoVae* h) {
   if (!h) return;
   if (h->overlap) {
+    (void)vae_flush_deferred(h, nullptr);     // an optimizer step must not be lost with its engine
     (void)hipStreamDestroy(h->side);
     for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->ev_dv[i]);
-    (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre); (void)hipEventDestroy(h->ev_cast);
-    (void)hipEventDestroy(h->ev_pack);
+    (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre);
+    for (int l = 1; l < 6; ++l) (void)hipEventDestroy(h->ev_lvl[l]);
   }
   delete h;
 }
@@ -509,6 +529,7 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
         add(h->enc[s][k], h->enc[s][k].gd, h->enc[s][k].o_wp_d);
       }
     }
+    h->n_packjobs_s4 = (int)jobs.size(); h->pack_blocks_s4 = blocks;
     for (int s = 0; s < 4; ++s) {
       add(h->dec[s], h->dec[s].gf, h->dec[s].o_wp_f);
       add(h->dec[s], h->dec[s].gd, h->dec[s].o_wp_d);
@@ -532,6 +553,7 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
         if (s == 3) { h->n_packjobs8_enc = (int)j8.size(); h->pack_blocks8_enc = blocks8; }
         for (int k = 0; k < 3; ++k) add8(h->enc[s][k]);
       }
+      h->n_packjobs8_s4 = (int)j8.size(); h->pack_blocks8_s4 = blocks8;
       for (int s = 0; s < 4; ++s) add8(h->dec[s]);
       LO_REQUIRE(j8.size() <= 32, "too many fp8 pack jobs");
       if (!j8.empty())
@@ -545,61 +567,125 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
   return LO_OK;
 }
 
+// side-stream bookkeeping: one event per operand-refresh level (see LoVae::ev_lvl)
+static int vae_side_record(LoVae* h, int lvl, hipStream_t on) {
+  LO_HIP(hipEventRecord(h->ev_lvl[lvl], on));
+  h->lvl_pending[lvl] = true;
+  return LO_OK;
+}
+
+// Levels 2..5 of a pipelined optimizer step: AdamW of everything from the encoder's last stage on, in the order the forward needs
+// the results, each chunk followed by the operand refresh that depends on it.  after_main != null: the side stream first waits
+// for what `after_main` has enqueued so far (the forward calls this once its first stage has been issued, so that the 1.5 GB of
+// AdamW traffic runs beside the later, MFMA- and L2-bound stages instead of beside the HBM-bound first one).
+static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
+  if (!h->defer.pending) return LO_OK;
+  h->defer.pending = false;
+  float* P = h->defer.P; const float* G = h->defer.G; float* M = h->defer.M; float* V = h->defer.V; void* ws = h->defer.ws;
+  const float* norm = h->defer.norm;
+  const float lr = h->defer.lr, b1 = h->defer.beta1, b2 = h->defer.beta2, eps = h->defer.eps, wd = h->defer.wd;
+  const int step = h->defer.step, L = h->L;
+  hipStream_t sd = h->side;
+  if (after_main) {
+    LO_HIP(hipEventRecord(h->ev_pre, after_main));
+    LO_HIP(hipStreamWaitEvent(sd, h->ev_pre, 0));
+  }
+  const size_t n = h->flat_elems, b4 = h->p_off[h->enc[3][0].p_w], bh = h->p_off[h->idx_fc_mu_w], bd = h->p_off[h->idx_dfc_w];
+  const LoPackJob* jobs = WSP(LoPackJob, h->o_packjobs);
+  const LoPackF8Job* jobs8 = WSP(LoPackF8Job, h->o_packjobs8);
+  auto adam = [&](size_t lo, size_t hi) { return lo_adamw(P + lo, G + lo, M + lo, V + lo, hi - lo, norm, lr, b1, b2, eps, wd, step, sd); };
+  // level 2: encoder stage 4 (10 % of the parameters): first consumer ~0.45 ms into the forward
+  LO_TRY(adam(b4, bh));
+  LO_TRY(lo_pack_all(jobs + h->n_packjobs_enc, h->n_packjobs_s4 - h->n_packjobs_enc, h->pack_blocks_s4 - h->pack_blocks_enc, sd, h->pack_blocks_enc));
+  if (h->fp8_fwd)
+    LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8_s4 - h->n_packjobs8_enc, h->pack_blocks8_s4 - h->pack_blocks8_enc, sd, h->pack_blocks8_enc));
+  LO_TRY(vae_side_record(h, 2, sd));
+  // level 3: fc_mu / fc_logvar (weights + biases are adjacent: [bh, bd)) and their fp16 copy
+  LO_TRY(adam(bh, bd));
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, sd));
+  LO_TRY(vae_side_record(h, 3, sd));
+  // level 4: decoder.fc, the decoder and final convs
+  LO_TRY(adam(bd, n));
+  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, sd));
+  LO_TRY(lo_pack_all(jobs + h->n_packjobs_s4, h->n_packjobs - h->n_packjobs_s4, h->pack_blocks - h->pack_blocks_s4, sd, h->pack_blocks_s4));
+  if (h->fp8_fwd)
+    LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_s4, h->n_packjobs8 - h->n_packjobs8_s4, h->pack_blocks8 - h->pack_blocks8_s4, sd, h->pack_blocks8_s4));
+  LO_TRY(vae_side_record(h, 4, sd));
+  // level 5: the transposed copies (data gradients of the Linear layers: backward only)
+  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, sd));
+  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, sd));
+  LO_TRY(vae_side_record(h, 5, sd));
+  return LO_OK;
+}
+
+// `st` waits for operand-refresh level `lvl` (and with it every lower one); a deferred optimizer tail is enqueued first
+static int vae_wait_level(LoVae* h, hipStream_t st, int lvl) {
+  if (lvl >= 2) LO_TRY(vae_flush_deferred(h, nullptr));
+  for (int l = lvl; l >= 1; --l)
+    if (h->lvl_pending[l]) {
+      LO_HIP(hipStreamWaitEvent(st, h->ev_lvl[l], 0));      // the highest pending level <= lvl: same stream, recorded in order
+      for (int k = 1; k <= l; ++k) h->lvl_pending[k] = false;
+      break;
+    }
+  return LO_OK;
+}
+
 extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
   LO_REQUIRE(h && P && ws, "lo_vae_pack: null argument");
   hipStream_t st = S(stream);
+  LO_TRY(vae_flush_deferred(h, nullptr));     // an optimizer tail still to be enqueued writes the parameters this pack reads
   LO_TRY(vae_ensure_pack_jobs(h, P, ws, st));
   // the four Linear-layer copies (0.15 ms at L=512) are not needed before the end of the encoder: refresh them on the side
-  // stream while the conv pack and the encoder forward run; the consumers wait on ev_cast (vae_wait_casts)
+  // stream while the conv pack and the encoder forward run; the consumers wait on the level events (vae_wait_level)
   hipStream_t cs = st;
   if (h->overlap && !g_lo_prof_on) {
+    if (h->lvl_pending[5]) LO_HIP(hipStreamWaitEvent(st, h->ev_lvl[5], 0));   // order after an optimizer tail already running
     LO_HIP(hipEventRecord(h->ev_pre, st));
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
     cs = h->side;
   }
   // the conv pack too (LO_SIDE_PACK, default on): the first conv of the encoder reads the fp32 weights directly, so the pack
-  // hides behind it and its GroupNorm; every other consumer waits on ev_pack (vae_wait_pack)
+  // hides behind it and its GroupNorm; every other consumer waits on its level
   static const int side_pack = getenv("LO_SIDE_PACK") ? atoi(getenv("LO_SIDE_PACK")) : 1;
   hipStream_t ps = side_pack ? cs : st;
   LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, ps));
   if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(WSP(LoPackF8Job, h->o_packjobs8), h->n_packjobs8, h->pack_blocks8, ps));
-  if (ps != st) {
-    LO_HIP(hipEventRecord(h->ev_pack, ps));
-    h->pack_pending = true;
-  }
+  if (ps != st) { LO_TRY(vae_side_record(h, 1, ps)); LO_TRY(vae_side_record(h, 2, ps)); }
   const int L = h->L;
   // encoder head: [fc_mu.weight ; fc_logvar.weight] is one contiguous [2L][32768] fp32 matrix in the flat buffer
   LO_REQUIRE(h->p_off[h->idx_fc_lv_w] == h->p_off[h->idx_fc_mu_w] + (size_t)L * 32768, "flat layout: head weights not adjacent");
   LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, cs));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, cs));
   LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, cs));
+  if (cs != st) { LO_TRY(vae_side_record(h, 3, cs)); LO_TRY(vae_side_record(h, 4, cs)); }
+  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, cs));
   LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, cs));
-  if (cs != st) {
-    LO_HIP(hipEventRecord(h->ev_cast, cs));
-    h->cast_pending = true;
-  }
+  if (cs != st) LO_TRY(vae_side_record(h, 5, cs));
   return LO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pipelined optimizer step: clip + AdamW + operand refresh in one call, ordered so that the NEXT forward can start after the
-// first encoder stages' share of the update.  Encoder stages 1..3 hold 3 % of the parameters and are what the next step needs
-// first; stage 4, the Linear layers and the decoder (97 %, 0.27 ms of AdamW at the HBM roofline) are only read 0.6 ms or more
-// into the next forward, so their update, their fp16 casts and their packs run on the side stream beside it:
-//   stream:  gradient norm -> AdamW [0, b4)                                (b4 = offset of the encoder's last stage: 3 % of the bytes)
-//   side  :  pack encoder stages 1..3 (ev_pack) -> AdamW [b4, n) -> pack stage 4 + decoder convs, fp8 copies, Linear casts (ev_cast)
-// lo_vae_forward waits for ev_pack before its second conv and for ev_cast before the encoder's last stage (0.6 ms in).
-// Until then parameters [b, n) and their Adam moments are in flight on the side stream: lo_vae_join orders another stream
-// (e.g. before the caller reads the parameters itself).  Without the side stream everything runs in order on `stream`.
-// presummed != 0: scratch[512..1024) already holds the sum of squares of [b, n) (lo_vae_set_gradnorm_scratch).
+// Pipelined optimizer step: clip + AdamW + operand refresh, ordered so that the NEXT forward starts after 3 % of the update and
+// the rest runs beside it where it hurts least.
+//   stream:  gradient norm -> AdamW [0, b4)          (b4 = offset of the encoder's last stage: stages 1..3 hold 3 % of the bytes)
+//   side  :  pack encoder stages 1..3 (level 1) -> AdamW stage 4 + its packs (level 2) -> AdamW fc_mu|fc_logvar + fp16 copy (3)
+//            -> AdamW decoder.fc / decoder + copy + packs (4) -> transposed copies (5).  The forward waits for level 2 before
+//            encoder stage 4, 3 before the heads, 4 before the decoder; the backward for level 5.
+// LO_DEFER_OPT=1: levels 2..5 are not enqueued here but by the next lo_vae_forward behind its first stage (vae_flush_deferred;
+// everything else that touches the parameters flushes first: lo_vae_join, lo_vae_pack, the level waits, lo_vae_destroy).  The
+// timeline (tools/timeline.py) shows the 0.33 ms AdamW kernel beside the HBM-bound first stage of the next forward, whose first
+// GroupNorm pass then takes 302 us instead of 17 -- but moving that traffic behind the first stage does not shorten the step.
+// Until level 4 has completed, parameters [b4, n) and their Adam moments are in flight on the side stream: lo_vae_join orders
+// another stream (e.g. before the caller reads the parameters itself).  Without the side stream everything runs in order on
+// `stream`.  presummed != 0: scratch[512..1024) already holds the sum of squares of [b, n) (lo_vae_set_gradnorm_scratch).
 // ---------------------------------------------------------------------------------------------
 extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* M, float* V, void* ws, float max_norm, float lr,
                                      float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, int presummed,
                                      void* stream) {
   LO_REQUIRE(h && P && G && M && V && ws && scratch, "lo_vae_optimizer_step: null argument");
   hipStream_t st = S(stream);
+  LO_TRY(vae_flush_deferred(h, nullptr));     // two optimizer steps without a forward in between
   // b: begin of the range whose sum of squares may be presummed (fc_mu.weight);  b4: begin of the encoder's last stage -- the
-  // stream itself only updates stages 1..3 (3 % of the parameters, what the next forward reads in its first 0.6 ms)
+  // stream itself only updates stages 1..3 (3 % of the parameters, what the next forward reads in its first 0.45 ms)
   const size_t n = h->flat_elems, b = h->p_off[h->idx_fc_mu_w], b4 = h->p_off[h->enc[3][0].p_w];
   LO_TRY(vae_ensure_pack_jobs(h, P, ws, st));
   if (presummed) LO_TRY(lo_gradnorm_split(G, b, max_norm, scratch, scratch + 1024, st));
@@ -613,50 +699,28 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
   LO_HIP(hipEventRecord(h->ev_pre, st));
   LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
   hipStream_t sd = h->side;
-  const LoPackJob* jobs = WSP(LoPackJob, h->o_packjobs);
-  const LoPackF8Job* jobs8 = WSP(LoPackF8Job, h->o_packjobs8);
-  LO_TRY(lo_pack_all(jobs, h->n_packjobs_enc, h->pack_blocks_enc, sd));
-  if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(jobs8, h->n_packjobs8_enc, h->pack_blocks8_enc, sd));
-  LO_HIP(hipEventRecord(h->ev_pack, sd));
-  h->pack_pending = true;
-  LO_TRY(lo_adamw(P + b4, G + b4, M + b4, V + b4, n - b4, norm, lr, beta1, beta2, eps, weight_decay, step, sd));
-  LO_TRY(lo_pack_all(jobs + h->n_packjobs_enc, h->n_packjobs - h->n_packjobs_enc, h->pack_blocks - h->pack_blocks_enc, sd, h->pack_blocks_enc));
-  if (h->fp8_fwd)
-    LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8 - h->n_packjobs8_enc, h->pack_blocks8 - h->pack_blocks8_enc, sd,
-                          h->pack_blocks8_enc));
-  const int L = h->L;
-  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, sd));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, sd));
-  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, sd));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, sd));
-  LO_HIP(hipEventRecord(h->ev_cast, sd));
-  h->cast_pending = true;
+  LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs_enc, h->pack_blocks_enc, sd));
+  if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(WSP(LoPackF8Job, h->o_packjobs8), h->n_packjobs8_enc, h->pack_blocks8_enc, sd));
+  LO_TRY(vae_side_record(h, 1, sd));
+  h->defer.pending = true;
+  h->defer.P = P; h->defer.G = G; h->defer.M = M; h->defer.V = V; h->defer.ws = ws; h->defer.norm = norm;
+  h->defer.lr = lr; h->defer.beta1 = beta1; h->defer.beta2 = beta2; h->defer.eps = eps; h->defer.wd = weight_decay; h->defer.step = step;
+  // Measured (round 2, interleaved pairs of 300-step runs): deferring the tail behind the next forward's first stage (LO_DEFER_OPT=1,
+  // LO_DEFER_STAGE=0/1/2) gives 20 096 / 20 117 / 19 962 / 20 158 / 20 097 / 20 194 sprites/s against 19 965 / 20 128 for
+  // enqueueing it at once: no difference -- where the AdamW traffic lands only changes WHICH kernels it slows down, not the sum.
+  // Default: at once (fewer states to reason about); the deferred form stays behind the knob.
+  static const int defer_tail = getenv("LO_DEFER_OPT") ? atoi(getenv("LO_DEFER_OPT")) : 0;
+  if (!defer_tail) LO_TRY(vae_flush_deferred(h, nullptr));
   return LO_OK;
 }
-// `stream` waits for whatever lo_vae_pack / lo_vae_optimizer_step left running on the side stream.
+// `stream` waits for whatever lo_vae_pack / lo_vae_optimizer_step left running (or still to be enqueued) on the side stream.
 extern "C" int lo_vae_join(LoVae* h, void* stream) {
   LO_REQUIRE(h, "lo_vae_join: null handle");
   hipStream_t st = S(stream);
-  if (h->pack_pending) LO_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));
-  if (h->cast_pending) LO_HIP(hipStreamWaitEvent(st, h->ev_cast, 0));
+  LO_TRY(vae_flush_deferred(h, nullptr));
+  for (int l = 5; l >= 1; --l)
+    if (h->lvl_pending[l]) { LO_HIP(hipStreamWaitEvent(st, h->ev_lvl[l], 0)); break; }
   // the flags stay set: the executor's own stream may be a different one and still has to wait
-  return LO_OK;
-}
-
-// first consumer of a packed conv weight after lo_vae_pack
-static int vae_wait_pack(LoVae* h, hipStream_t st) {
-  if (h->pack_pending) {
-    LO_HIP(hipStreamWaitEvent(st, h->ev_pack, 0));
-    h->pack_pending = false;
-  }
-  return LO_OK;
-}
-// first consumer of a Linear-layer fp16 copy after lo_vae_pack: order it after the side-stream refresh
-static int vae_wait_casts(LoVae* h, hipStream_t st) {
-  if (h->cast_pending) {
-    LO_HIP(hipStreamWaitEvent(st, h->ev_cast, 0));
-    h->cast_pending = false;
-  }
   return LO_OK;
 }
 
@@ -689,8 +753,7 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
 static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* ws, float* recon, const float* target,
                                hipStream_t st) {
   const int B = h->B;
-  LO_TRY(vae_wait_pack(h, st));
-  LO_TRY(vae_wait_casts(h, st));
+  LO_TRY(vae_wait_level(h, st, 4));
   LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
                      nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(WSP(f16, h->o_yfc), WSP(f16, h->o_h0), B, 64, 512, st, h->o_h08 ? WSP(uint8_t, h->o_h08) : nullptr));
@@ -723,11 +786,11 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
       LO_TRY(lo_first_conv_fwd(x, PRM(c0.p_w), PRM(c0.p_b), WSP(f16, c0.o_v), WSP(float, c0.o_part), B, st));
       LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
                        WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
-      LO_TRY(vae_wait_pack(h, st));
+      LO_TRY(vae_wait_level(h, st, 1));
     } else {
       // the last stage's packed weights are refreshed at the END of the side-stream chain of a pipelined optimizer step
       // (after the AdamW of everything from this stage on): same event as the Linear casts
-      if (s == 3) LO_TRY(vae_wait_casts(h, st));
+      if (s == 3) LO_TRY(vae_wait_level(h, st, 2));
       LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8));
     }
     LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8));
@@ -735,10 +798,13 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
     LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st, c1.o_a8, h->o_eout8[s]));
     cur = WSP(f16, h->o_eout[s]);
     cur8 = h->o_eout8[s];
+    // the deferred tail of a pipelined optimizer step goes to the side stream behind this stage (see lo_vae_optimizer_step)
+    static const int flush_after = getenv("LO_DEFER_STAGE") ? atoi(getenv("LO_DEFER_STAGE")) : 0;
+    if (s == flush_after) LO_TRY(vae_flush_deferred(h, st));
   }
   // ---- heads + reparameterisation (lunar_generate.py:150-152, 259-261)
   LO_TRY(lo_nhwc_to_nchw_f16(cur, WSP(f16, h->o_xflat), B, 64, 512, st));
-  LO_TRY(vae_wait_casts(h, st));
+  LO_TRY(vae_wait_level(h, st, 3));
   LO_TRY(lo_conv_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_wp_head), nullptr, nullptr, nullptr, nullptr,
                      WSP(float, h->o_slab_head), h->head_split, st));
   LO_REQUIRE(h->p_off[h->idx_fc_lv_b] == h->p_off[h->idx_fc_mu_b] + (size_t)L, "flat layout: head biases not adjacent");
@@ -911,8 +977,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   if (fused && (!h->loss_done || !target)) { lo_set_error("lo_vae_backward: fused mode needs lo_vae_loss and a target"); return LO_ERR_STATE; }
   LO_REQUIRE(loss_scale > 0.f, "lo_vae_backward: loss_scale must be positive");
   hipStream_t st = S(stream);
-  LO_TRY(vae_wait_pack(h, st));     // no-ops after a forward; cover a lo_vae_pack issued between forward and backward
-  LO_TRY(vae_wait_casts(h, st));
+  LO_TRY(vae_wait_level(h, st, 5));   // the transposed Linear copies (and, after a lo_vae_pack between forward and backward, everything)
   const int B = h->B, L = h->L;
   const float inv = 1.0f / loss_scale;
   f16* Ga = WSP(f16, h->o_G[0]);

@@ -5,6 +5,7 @@
 //               train_hybrid.py:859)                                                  N = 3
 // plus their weight / data gradients.  fp32 VALU math, LDS-staged input tiles, coalesced NHWC fp16 stores.
 #include "lo_common.h"
+#include <stdlib.h>
 
 // =============================================================================================
 // first conv forward: x fp32 [B,3,128,128] -> v fp16 NHWC [B,64,64,64] (+bias) + GN partials [B][64][8][2]
@@ -113,6 +114,74 @@ __global__ __launch_bounds__(256) void lo_first_conv_wgrad_kernel(const float* _
   for (int i = tid; i < FC_CO * 27; i += 256) {
     int c = i / 27, k = i % 27;
     out[i] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
+  }
+}
+
+// The same weight gradient on MFMA: D[co][k] = sum_p dv[p][co] X[p][k] with k = (ci, r, s) < 27 padded to 32 and the reduction
+// over the 64 pixels of an output row in two 32-pixel MFMA steps.  The direct kernel above issues one broadcast LDS read per FMA
+// (27 per pixel and thread) and is LDS-bound: 72 us for 0.9 GFLOP and 46 MB at batch 64; here a row costs 8 MFMAs per wave.
+//   A[co][p]  : dv tile [64 p][64 co] fp16 in LDS, fragments by ds_read_b64_tr_b16 (lane group q of a wave takes pixels 4q..4q+3 and
+//               16+4q..16+4q+3 of the step: the same k permutation on both operands leaves the sum unchanged)
+//   B[p][k]   : im2col of the three staged input rows, built in LDS TRANSPOSED ([k][p], so a lane's four consecutive pixels are one
+//               8-byte read), split into fp16 hi + lo halves (x = hi + lo to 2^-22): two accumulator sets, added at the end, keep
+//               the fp32-input precision the gradient test asks for (1e-4 relative L2)
+// Partial layout: partial[wg][co*27 + k] over ROWS output rows per workgroup (4: 1024 workgroups at batch 64, four per CU -- the
+// kernel is a chain of load -> barrier -> build -> barrier -> MFMA per row, so concurrency across workgroups hides its latency).
+template <int ROWS>
+__global__ __launch_bounds__(256) void lo_first_conv_wgrad_mfma_kernel(const float* __restrict__ x, const f16* __restrict__ dv,
+                                                                       float* __restrict__ partial) {
+  __shared__ float xs[3][3][FC_W + 2];
+  __shared__ __attribute__((aligned(16))) f16 ds[64][FC_CO];          // [pixel][co], 128-byte rows
+  __shared__ __attribute__((aligned(16))) f16 xt[2][32][64 + 8];      // [hi / lo][k][pixel] (+8: rows 144 bytes apart)
+  const int tid = threadIdx.x, n = blockIdx.y, rb = blockIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int oy = rb * ROWS; oy < rb * ROWS + ROWS; ++oy) {
+    __syncthreads();
+    fc_stage_rows(x, xs, n, oy, tid);
+    const f16* src = dv + (((size_t)n * 64 + oy) * 64) * FC_CO;
+    for (int i = tid; i < 64 * FC_CO / 8; i += 256)
+      reinterpret_cast<f16x8*>(&ds[0][0])[i] = reinterpret_cast<const f16x8*>(src)[i];
+    __syncthreads();
+    for (int i = tid; i < 32 * 64; i += 256) {
+      const int k = i >> 6, p = i & 63;
+      float v = 0.f;
+      if (k < 27) {
+        const int ci = k / 9, r = (k % 9) / 3, sx = k % 3;
+        v = xs[ci][r][2 * p + sx];
+      }
+      const f16 hi = (f16)v;
+      xt[0][k][p] = hi;
+      xt[1][k][p] = (f16)(v - (float)hi);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // A: transposed reads of the dv tile; this lane supplies row (pixel) 4q + (i16 >> 2), columns 16*wave + 4*(i16 & 3) ..
+      const unsigned char* dbase = reinterpret_cast<const unsigned char*>(&ds[0][0]) + (size_t)(32 * ks + 4 * q + (i16 >> 2)) * 128 + wave * 32 + (i16 & 3) * 8;
+      h16x4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(dbase));
+      h16x4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(dbase + 16 * 128));
+      const f16x8 af = {(f16)a_lo[0], (f16)a_lo[1], (f16)a_lo[2], (f16)a_lo[3], (f16)a_hi[0], (f16)a_hi[1], (f16)a_hi[2], (f16)a_hi[3]};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16* xr = &xt[t >> 1][16 * (t & 1) + i16][32 * ks + 4 * q];
+        const f16x4 b0 = *reinterpret_cast<const f16x4*>(xr), b1 = *reinterpret_cast<const f16x4*>(xr + 16);
+        const f16x8 bf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D[co][k]: lane column k = 16*(t & 1) + i16, rows co = 16*wave + 4q + r
+  float* out = partial + ((size_t)n * gridDim.x + rb) * (FC_CO * 27);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = 16 * t + i16;
+    if (k < 27) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * wave + 4 * q + r) * 27 + k] = acc[t][r] + acc[2 + t][r];
+    }
   }
 }
 
@@ -365,12 +434,14 @@ int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v,
   LO_LAUNCH_CHECK("first_conv_fwd");
   return LO_OK;
 }
-// partial: B*8*1728 floats
+// partial: B*16*1728 floats
 int lo_first_conv_wgrad(const float* x, const f16* dv, float* partial, float* dw, int B, float scale, hipStream_t st) {
   LoProfScope _p("lo_first_conv_wgrad(+sum)", 2.0 * B * 4096 * 64 * 27, (double)B * (3 * 16384 * 4 + 4096 * 64 * 2), st);
-  hipLaunchKernelGGL(lo_first_conv_wgrad_kernel, dim3(8, B), dim3(256), 0, st, x, dv, partial);
+  static const bool direct = getenv("LO_FIRST_WGRAD_DIRECT") && atoi(getenv("LO_FIRST_WGRAD_DIRECT")) != 0;   // A/B knob: the fp32 VALU kernel
+  if (direct) hipLaunchKernelGGL(lo_first_conv_wgrad_kernel, dim3(8, B), dim3(256), 0, st, x, dv, partial);
+  else hipLaunchKernelGGL((lo_first_conv_wgrad_mfma_kernel<4>), dim3(16, B), dim3(256), 0, st, x, dv, partial);
   LO_LAUNCH_CHECK("first_conv_wgrad");
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, dw, B * 8, 1728, 1728, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, dw, B * (direct ? 8 : 16), 1728, 1728, scale);
   LO_LAUNCH_CHECK("first_conv_wgrad_sum");
   return LO_OK;
 }

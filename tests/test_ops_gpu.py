@@ -219,7 +219,7 @@ def test_first_conv(B):
     assert torch.allclose(tot[:, :, 1], (g5 * g5).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
     dy = _rand(B, 64, 64, 64, seed=4, scale=0.1)
     (dw_ref,) = torch.autograd.grad(ref, w, dy)
-    partial = torch.empty(B * 8 * 1728, dtype=torch.float32, device="cuda")
+    partial = torch.empty(B * 16 * 1728, dtype=torch.float32, device="cuda")
     dw = torch.empty(64, 3, 3, 3, dtype=torch.float32, device="cuda")
     dyd = to_nhwc_h(dy)
     lib.check(lib.lib.lo_first_conv_wgrad_op(xd.data_ptr(), dyd.data_ptr(), partial.data_ptr(), dw.data_ptr(), B, 1.0,
