@@ -1452,6 +1452,8 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
   const int B = h->B;
   const size_t px = (size_t)B * T_HW;
   const bool drop = training && dropout_p > 0.f;
+  LO_REQUIRE(!drop || (size_t)B * T_HW * (size_t)(h->F > 192 ? h->F : 192) <= 0xFFFFFFFFull,
+             "lo_teacher_forward: batch %d x feature_dim %d exceeds the 32-bit element index of the dropout mask generator", B, h->F);
   uint32_t thr = drop ? (uint32_t)lrintf(dropout_p * 65536.f) : 0u;
   if (drop && thr == 0) thr = 1;
   const float inv_keep = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
