@@ -226,6 +226,28 @@ __device__ __forceinline__ void lc_stage_a4(const f16* __restrict__ a4, unsigned
     *reinterpret_cast<u32x4*>(tile + p * LC_PITCH + ch * 16) = v;
   }
 }
+__device__ __forceinline__ void lc_stage_a4_wide(const f16* __restrict__ a4, unsigned char* tile, int n, int ty, int tx, int tid) {
+  // tile[(y*18 + x)] = a4[n][ty*16 - 1 + y][tx*16 - 1 + x][0..31], zero outside.  All six loads of a thread are issued before the
+  // first LDS store (the rolled loop below serialises six global latencies; in the backward kernel the 24 extra registers cost more
+  // than that: 83 -> 131 us, so it keeps the rolled form)
+  constexpr int NCH = LC_TP * LC_TP * 4, NIT = (NCH + 255) / 256;
+  u32x4 v[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int i = tid + k * 256;
+    const int ch = i & 3, p = i >> 2;
+    const int y = p / LC_TP, xx = p % LC_TP;
+    const int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
+    v[k] = (u32x4){0u, 0u, 0u, 0u};
+    if (i < NCH && (unsigned)iy < 128u && (unsigned)ix < 128u)
+      v[k] = *reinterpret_cast<const u32x4*>(a4 + (((size_t)n * 128 + iy) * 128 + ix) * LC_CI + ch * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int i = tid + k * 256;
+    if (i < NCH) *reinterpret_cast<u32x4*>(tile + (i >> 2) * LC_PITCH + (i & 3) * 16) = v[k];
+  }
+}
 
 __global__ __launch_bounds__(256) void lo_final_conv_fwd_kernel(const f16* __restrict__ a4, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, const float* __restrict__ target,
@@ -269,6 +291,79 @@ __global__ __launch_bounds__(256) void lo_final_conv_fwd_kernel(const f16* __res
     float d0 = r0 - target[o], d1 = r1 - target[o + 128 * 128], d2 = r2 - target[o + 2 * 128 * 128];
     float e = lo_wave_sum(d0 * d0 + d1 * d1 + d2 * d2);
     if ((tid & 63) == 0) red[tid >> 6] = e;
+    __syncthreads();
+    if (tid == 0) mse_partial[((size_t)n * gridDim.y + ty) * gridDim.x + tx] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// The same forward on MFMA.  The direct kernel above issues 324 ds_read_b128 per output pixel (36 patch reads + 288 broadcast
+// weight reads) and is LDS-bound: 63 us for 0.9 GFLOP and 92 MB at batch 64.  Here a tile row of 16 pixels is one 16x16 output
+// block D[px][col] and a tap is one v_mfma_f32_16x16x32_f16 over the 32 input channels:
+//   A[px][ci]  : 16 bytes of the staged patch at pixel (py + r, px + s), chunk g       (one ds_read_b128 per tap and tile row)
+//   B[ci][col] : the tap's weights split w = hi + lo (fp16 halves, exact to 2^-22): columns 0..2 hold hi of co 0..2, columns
+//                3..5 hold lo, so one MFMA per tap keeps fp32-weight precision (recon parity 2e-5; an fp16-weight form broke it
+//                in round 1); column co + 3 is added to column co by a lane shuffle after the nine taps
+// The 12 lanes with col < 3 hold four consecutive pixels each: 16-byte recon stores, 16-byte target loads.  tanh is
+// 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp (|err| < 3e-7): libm's tanhf on 12 of 64 lanes was half of the kernel's time.
+__device__ __forceinline__ float lc_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+
+__global__ __launch_bounds__(256) void lo_final_conv_fwd_mfma_kernel(const f16* __restrict__ a4, const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, const float* __restrict__ target,
+                                                                     float* __restrict__ recon, float* __restrict__ mse_partial) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[LC_TP * LC_TP * LC_PITCH];
+  __shared__ __attribute__((aligned(16))) f16 wf[9 * 4 * 6 * 8];   // [tap][g][hi co0..2 | lo co0..2][8 channels]
+  __shared__ float red[4];
+  const int tid = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
+  const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+  lc_stage_a4_wide(a4, tile, n, ty, tx, tid);
+  for (int i = tid; i < 3 * LC_CI * 9; i += 256) {    // coalesced read of the 864 weights, split, fragment order
+    const int t = i % 9, ci = (i / 9) % LC_CI, co = i / (9 * LC_CI);
+    const float wv = w[i];
+    const f16 hi = (f16)wv;
+    const int slot = ((t * 4 + (ci >> 3)) * 6 + co) * 8 + (ci & 7);
+    wf[slot] = hi;
+    wf[slot + 24] = (f16)(wv - (float)hi);
+  }
+  const float bv = m < 3 ? bias[m] : 0.f;
+  __syncthreads();
+  f16x8 wb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wb[t] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (m < 6) wb[t] = *reinterpret_cast<const f16x8*>(&wf[((t * 4 + g) * 6 + m) * 8]);
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int py = wave * 4 + rr;                      // tile row of this 16-pixel block
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int r = t / 3, sx = t % 3;
+      const f16x8 af = *reinterpret_cast<const f16x8*>(tile + ((py + r) * LC_TP + m + sx) * LC_PITCH + g * 16);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, wb[t], acc, 0, 0, 0);
+    }
+    // D[px][col]: column = m, rows px = 4g + j; lo part sits three lanes up
+    f32x4 lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] = __shfl_down(acc[j], 3, 64);
+    if (m < 3) {
+      const int oy = ty * LC_T + py, ox = tx * LC_T + 4 * g;
+      const size_t o = (((size_t)n * 3 + m) * 128 + oy) * 128 + ox;
+      f32x4 rv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[j] = lc_tanh(acc[j] + lo[j] + bv);
+      *reinterpret_cast<f32x4*>(recon + o) = rv;
+      if (mse_partial) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(target + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = rv[j] - tv[j]; sq += d * d; }
+      }
+    }
+  }
+  if (mse_partial) {
+    const float e = lo_wave_sum(sq);
+    if (lane == 0) red[wave] = e;
     __syncthreads();
     if (tid == 0) mse_partial[((size_t)n * gridDim.y + ty) * gridDim.x + tx] = red[0] + red[1] + red[2] + red[3];
   }
@@ -453,7 +548,9 @@ int lo_colsum(const float* partial, float* out, int nrow, int ncol, int stride, 
 int lo_final_conv_fwd(const f16* a4, const float* w, const float* bias, const float* target, float* recon,
                       float* mse_partial, int B, hipStream_t st) {
   LoProfScope _p("lo_final_conv_fwd", 2.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 + 3 * 4 * 2), st);
-  hipLaunchKernelGGL(lo_final_conv_fwd_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
+  static const bool direct = getenv("LO_FINAL_FWD_DIRECT") && atoi(getenv("LO_FINAL_FWD_DIRECT")) != 0;   // A/B knob: the fp32 VALU kernel
+  if (direct) hipLaunchKernelGGL(lo_final_conv_fwd_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
+  else hipLaunchKernelGGL(lo_final_conv_fwd_mfma_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
   LO_LAUNCH_CHECK("final_conv_fwd");
   return LO_OK;
 }
