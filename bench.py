@@ -284,10 +284,14 @@ def main():
                            "ms_per_step": ms / max(args.prof_steps, 1), "launches_per_step": n / max(args.prof_steps, 1)})
         roof["by_kernel"] = others
         if args.breakdown:
+            # floor = the larger of flops / MFMA peak and algorithmic bytes / HBM peak for the launches of the row; "of floor" is how
+            # close the measured time comes to it (LO_PROF_LAYERS=1 splits the conv rows per layer geometry)
             for k, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
-                sys.stderr.write(f"{k:34s} {r[0] / max(args.prof_steps, 1):9.4f} ms/step  n={r[1] // max(args.prof_steps, 1):3d}  "
+                floor_ms = 1e3 * max(r[2] / (PEAK_MFMA_F16_TFLOPS * 1e12), r[3] / (PEAK_HBM_GBS * 1e9))
+                sys.stderr.write(f"{k:52s} {r[0] / max(args.prof_steps, 1):9.4f} ms/step  n={r[1] // max(args.prof_steps, 1):3d}  "
                                  f"{(r[2] / (r[0] * 1e-3) / 1e12 if r[0] > 0 else 0):8.1f} TFLOP/s  "
-                                 f"{(r[3] / (r[0] * 1e-3) / 1e9 if r[0] > 0 else 0):8.1f} GB/s\n")
+                                 f"{(r[3] / (r[0] * 1e-3) / 1e9 if r[0] > 0 else 0):8.1f} GB/s  "
+                                 f"floor {floor_ms / max(args.prof_steps, 1):7.4f} ms ({(floor_ms / r[0] if r[0] > 0 else 0):4.2f} of floor)\n")
             sys.stderr.write(f"sum of kernel time {total_ms / max(args.prof_steps, 1):.4f} ms/step\n")
         out = {
             "metric": "128x128 sprites/sec, VAE training step (train_hybrid.py _process_batch), latent_dim=512",

@@ -574,6 +574,20 @@ static int vae_side_record(LoVae* h, int lvl, hipStream_t on) {
   return LO_OK;
 }
 
+// The transposed fp16 copies of the two Linear weights (operands of their data gradients), made from the fp16 forward copies that
+// the same stream has just refreshed: 4 bytes of traffic per element instead of the 6 of a transposing cast from fp32, and the
+// same bits (LO_TRANSPOSE_F32=1: from the fp32 parameters).  2L and 32768 are multiples of 64 (L is 128, 256 or 512).
+static int vae_linear_transposes(LoVae* h, const float* P, void* ws, hipStream_t st) {
+  static const bool from_f32 = getenv("LO_TRANSPOSE_F32") && atoi(getenv("LO_TRANSPOSE_F32")) != 0;
+  const int L = h->L;
+  if (from_f32 || (2 * L) % 64 != 0 || L % 64 != 0) {
+    LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, st));
+    return lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, st);
+  }
+  LO_TRY(lo_nhwc_to_nchw_f16(WSP(f16, h->o_wp_head), WSP(f16, h->o_wp_head_t), 1, 2 * L, 32768, st));   // [2L][32768] -> [32768][2L]
+  return lo_nhwc_to_nchw_f16(WSP(f16, h->o_wp_dfc), WSP(f16, h->o_wp_dfc_t), 1, 32768, L, st);          // [32768][L] -> [L][32768]
+}
+
 // Levels 2..5 of a pipelined optimizer step: AdamW of everything from the encoder's last stage on, in the order the forward needs
 // the results, each chunk followed by the operand refresh that depends on it.  after_main != null: the side stream first waits
 // for what `after_main` has enqueued so far (the forward calls this once its first stage has been issued, so that the 1.5 GB of
@@ -593,7 +607,12 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
   const size_t n = h->flat_elems, b4 = h->p_off[h->enc[3][0].p_w], bh = h->p_off[h->idx_fc_mu_w], bd = h->p_off[h->idx_dfc_w];
   const LoPackJob* jobs = WSP(LoPackJob, h->o_packjobs);
   const LoPackF8Job* jobs8 = WSP(LoPackF8Job, h->o_packjobs8);
-  auto adam = [&](size_t lo, size_t hi) { return lo_adamw(P + lo, G + lo, M + lo, V + lo, hi - lo, norm, lr, b1, b2, eps, wd, step, sd); };
+  auto adam = [&](size_t lo, size_t hi, f16* cast = nullptr) {
+    return hi > lo ? lo_adamw(P + lo, G + lo, M + lo, V + lo, hi - lo, norm, lr, b1, b2, eps, wd, step, sd, cast) : LO_OK;
+  };
+  // the Linear layers' fp16 forward operands come out of the AdamW pass itself (LO_ADAM_CAST=0: separate cast launches)
+  static const int fuse_cast = getenv("LO_ADAM_CAST") ? atoi(getenv("LO_ADAM_CAST")) : 1;
+  const size_t nh = (size_t)2 * L * 32768, nd = (size_t)32768 * L;
   // level 2: encoder stage 4 (10 % of the parameters): first consumer ~0.45 ms into the forward
   LO_TRY(adam(b4, bh));
   LO_TRY(lo_pack_all(jobs + h->n_packjobs_enc, h->n_packjobs_s4 - h->n_packjobs_enc, h->pack_blocks_s4 - h->pack_blocks_enc, sd, h->pack_blocks_enc));
@@ -601,19 +620,28 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
     LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8_s4 - h->n_packjobs8_enc, h->pack_blocks8_s4 - h->pack_blocks8_enc, sd, h->pack_blocks8_enc));
   LO_TRY(vae_side_record(h, 2, sd));
   // level 3: fc_mu / fc_logvar (weights + biases are adjacent: [bh, bd)) and their fp16 copy
-  LO_TRY(adam(bh, bd));
-  LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, sd));
+  if (fuse_cast) {
+    LO_TRY(adam(bh, bh + nh, WSP(f16, h->o_wp_head)));
+    LO_TRY(adam(bh + nh, bd));
+  } else {
+    LO_TRY(adam(bh, bd));
+    LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), nh, sd));
+  }
   LO_TRY(vae_side_record(h, 3, sd));
   // level 4: decoder.fc, the decoder and final convs
-  LO_TRY(adam(bd, n));
-  LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, sd));
+  if (fuse_cast) {
+    LO_TRY(adam(bd, bd + nd, WSP(f16, h->o_wp_dfc)));
+    LO_TRY(adam(bd + nd, n));
+  } else {
+    LO_TRY(adam(bd, n));
+    LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), nd, sd));
+  }
   LO_TRY(lo_pack_all(jobs + h->n_packjobs_s4, h->n_packjobs - h->n_packjobs_s4, h->pack_blocks - h->pack_blocks_s4, sd, h->pack_blocks_s4));
   if (h->fp8_fwd)
     LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_s4, h->n_packjobs8 - h->n_packjobs8_s4, h->pack_blocks8 - h->pack_blocks8_s4, sd, h->pack_blocks8_s4));
   LO_TRY(vae_side_record(h, 4, sd));
   // level 5: the transposed copies (data gradients of the Linear layers: backward only)
-  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, sd));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, sd));
+  LO_TRY(vae_linear_transposes(h, P, ws, sd));
   LO_TRY(vae_side_record(h, 5, sd));
   return LO_OK;
 }
@@ -657,8 +685,7 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
   LO_TRY(lo_cast_f32_f16(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head), (size_t)2 * L * 32768, cs));
   LO_TRY(lo_cast_f32_f16(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc), (size_t)32768 * L, cs));
   if (cs != st) { LO_TRY(vae_side_record(h, 3, cs)); LO_TRY(vae_side_record(h, 4, cs)); }
-  LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, cs));
-  LO_TRY(lo_transpose_cast(PRM(h->idx_dfc_w), WSP(f16, h->o_wp_dfc_t), 32768, L, cs));
+  LO_TRY(vae_linear_transposes(h, P, ws, cs));
   if (cs != st) LO_TRY(vae_side_record(h, 5, cs));
   return LO_OK;
 }

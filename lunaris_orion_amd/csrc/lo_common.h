@@ -33,6 +33,11 @@ int lo_check_hip(hipError_t e, const char* what);
     if (_e != LO_OK) return _e;                        \
   } while (0)
 #define LO_LAUNCH_CHECK(name) LO_HIP(hipGetLastError())
+#define LO_CHECK(...)                                  \
+  do {                                                 \
+    int _e = (__VA_ARGS__);                                   \
+    if (_e != LO_OK) return _e;                        \
+  } while (0)
 #define LO_REQUIRE(cond, ...)                          \
   do {                                                 \
     if (!(cond)) {                                     \
@@ -107,6 +112,8 @@ struct LoPackJob {
   int block0;         // first block of this job in the fused launch
   LoGeom g;
 };
+
+const char* lo_prof_geom_name(const char* base, const LoGeom& g);   // per-layer profiler names under LO_PROF_LAYERS
 
 enum LoConvKind {
   LO_CONV3_S1 = 0,        // Conv2d k3 s1 p1 forward

@@ -222,6 +222,13 @@ __device__ __forceinline__ int lo_xcd_remap(int bid, int total) {
 // so a tile row is the same 128 bytes as the fp16 BK = 64 row, and one K step is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per
 // 16x16 block (lane holds row lane&15 and 32 bytes of k: chunks fq and fq + 4 of the row; unit block scales) - twice the
 // K per byte moved and per MFMA cycle.  The epilogue multiplies by f8_scale[phase][n] before the bias.
+template <int BM, int BN, int BK, int NSTAGE, bool F8>
+constexpr int igemm_lds_bytes() {   // the K-loop ring, or the epilogue's staging tile + reduction scratch, whichever is larger
+  constexpr int ring = NSTAGE * (BM + BN) * BK * (F8 ? 1 : 2);
+  constexpr int epi = BM * (BN * 2 + 16) + 16384 + 1024;
+  return ring > epi ? ring : epi;
+}
+
 template <int BM, int BN, int BK, int NSTAGE, bool SPLITK, bool F8 = false>
 __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   constexpr int ES = F8 ? 1 : 2;          // bytes per operand element
@@ -240,8 +247,9 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2; // wave tile (2 x 2 waves)
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;     // epilogue staging pitch (bytes)
-  constexpr int LDS_BYTES = (NSTAGE * STAGE > BM * OPITCH + 16384 + 1024) ? NSTAGE * STAGE : BM * OPITCH + 16384 + 1024;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+  // dynamic LDS (igemm_lds_bytes<...>() bytes, passed by the launcher): the deep-pipeline instantiations exceed the 64 KB a static
+  // array may have; it is the kernel's only LDS object, so it starts at offset 0 (1 KB-aligned DMA destinations)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const LoGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -875,6 +883,21 @@ static inline double geom_bytes(const LoGeom& g) {
   return 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + (double)g.B * g.Hout * g.Wout * g.Cout + geom_packed_elems(g));
 }
 
+template <int BM, int BN, int BK, int NS, bool SK, bool F8 = false>
+static int igemm_launch(dim3 grid, const IgemmArgs& a, hipStream_t st) {
+  constexpr int lds = igemm_lds_bytes<BM, BN, BK, NS, F8>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  if constexpr (lds > 65536) {
+    static bool attr = false;
+    if (!attr) {
+      LO_HIP(hipFuncSetAttribute((const void*)lo_igemm_nt<BM, BN, BK, NS, SK, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr = true;
+    }
+  }
+  hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NS, SK, F8>), grid, dim3(256), lds, st, a);
+  return LO_OK;
+}
+
 template <int BM, int BN, int BK>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   const LoGeom& g = a.g;
@@ -884,7 +907,7 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   // / skip gradient it adds (add_src) and the producing layer's raw conv output for the fused GroupNorm-backward reduction
   // (gb_v), each the size of the output
   const double out_bytes = 2.0 * (double)g.B * g.Hout * g.Wout * g.Cout;
-  LoProfScope _p(name, geom_flops(g), geom_bytes(g) + (a.add_src ? out_bytes : 0.0) + (a.gb_v ? out_bytes : 0.0), st);
+  LoProfScope _p(lo_prof_geom_name(name, g), geom_flops(g), geom_bytes(g) + (a.add_src ? out_bytes : 0.0) + (a.gb_v ? out_bytes : 0.0), st);
   dim3 grid(((a.M + BM - 1) / BM) * (g.Cout / BN) * (a.nsplit > 1 ? a.nsplit : g.n_phase));
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);
@@ -894,12 +917,33 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   int ksteps_max = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps_max = g.T[p] * (g.Cin / BK) > ksteps_max ? g.T[p] * (g.Cin / BK) : ksteps_max;
   const bool shallow = shallow_env >= 0 ? shallow_env != 0 : ksteps_max <= 9;
+  // deep pipeline (LO_DEEP_PIPE=k: k more stages): a launch whose grid leaves LDS unused (<= 2 workgroups per CU on the VAE's short
+  // grids) spends it on more K steps in flight, as long as that costs no resident workgroup the grid could have used
+  static const int deep_env = getenv("LO_DEEP_PIPE") ? atoi(getenv("LO_DEEP_PIPE")) : 0;
+  const int wgs_cu = ((int)grid.x + 255) / 256;
+  auto fits = [&](int lds_new, int lds_old) {
+    const int res_old = (160 * 1024) / lds_old, res_new = (160 * 1024) / lds_new;
+    return res_new >= 1 && res_new >= (wgs_cu < res_old ? wgs_cu : res_old);
+  };
+  constexpr int L0 = igemm_lds_bytes<BM, BN, BK, NSTAGE, false>();
+  int deep = 0;
+  if (a.nsplit <= 1 && !shallow && deep_env > 0 && ksteps_max >= 4 * NSTAGE) {
+    if (deep_env >= 3 && fits(igemm_lds_bytes<BM, BN, BK, NSTAGE + 3, false>(), L0)) deep = 3;
+    else if (deep_env >= 2 && fits(igemm_lds_bytes<BM, BN, BK, NSTAGE + 2, false>(), L0)) deep = 2;
+    else if (fits(igemm_lds_bytes<BM, BN, BK, NSTAGE + 1, false>(), L0)) deep = 1;
+  }
   if (a.nsplit > 1)
-    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE, true>), grid, dim3(256), 0, st, a);
+    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE, true>(grid, a, st));
   else if (shallow && NSTAGE > 2)
-    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, (NSTAGE > 2 ? NSTAGE - 1 : 2), false>), grid, dim3(256), 0, st, a);
+    LO_CHECK(igemm_launch<BM, BN, BK, (NSTAGE > 2 ? NSTAGE - 1 : 2), false>(grid, a, st));
+  else if (deep == 3)
+    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE + 3, false>(grid, a, st));
+  else if (deep == 2)
+    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE + 2, false>(grid, a, st));
+  else if (deep == 1)
+    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE + 1, false>(grid, a, st));
   else
-    hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NSTAGE, false>), grid, dim3(256), 0, st, a);
+    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE, false>(grid, a, st));
   LO_LAUNCH_CHECK("igemm");
   return LO_OK;
 }
@@ -912,11 +956,11 @@ static int launch_igemm_f8(const IgemmArgs& a, hipStream_t st) {
   const LoGeom& g = a.g;
   static char name[64];
   snprintf(name, sizeof(name), "lo_igemm_nt<%d,%d,128>/fp8", BM, BN);
-  LoProfScope _p(name, geom_flops(g), 0.5 * geom_bytes(g) + (double)g.B * g.Hout * g.Wout * g.Cout, st);
+  LoProfScope _p(lo_prof_geom_name(name, g), geom_flops(g), 0.5 * geom_bytes(g) + (double)g.B * g.Hout * g.Wout * g.Cout, st);
   dim3 grid(((a.M + BM - 1) / BM) * (g.Cout / BN) * g.n_phase);
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);
-  hipLaunchKernelGGL((lo_igemm_nt<BM, BN, 128, NSTAGE, false, true>), grid, dim3(256), 0, st, a);
+  LO_CHECK((igemm_launch<BM, BN, 128, NSTAGE, false, true>(grid, a, st)));
   LO_LAUNCH_CHECK("igemm_f8");
   return LO_OK;
 }
@@ -1161,11 +1205,11 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
     int nsplit = 0;
     const int total = geom_packed_elems(g);
     {
-      LoProfScope _p("lo_wgrad3x3_mt", geom_flops(g), geom_bytes(g), st);
+      LoProfScope _p(lo_prof_geom_name("lo_wgrad3x3_mt", g), geom_flops(g), geom_bytes(g), st);
       int r = lo_wgrad3_run(g, x, dy, slab, st, &nsplit);
       if (r != LO_OK) return r;
     }
-    LoProfScope _p2("lo_wgrad_reduce", 0, 4.0 * total * (nsplit + 1), st);
+    LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);
     hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
     LO_LAUNCH_CHECK("wgrad_reduce");
     return LO_OK;
@@ -1189,7 +1233,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   dim3 grid(((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps * a.nsplit);
   static const int wg_stages = getenv("LO_WGRAD_STAGES") ? atoi(getenv("LO_WGRAD_STAGES")) : 3;   // 64-pixel steps: LDS stages (3 where the tile fits: +0.9 % on the step)
   {
-    LoProfScope _p("lo_wgrad_tn", geom_flops(g), geom_bytes(g), st);
+    LoProfScope _p(lo_prof_geom_name("lo_wgrad_tn", g), geom_flops(g), geom_bytes(g), st);
 #define LO_WG(BMW, BNW)                                                                            \
   do {                                                                                             \
     if (bkp == 64 && wg_stages == 3 && (BMW + BNW) <= 192) hipLaunchKernelGGL((lo_wgrad_tn<BMW, BNW, 3, 64>), grid, dim3(256), 0, st, a);   \
@@ -1205,7 +1249,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   LO_LAUNCH_CHECK("wgrad_tn");
   if (a.direct) return LO_OK;
   int total = a.packed_elems;
-  LoProfScope _p2("lo_wgrad_reduce", 0, 4.0 * total * (a.nsplit + 1), st);
+  LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (a.nsplit + 1), st);
   hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
   LO_LAUNCH_CHECK("wgrad_reduce");
   return LO_OK;

@@ -88,7 +88,7 @@ int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float*
 int lo_sumsq_range(const float* g, size_t begin, size_t end, float* partial, hipStream_t st);   // -> partial[512 .. 1024)
 int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st);
 int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
-             float eps, float wd, int step, hipStream_t st);
+             float eps, float wd, int step, hipStream_t st, f16* cast = nullptr);
 
 // lo_attn.hip
 int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,

@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* 
 __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, size_t n, const float* __restrict__ norm,
                                                        float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                                       float bc2_sqrt) {
+                                                       float bc2_sqrt, f16* __restrict__ cast) {
+  // cast != null: the fp16 operand copy of the updated parameters (same layout) is written in the same pass -- the Linear layers'
+  // forward operands; a skipped update leaves parameters and copy as they were
   const float coef = norm ? norm[1] : 1.0f;
   const bool ok = norm ? (norm[2] != 0.f) : true;
   if (!ok) return;
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
     reinterpret_cast<f32x4*>(p)[k] = pv;
     reinterpret_cast<f32x4*>(m)[k] = mv;
     reinterpret_cast<f32x4*>(v)[k] = vv;
+    if (cast) reinterpret_cast<f16x4*>(cast)[k] = (f16x4){(f16)pv[0], (f16)pv[1], (f16)pv[2], (f16)pv[3]};
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (size_t k = n4 * 4; k < n; ++k) {
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
       p[k] = pp - step_size * (mm / (sqrtf(v2) / bc2_sqrt + eps));
       m[k] = mm;
       v[k] = v2;
+      if (cast) cast[k] = (f16)p[k];
     }
 }
 
@@ -362,14 +366,16 @@ int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial /*>=102
   return LO_OK;
 }
 int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
-             float eps, float wd, int step, hipStream_t st) {
+             float eps, float wd, int step, hipStream_t st, f16* cast) {
   float bc1 = 1.0f - powf(beta1, (float)step);
   float bc2 = 1.0f - powf(beta2, (float)step);
   double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
   (void)bc1; (void)bc2;
-  LoProfScope _p("lo_adamw", 0, 28.0 * n, st);
-  hipLaunchKernelGGL(lo_adamw_kernel, dim3(2048), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
-                     (float)bc1d, (float)sqrt(bc2d));
+  LoProfScope _p(cast ? "lo_adamw(+fp16 copy)" : "lo_adamw", 0, (cast ? 30.0 : 28.0) * n, st);
+  const size_t want = (n / 4 + 255) / 256;
+  const int nblk = want >= 2048 ? 2048 : (want < 1 ? 1 : (int)want);
+  hipLaunchKernelGGL(lo_adamw_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
+                     (float)bc1d, (float)sqrt(bc2d), cast);
   LO_LAUNCH_CHECK("adamw");
   return LO_OK;
 }

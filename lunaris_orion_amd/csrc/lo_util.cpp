@@ -1,6 +1,7 @@
 #include "lo_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 static thread_local char g_err[512] = "";
 void lo_set_error(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -38,6 +39,19 @@ void lo_prof_begin(const char* name, double flops, double bytes, hipStream_t st)
 }
 void lo_prof_end(hipStream_t st) {
   if (!g_recs.empty() && g_recs.back().e1) (void)hipEventRecord(g_recs.back().e1, st);
+}
+// Under LO_PROF_LAYERS a conv-like launch is named "<kernel> <Cin>><Cout> <Hin>><Hout> T<taps>": one interned string per distinct
+// (kernel, geometry), since the records keep the pointer.  Without it (or with the profiler off) the kernel name itself.
+const char* lo_prof_geom_name(const char* base, const LoGeom& g) {
+  static const bool per_layer = getenv("LO_PROF_LAYERS") != nullptr;
+  if (!per_layer || !g_lo_prof_on) return base;
+  static std::vector<std::string*> table;
+  char text[96];
+  snprintf(text, sizeof(text), "%s %d>%d %d>%d T%d", base, g.Cin, g.Cout, g.Hin, g.Hout, g.T[0] * (g.n_phase > 1 ? -g.n_phase : 1));
+  for (std::string* e : table)
+    if (*e == text) return e->c_str();
+  table.push_back(new std::string(text));
+  return table.back()->c_str();
 }
 extern "C" void lo_prof_enable(int on) {
   g_lo_prof_on = on != 0;
