@@ -898,7 +898,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
     if (prod && h->fuse_gnb) {
       gb.v = WSP(f16, prod->o_v); gb.stats = WSP(float, prod->o_stats); gb.gamma = PRM(prod->p_gw); gb.beta = PRM(prod->p_gb);
       gb.P1 = WSP(float, prod->o_P1);
-      prod->np1 = (c.gd.GH * c.gd.GW / lo_conv_tile_m(c.gd)) * c.gd.n_phase;
+      prod->np1 = lo_conv_gnb_rows(c.gd);
       gbp = &gb;
     }
     static char dtag[32][64];

@@ -1091,8 +1091,8 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   int ksteps = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
-  if (a.nsplit == 1 && !gb && lo_conv3_tiles_per_image(g, ex != nullptr) > 0)
-    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex);   // fused-tap kernel for 3x3 stride-1
+  if (a.nsplit == 1 && lo_conv3_tiles_per_image(g, ex != nullptr) > 0 && (!gb || lo_conv3_fuses_gnb(g)))
+    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb);   // fused-tap kernel for 3x3 stride-1
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");
     LO_REQUIRE(BK == 64 && g.Cout % 64 == 0, "lo_conv_run: split-K path needs Cin%%64==0 and Cout%%64==0");
@@ -1155,6 +1155,10 @@ int lo_conv_bn_rows(const LoGeom& g) {
   int t = lo_conv3_tiles_per_image(g, true);
   if (t > 0) return g.B * t;
   return (int)(((size_t)g.B * g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase);
+}
+int lo_conv_gnb_rows(const LoGeom& g) {
+  if (lo_conv3_fuses_gnb(g)) return lo_conv3_tiles_per_image(g, false);
+  return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
 }
 int lo_conv_mt(const LoGeom& g) {
   int t = lo_conv3_tiles_per_image(g);

@@ -43,6 +43,13 @@ struct Conv3Args {
 #ifdef LO_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/conv3_stamp.cpp): [workgroup][wave][16] shader-clock stamps
 #endif
+  // fused GroupNorm-backward reduction (lo_conv3x3_pp only; same contract as IgemmArgs::gb_* in lo_conv.hip): the output is the
+  // gradient wrt the activation of a conv+GN+Mish layer whose raw conv output is gb_v; P1[n][tile][c] = (sum du, sum du*xhat)
+  const f16* gb_v = nullptr;
+  const float* gb_stats = nullptr;
+  const float* gb_gamma = nullptr;
+  const float* gb_beta = nullptr;
+  float* gb_P1 = nullptr;
 };
 #ifdef LO_STAMPS
 unsigned long long* g_lo_conv3_stamps = nullptr;
@@ -336,7 +343,9 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 // (the natural pair (2 fq, 2 fq + 1) touches only every other 16-byte slot per read: 2-way conflicts, measured 289 us per teacher
 // conv against 236 with this form); which k a byte is multiplied as does not matter as long as both operands agree, and they do:
 // both images are read through the same chunk -> k map.  The epilogue multiplies by f8_scale[n] before the bias.  (Teacher 3x3 convolutions of the dropout path in fp8 mode, BASELINE config 5.)
-template <int BN, int TH, int TW, bool XF, bool F8 = false>
+// ONECB: the launch has a single channel block (Cin == 64 for fp16): the second patch buffer is never filled, and without it two
+// workgroups fit on a CU, so that one's prologue / epilogue overlaps the other's tap loop.
+template <int BN, int TH, int TW, bool XF, bool F8 = false, bool ONECB = false>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   static_assert(!(XF && F8), "the transform on load works on fp16 patches");
   constexpr int ES = F8 ? 1 : 2;              // bytes per operand element
@@ -358,13 +367,14 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   constexpr int OPITCH = BN * 2 + 16;
   constexpr int XF_LEV = 2, XF_C = 128;       // transform constants staged in LDS: [2 levels][6 classes][128 channels] fp16
   constexpr int K_BYTES = XF ? XF_LEV * 6 * XF_C * 2 : 0;
-  constexpr int MAIN_BYTES = 2 * PATCH_BYTES + NSB * B_BYTES + K_BYTES;
+  constexpr int NPB = ONECB ? 1 : 2;          // patch buffers
+  constexpr int MAIN_BYTES = NPB * PATCH_BYTES + NSB * B_BYTES + K_BYTES;
   constexpr int EPI_BYTES = BM * OPITCH + NTHR * 64;
   constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
   unsigned char* const s_patch = smem;
-  unsigned char* const s_b = smem + 2 * PATCH_BYTES;
+  unsigned char* const s_b = smem + NPB * PATCH_BYTES;
   unsigned char* const s_k = s_b + NSB * B_BYTES;
 
   const LoGeom& g = a.g;
@@ -611,6 +621,16 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   float ga1[8], ga2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
+  float gsc[8], gsh[8];   // fused GN-backward reduction: u = v * gsc + gsh for this thread's 8 channels (the tile lies inside one sample)
+  if (a.gb_v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = n0 + ochunk * 8 + j, gr = c / G;
+      const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
+      gsc[j] = a.gb_gamma[c] * rstd;
+      gsh[j] = a.gb_beta[c] - mean * gsc[j];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < OP; ++i) {
     int ml = orow + i * ORPP;
@@ -630,6 +650,16 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     if (a.bn_partial) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; ga1[j] += x; ga2[j] += x * x; }
+    }
+    if (a.gb_v) {
+      const f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float hv = (float)vv[j];
+        const float du = (float)h[j] * lo_mish_grad(hv * gsc[j] + gsh[j]);
+        ga1[j] += du;
+        ga2[j] += du * hv;          // sum du*xhat = rstd * (sum du*v - mean * sum du): finished after the loop
+      }
     }
     if (a.gn_partial) {
 #pragma unroll
@@ -651,6 +681,29 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
       dst[o] = tot;
     }
+  }
+  if (a.gb_v) {
+    if (a.bn_partial) __syncthreads();   // `red` is reused (no caller sets both; the barrier keeps that legal)
+    // the saved mean / rstd are read here, after the store loop, not held in registers across it (same form as lo_igemm_nt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gr = (n0 + ochunk * 8 + j) / G;
+      const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
+      ga2[j] = rstd * (ga2[j] - mean * ga1[j]);
+    }
+    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);   // [NTHR][16] floats
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j * 2] = ga1[j]; red[tid * 16 + j * 2 + 1] = ga2[j]; }
+    __syncthreads();
+    float* dst = a.gb_P1 + (((size_t)n_img * tiles_img + t_img) * g.Cout + n0) * 2;
+    for (int o = tid; o < BN * 2; o += NTHR) {
+      int cl = o >> 1, w = o & 1;
+      int ccx = cl >> 3, j = cl & 7;
+      float tot = 0.f;
+      for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
+      dst[o] = tot;
+    }
+    if (a.gn_partial) __syncthreads();
   }
   if (a.gn_partial) {
     float* red = reinterpret_cast<float*>(smem + BM * OPITCH);
@@ -696,7 +749,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-// mode: 0 = off, 1 = LO_HALO=1 (every applicable shape), 2 = default (shapes where it measured faster)
+// mode: 0 = off, 1 = LO_HALO=1 (every applicable shape, older tile choice), 2 = default (shapes where it measured faster),
+// 3 = the ping-pong kernel on every shape it can tile
 static inline int conv3_mode() {
   static const int m = getenv("LO_HALO") ? atoi(getenv("LO_HALO")) : 2;
   return m;
@@ -708,6 +762,14 @@ static inline bool conv3_tile(const LoGeom& g, int* th, int* tw, int* bn, int* n
   static const int want_bn = getenv("LO_HALO_BN") ? atoi(getenv("LO_HALO_BN")) : 128;
   static const int want_big = getenv("LO_HALO_BIG") ? atoi(getenv("LO_HALO_BIG")) : 1;
   *nw = 4;
+  // the 8-wave ping-pong kernel with the tile that gives >= 256 workgroups: 16x16 pixels x 64 channels for Cout = 64, 8x16 x 128
+  // when the 16x16 x 128 tile would leave CUs idle (LO_HALO=1 keeps the older choice below, which includes the 4-wave kernels)
+  if (conv3_mode() >= 2 && g.Win % 16 == 0 && g.Hin % 16 == 0) {
+    const long t16 = (long)g.B * (g.Hin / 16) * (g.Win / 16);
+    if (g.Cout % 128 == 0 && t16 * (g.Cout / 128) >= 256) { *th = 16; *tw = 16; *bn = 128; *nw = 8; return true; }
+    if (g.Cout % 128 == 0) { *th = 8; *tw = 16; *bn = 128; *nw = 8; return true; }
+    if (g.Cout == 64) { *th = 16; *tw = 16; *bn = 64; *nw = 8; return true; }
+  }
   if (want_big && g.Win % 16 == 0 && g.Hin % 16 == 0 && g.Cout % 128 == 0) { *th = 16; *tw = 16; *bn = 128; *nw = 8; }
   else if (g.Win % 16 == 0) { *th = 8; *tw = 16; *bn = (want_bn == 128 && g.Cout % 128 == 0) ? 128 : 64; }
   else if (g.Win % 8 == 0) { *th = 8; *tw = 8; *bn = (want_bn == 128 && g.Cout % 128 == 0) ? 128 : 64; }
@@ -722,20 +784,32 @@ int lo_conv3_tiles_per_image(const LoGeom& g, bool need_bn) {
   const int mode = conv3_mode();
   if (mode == 0 || !conv3_tile(g, &th, &tw, &bn, &nw)) return 0;
   if (need_bn && nw != 8) return 0;   // BatchNorm partial rows (teacher epilogue) only with the 16x16-pixel tile
+  if (mode >= 2 && nw != 8) return 0;
   if (mode == 2) {
-    // default: the 16x16-pixel x 128-channel workgroup on long grids (>= 4 tiles per CU), where it measured faster than
-    // lo_igemm_nt
+    // default: where it measured faster than lo_igemm_nt -- the 16x16-pixel x 128-channel workgroup on
+    // long grids (>= 4 tiles per CU: the teacher), and, for launches without the BatchNorm epilogue, any tile choice above that
+    // puts a workgroup on every CU (the VAE's 64 / 128 / 256-channel ResBlock convolutions at batch 64: 44 -> 36, 34 -> 28,
+    // 36 -> 33 us; +1.0 % on the step over three interleaved pairs)
     const long tiles = (long)g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
-    if (!(nw == 8 && tiles >= 1024)) return 0;
+    const bool long_grid = th == 16 && bn == 128 && tiles >= 1024;
+    if (!(long_grid || (!need_bn && tiles >= 256))) return 0;
   }
   return (g.Hin / th) * (g.Win / tw);
 }
 
+// does the kernel lo_conv3_run would launch for g carry the fused GroupNorm-backward epilogue?  (the 8-wave ping-pong kernel does)
+bool lo_conv3_fuses_gnb(const LoGeom& g) {
+  int th, tw, bn, nw;
+  return lo_conv3_tiles_per_image(g, false) > 0 && conv3_tile(g, &th, &tw, &bn, &nw) && nw == 8;
+}
+
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                 float* gn_partial, hipStream_t st, const LoConvExtra* ex) {
+                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb) {
   int th, tw, bn, nw;
   LO_REQUIRE(conv3_tile(g, &th, &tw, &bn, &nw), "lo_conv3_run: geometry not supported by the fused-tap kernel");
+  LO_REQUIRE(!gb || nw == 8, "lo_conv3_run: the fused GroupNorm-backward epilogue needs the 8-wave kernel");
   Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, nullptr, g};
+  if (gb) { a.gb_v = gb->v; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_P1 = gb->P1; }
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif
@@ -743,10 +817,13 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
   double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
   double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * (g.Cin + g.Cout) + 9.0 * g.Cin * g.Cout);
   static char name[64];
-  snprintf(name, sizeof(name), "lo_conv3x3_halo<%d,%dx%d>", bn, th, tw);
+  snprintf(name, sizeof(name), nw == 8 ? "lo_conv3x3_pp<%d,%dx%d>" : "lo_conv3x3_halo<%d,%dx%d>", bn, th, tw);
   LoProfScope _p(name, flops, bytes, st);
   static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;   // 0: lock-step 8-wave kernel (A/B knob)
-  if (nw == 8 && pp) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
+  if (nw == 8 && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, false>), dim3(tiles), dim3(512), 0, st, a);
+  else if (nw == 8 && bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, false, false, true>), dim3(tiles), dim3(512), 0, st, a);
+  else if (nw == 8 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
+  else if (nw == 8 && pp) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
   else if (nw == 8) hipLaunchKernelGGL((lo_conv3x3_halo<128, 16, 16, 8, 3>), dim3(tiles), dim3(512), 0, st, a);
   else if (tw == 16 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_halo<64, 8, 16, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
   else if (tw == 16 && bn == 128) hipLaunchKernelGGL((lo_conv3x3_halo<128, 8, 16, 4, 3>), dim3(tiles), dim3(256), 0, st, a);

@@ -35,7 +35,9 @@ bool lo_conv3_pp_f8_applies(const LoGeom& g);
 int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, f16* out,
                        hipStream_t st, const LoConvExtra* ex);
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                 float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr);
+                 float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr, const LoGnBwdFuse* gb = nullptr);
+bool lo_conv3_fuses_gnb(const LoGeom& g);
+int lo_conv_gnb_rows(const LoGeom& g);   // P1 rows per sample written by lo_conv_run(g, ..., gb) (fused GroupNorm-backward epilogue)
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);
 int lo_wgrad_nsplit(const LoGeom& g);
 int lo_wgrad3_nsplit(const LoGeom& g);   // multi-tap 3x3 stride-1 weight-gradient kernel: pixel splits, 0 = does not apply
