@@ -752,8 +752,18 @@ extern "C" int lo_vae_join(LoVae* h, void* stream) {
 }
 
 // in8: e4m3 copy of `in` (fp8 mode, layers with c.f8); y8: where to leave the e4m3 copy of y (0 = nobody reads it)
+// xprod: the conv+GN+Mish layer (plain mode) whose GroupNorm + Mish this conv applies on load; `in` is then its raw output o_v and
+//        its activation o_a / statistics are written by this launch (lo_conv3x3_pp<XF = 2>)
+// defer_gn: this layer's own GroupNorm pass is left to its consumer (which will be called with xprod = &c)
+static bool vae_gn_on_load(const LoVae* h, const ConvLayer& prod, const ConvLayer& cons) {
+  // Measured at batch 64 (three interleaved pairs of 300-step runs): 21 425 sprites/s with it, 21 593 without.  The separate passes
+  // it removes take 16 / 11 / 9 us (64 / 128 / 256 channels) but the consuming convs get 14 / 9 / 10 us slower: the Mish of the
+  // halo-inflated patch runs with every wave of the workgroup stopped between two barriers, off the MFMA pipe.  Off by default.
+  static const int on = getenv("LO_GN_ON_LOAD") ? atoi(getenv("LO_GN_ON_LOAD")) : 0;
+  return on && !h->fp8_fwd && !cons.f8 && cons.Cin <= 256 && lo_conv3_fuses_gnb(cons.gf);
+}
 static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16* y, int mode, const float* P, void* ws,
-                   hipStream_t st, size_t o_in8 = 0, size_t o_y8 = 0) {
+                   hipStream_t st, size_t o_in8 = 0, size_t o_y8 = 0, ConvLayer* xprod = nullptr, bool defer_gn = false) {
   static char ftag[64][64];
   static int fcount = 0;
   if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
@@ -766,11 +776,16 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
     LO_REQUIRE(o_in8, "fp8 mode: no e4m3 copy of the input of a conv %d->%d", c.Cin, c.Cout);
     r_ = lo_conv_run_f8(c.gf, WSP(uint8_t, o_in8), WSP(uint8_t, c.o_wp8), WSP(float, c.o_wscale), PRM(c.p_b), nullptr, WSP(f16, c.o_v),
                         WSP(float, c.o_part), st);
+  } else if (xprod) {
+    LoGnApplyFuse xg{WSP(float, xprod->o_part), xprod->MT, PRM(xprod->p_gw), PRM(xprod->p_gb), WSP(float, xprod->o_stats), WSP(f16, xprod->o_a)};
+    r_ = lo_conv_run(c.gf, WSP(f16, xprod->o_v), WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st,
+                     nullptr, nullptr, &xg);
   } else {
     r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st);
   }
   g_lo_prof_tag = nullptr;
   if (r_ != LO_OK) return r_;
+  if (defer_gn) return LO_OK;
   return lo_gn_fwd(WSP(f16, c.o_v), WSP(float, c.o_part), c.MT, PRM(c.p_gw), PRM(c.p_gb), other, y, WSP(float, c.o_stats), h->B,
                    c.Ho * c.Wo, c.Cout, mode, st, o_y8 ? WSP(uint8_t, o_y8) : nullptr);
 }
@@ -809,20 +824,24 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
     ConvLayer& c0 = h->enc[s][0];
     ConvLayer& c1 = h->enc[s][1];
     ConvLayer& c2 = h->enc[s][2];
+    // GroupNorm + Mish of c0 / c1 on the operand load of the ResBlock conv that consumes them, where that conv runs on the
+    // fused-tap kernel (stages 1..3 at batch 64): the activation is still written (by that conv), the separate pass is not run
+    const bool f01 = vae_gn_on_load(h, c0, c1), f12 = vae_gn_on_load(h, c1, c2);
     if (s == 0) {
       LO_TRY(lo_first_conv_fwd(x, PRM(c0.p_w), PRM(c0.p_b), WSP(f16, c0.o_v), WSP(float, c0.o_part), B, st));
-      LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
-                       WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
+      if (!f01)
+        LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
+                         WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
       LO_TRY(vae_wait_level(h, st, 1));
     } else {
       // the last stage's packed weights are refreshed at the END of the side-stream chain of a pipelined optimizer step
       // (after the AdamW of everything from this stage on): same event as the Linear casts
       if (s == 3) LO_TRY(vae_wait_level(h, st, 2));
-      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8));
+      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8, nullptr, f01));
     }
-    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8));
+    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8, f01 ? &c0 : nullptr, f12));
     // ResBlock tail: out = mish(mish(GN(conv2)) + identity); c2.o_a is unused, the result is the stage output
-    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st, c1.o_a8, h->o_eout8[s]));
+    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st, c1.o_a8, h->o_eout8[s], f12 ? &c1 : nullptr));
     cur = WSP(f16, h->o_eout[s]);
     cur8 = h->o_eout8[s];
     // the deferred tail of a pipelined optimizer step goes to the side stream behind this stage (see lo_vae_optimizer_step)

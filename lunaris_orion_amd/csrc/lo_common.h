@@ -113,6 +113,34 @@ struct LoPackJob {
   LoGeom g;
 };
 
+// GroupNorm(8) statistics of sample n from the conv epilogue's partial sums partial[n][MT][8][2]: s_stat[g*2] = mean, [g*2+1] = rstd
+// (lo_gn_fwd, and the fused-tap kernel when it applies the normalisation on load)
+__device__ __forceinline__ void lo_gn_group_stats(const float* partial, int MT, int n, float inv_m, float* s_stat, int tid) {
+  // 64 threads: group = tid>>3, part = tid&7 ; double accumulation, fixed order
+  if (tid < 64) {
+    int grp = tid >> 3, part = tid & 7;
+    double s = 0.0, q = 0.0;
+    for (int mt = part; mt < MT; mt += 8) {
+      const float* p = partial + (((size_t)n * MT + mt) * 8 + grp) * 2;
+      s += (double)p[0];
+      q += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (part == 0) {
+      double mean = s * inv_m;
+      double var = q * inv_m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stat[grp * 2 + 0] = (float)mean;
+      s_stat[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)1e-5f));
+    }
+  }
+}
+
+
 const char* lo_prof_geom_name(const char* base, const LoGeom& g);   // per-layer profiler names under LO_PROF_LAYERS
 
 enum LoConvKind {

@@ -1072,7 +1072,8 @@ int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStrea
 
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb, const LoConvExtra* ex) {
+                float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb, const LoConvExtra* ex,
+                const LoGnApplyFuse* xg) {
   IgemmArgs a;
   a.in = in; a.w = wp; a.bias = bias; a.add_src = add_src; a.out = out; a.gn_partial = gn_partial; a.slab = slab;
   a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
@@ -1092,7 +1093,8 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
   if (a.nsplit == 1 && lo_conv3_tiles_per_image(g, ex != nullptr) > 0 && (!gb || lo_conv3_fuses_gnb(g)))
-    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb);   // fused-tap kernel for 3x3 stride-1
+    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb, xg);   // fused-tap kernel for 3x3 stride-1
+  LO_REQUIRE(!xg, "lo_conv_run: GroupNorm on load is only available in the fused-tap kernel (check lo_conv3_fuses_gnb first)");
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");
     LO_REQUIRE(BK == 64 && g.Cout % 64 == 0, "lo_conv_run: split-K path needs Cin%%64==0 and Cout%%64==0");

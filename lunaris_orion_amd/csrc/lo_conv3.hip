@@ -45,6 +45,17 @@ struct Conv3Args {
 #endif
   // fused GroupNorm-backward reduction (lo_conv3x3_pp only; same contract as IgemmArgs::gb_* in lo_conv.hip): the output is the
   // gradient wrt the activation of a conv+GN+Mish layer whose raw conv output is gb_v; P1[n][tile][c] = (sum du, sum du*xhat)
+  // GroupNorm + Mish of the PRODUCING layer applied on load (lo_conv3x3_pp<..., XF = 2>): `in` is that layer's raw conv output v;
+  // mean / rstd come from its conv epilogue's partial sums xg_partial [B][xg_MT][8][2]; the patch is transformed in LDS,
+  // a = mish(v * gamma * rstd + beta - mean * gamma * rstd), and the workgroups of the first channel tile also write their
+  // interior pixels of a to xg_y and (first tile of a sample) the statistics to xg_stats [B][8][2]: the separate lo_gn_fwd pass
+  // (one read of v, one launch) disappears, the activation it would have written still exists for the backward.
+  const float* xg_partial = nullptr;
+  int xg_MT = 0;
+  const float* xg_gamma = nullptr;
+  const float* xg_beta = nullptr;
+  float* xg_stats = nullptr;
+  f16* xg_y = nullptr;
   const f16* gb_v = nullptr;
   const float* gb_stats = nullptr;
   const float* gb_gamma = nullptr;
@@ -345,7 +356,8 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 // both images are read through the same chunk -> k map.  The epilogue multiplies by f8_scale[n] before the bias.  (Teacher 3x3 convolutions of the dropout path in fp8 mode, BASELINE config 5.)
 // ONECB: the launch has a single channel block (Cin == 64 for fp16): the second patch buffer is never filled, and without it two
 // workgroups fit on a CU, so that one's prologue / epilogue overlaps the other's tap loop.
-template <int BN, int TH, int TW, bool XF, bool F8 = false, bool ONECB = false>
+// XF: 0 = none, 1 = the teacher's folded block tail (levels of lrelu(x + k)), 2 = GroupNorm + Mish of the producing layer
+template <int BN, int TH, int TW, int XF, bool F8 = false, bool ONECB = false>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   static_assert(!(XF && F8), "the transform on load works on fp16 patches");
   constexpr int ES = F8 ? 1 : 2;              // bytes per operand element
@@ -366,7 +378,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   constexpr int WGM = 4, WM = BM / WGM, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;
   constexpr int XF_LEV = 2, XF_C = 128;       // transform constants staged in LDS: [2 levels][6 classes][128 channels] fp16
-  constexpr int K_BYTES = XF ? XF_LEV * 6 * XF_C * 2 : 0;
+  constexpr int XG_CMAX = 256;                // XF = 2: (scale, shift) per input channel as float2, then 16 floats of statistics
+  constexpr int K_BYTES = XF == 1 ? XF_LEV * 6 * XF_C * 2 : (XF == 2 ? XG_CMAX * 8 + 64 : 0);
   constexpr int NPB = ONECB ? 1 : 2;          // patch buffers
   constexpr int MAIN_BYTES = NPB * PATCH_BYTES + NSB * B_BYTES + K_BYTES;
   constexpr int EPI_BYTES = BM * OPITCH + NTHR * 64;
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int iy = y0 - 1 + py, ix = x0 - 1 + px;
     bool ok = pp < NPIX && px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     p_src[i] = ok ? (((n_img * H + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16) : -1;
-    if (XF && ok && iy < 8) {
+    if (XF == 1 && ok && iy < 8) {
       p_src[i] = (((n_img * 8 + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16);
       p_xc |= 1u << i;
     }
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       int off = -1;
 #pragma unroll
       for (int i = 0; i < PI; ++i) if (i == piece) off = p_src[i];
-      const unsigned char* base = (XF && ((p_xc >> piece) & 1u)) ? xcb : inb;
+      const unsigned char* base = (XF == 1 && ((p_xc >> piece) & 1u)) ? xcb : inb;
       const unsigned char* src = off >= 0 ? base + (off + cb * 128) : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_patch + buf * PATCH_BYTES + q * 1024), 16, 0, 0);
@@ -465,6 +478,33 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   // T_nlev(..T_1(x)); rows 0..7 came from xc already transformed, pixels outside the image stay zero (the padding)
   auto xform_patch = [&](int buf, int cb) __attribute__((always_inline)) {
     unsigned char* pb = s_patch + buf * PATCH_BYTES;
+    if constexpr (XF == 2) {
+      // GroupNorm + Mish of the producing layer on every in-image pixel of the patch (the zero padding stays zero); the same
+      // arithmetic as lo_gn_fwd's plain mode.  Interior pixels are the by-product store of the activation.
+      const float* tab = reinterpret_cast<const float*>(s_k);
+      for (int idx = tid; idx < NPIX * 8; idx += NTHR) {
+        const int pp = idx >> 3, pos = idx & 7;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        if (px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const int c = cb * 64 + ((pos ^ lo_swz3(pp)) * 8);
+          const f16x8 v = *reinterpret_cast<const f16x8*>(pb + pp * 128 + pos * 16);
+          f16x8 y;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(tab + (c + j) * 2);   // sc[j], sh[j], sc[j+1], sh[j+1]
+            const lo_f2 hv = {(float)v[j], (float)v[j + 1]};
+            const lo_f2 m = lo_mish2(hv * (lo_f2){t[0], t[2]} + (lo_f2){t[1], t[3]});
+            y[j] = (f16)m[0];
+            y[j + 1] = (f16)m[1];
+          }
+          *reinterpret_cast<f16x8*>(pb + pp * 128 + pos * 16) = y;
+          if (nt_i == 0 && py >= 1 && py <= TH && px >= 1 && px <= TW)
+            *reinterpret_cast<f16x8*>(a.xg_y + ((size_t)(n_img * H + iy) * W + ix) * Cin + c) = y;
+        }
+      }
+      return;
+    }
     for (int idx = tid; idx < NPIX * 8; idx += NTHR) {
       const int pp = idx >> 3, pos = idx & 7;
       const int py = pp / PW, px = pp - py * PW;
@@ -482,7 +522,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       }
     }
   };
-  if (XF) {
+  if (XF == 1) {
     for (int i = tid; i < a.nlev * 6 * XF_C / 8; i += NTHR)
       *reinterpret_cast<f16x8*>(s_k + i * 16) = *reinterpret_cast<const f16x8*>(a.kx + i * 8);
   }
@@ -491,6 +531,23 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   for (int i = 0; i < PI; ++i) issue_patch_piece(0, 0, i);
 #pragma unroll
   for (int s = 0; s < D; ++s) issue_b(s, s);
+  if constexpr (XF == 2) {
+    // statistics of this sample from the producer's partial sums, then (scale, shift) per input channel -- under the latency of
+    // the LDS-DMA just issued.  Same expressions as lo_gn_fwd, which this launch replaces.
+    float* tab = reinterpret_cast<float*>(s_k);
+    float* s_stat = tab + XG_CMAX * 2;
+    const int Gi = Cin >> 3;
+    lo_gn_group_stats(a.xg_partial, a.xg_MT, n_img, 1.0f / ((float)(H * W) * (float)Gi), s_stat, tid);
+    __syncthreads();
+    if (tid < Cin) {
+      const int gr = tid / Gi;
+      const float mean = s_stat[gr * 2], rstd = s_stat[gr * 2 + 1];
+      const float sc = a.xg_gamma[tid] * rstd;
+      tab[tid * 2] = sc;
+      tab[tid * 2 + 1] = a.xg_beta[tid] - mean * sc;
+    }
+    if (nt_i == 0 && t_img == 0 && tid < 16 && a.xg_stats) a.xg_stats[n_img * 16 + tid] = s_stat[tid];
+  }
   LO_VMCNT(IB * (D - 1));            // patch + step 0 landed (this wave's share)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // XF: the staged constants
   __builtin_amdgcn_s_barrier();
@@ -804,12 +861,17 @@ bool lo_conv3_fuses_gnb(const LoGeom& g) {
 }
 
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb) {
+                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb, const LoGnApplyFuse* xg) {
   int th, tw, bn, nw;
   LO_REQUIRE(conv3_tile(g, &th, &tw, &bn, &nw), "lo_conv3_run: geometry not supported by the fused-tap kernel");
   LO_REQUIRE(!gb || nw == 8, "lo_conv3_run: the fused GroupNorm-backward epilogue needs the 8-wave kernel");
+  LO_REQUIRE(!xg || (nw == 8 && g.Cin <= 256 && g.Cin % 64 == 0), "lo_conv3_run: GroupNorm on load needs the 8-wave kernel and Cin <= 256");
   Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, nullptr, g};
   if (gb) { a.gb_v = gb->v; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_P1 = gb->P1; }
+  if (xg) {
+    LO_REQUIRE(xg->partial && xg->MT > 0 && xg->gamma && xg->beta && xg->y, "lo_conv3_run: incomplete GroupNorm-on-load arguments");
+    a.xg_partial = xg->partial; a.xg_MT = xg->MT; a.xg_gamma = xg->gamma; a.xg_beta = xg->beta; a.xg_stats = xg->stats; a.xg_y = xg->y;
+  }
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif
@@ -818,9 +880,14 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
   double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * (g.Cin + g.Cout) + 9.0 * g.Cin * g.Cout);
   static char name[64];
   snprintf(name, sizeof(name), nw == 8 ? "lo_conv3x3_pp<%d,%dx%d>" : "lo_conv3x3_halo<%d,%dx%d>", bn, th, tw);
-  LoProfScope _p(name, flops, bytes, st);
+  if (xg) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cin;   // the by-product store of the normalised activation
+  LoProfScope _p(xg ? "lo_conv3x3_pp (GroupNorm + Mish on load)" : name, flops, bytes, st);
   static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;   // 0: lock-step 8-wave kernel (A/B knob)
-  if (nw == 8 && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, false>), dim3(tiles), dim3(512), 0, st, a);
+  if (xg && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
+  else if (xg && bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, 2, false, true>), dim3(tiles), dim3(512), 0, st, a);
+  else if (xg && bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
+  else if (xg) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
+  else if (nw == 8 && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, false>), dim3(tiles), dim3(512), 0, st, a);
   else if (nw == 8 && bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, false, false, true>), dim3(tiles), dim3(512), 0, st, a);
   else if (nw == 8 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
   else if (nw == 8 && pp) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);

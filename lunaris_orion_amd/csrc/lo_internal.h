@@ -9,12 +9,15 @@ int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
 int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base = 0);   // block_base: a sub-range of the table
 int lo_pack_blocks(const LoGeom& g);   // blocks of one job in the fused pack launch
 struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
+// GroupNorm + Mish of the producing layer applied on the consumer's operand load (fused-tap kernel only, see Conv3Args::xg_*):
+// `in` of the conv is the producer's raw output; partial / MT = its epilogue sums; y / stats = what lo_gn_fwd would have written
+struct LoGnApplyFuse { const float* partial; int MT; const float* gamma; const float* beta; float* stats; f16* y; };
 // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums; out_pitch > 0: the output tensor has out_pitch channels per pixel
 // and this op writes its Cout channels starting at channel out_choff (writing straight into a concatenated tensor)
 struct LoConvExtra { int act; float* bn_partial; int out_pitch = 0; int out_choff = 0; };
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr,
-                const LoConvExtra* ex = nullptr);
+                const LoConvExtra* ex = nullptr, const LoGnApplyFuse* xg = nullptr);
 // fp8 (e4m3) operand path of the forward convs
 struct LoPackF8Job { const f16* src; uint8_t* dst; float* scale; int K[LO_MAX_PHASE]; int wofs[LO_MAX_PHASE]; int Cout, n_phase, block0; };
 bool lo_conv_f8_applies(const LoGeom& g);
@@ -35,7 +38,8 @@ bool lo_conv3_pp_f8_applies(const LoGeom& g);
 int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const float* wscale, const float* bias, f16* out,
                        hipStream_t st, const LoConvExtra* ex);
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                 float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr, const LoGnBwdFuse* gb = nullptr);
+                 float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr, const LoGnBwdFuse* gb = nullptr,
+                 const LoGnApplyFuse* xg = nullptr);
 bool lo_conv3_fuses_gnb(const LoGeom& g);
 int lo_conv_gnb_rows(const LoGeom& g);   // P1 rows per sample written by lo_conv_run(g, ..., gb) (fused GroupNorm-backward epilogue)
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);

@@ -37,31 +37,6 @@ struct GnFwdArgs {
   uint8_t* y8;           // optional e4m3 copy of y * LO_F8_ACT_SCALE (operand of an fp8 conv), same layout
 };
 
-__device__ __forceinline__ void gn_group_stats(const float* partial, int MT, int n, float inv_m, float* s_stat, int tid) {
-  // 64 threads: group = tid>>3, part = tid&7 ; double accumulation, fixed order
-  if (tid < 64) {
-    int grp = tid >> 3, part = tid & 7;
-    double s = 0.0, q = 0.0;
-    for (int mt = part; mt < MT; mt += 8) {
-      const float* p = partial + (((size_t)n * MT + mt) * 8 + grp) * 2;
-      s += (double)p[0];
-      q += (double)p[1];
-    }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      s += __shfl_xor(s, o, 64);
-      q += __shfl_xor(q, o, 64);
-    }
-    if (part == 0) {
-      double mean = s * inv_m;
-      double var = q * inv_m - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_stat[grp * 2 + 0] = (float)mean;
-      s_stat[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)GN_EPS));
-    }
-  }
-}
-
 template <int MODE>   // the mode as a template parameter: the PLAIN launches do not carry the second operand's registers
 __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
   __shared__ float s_stat[16];
@@ -73,7 +48,7 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
   const f32x4 gm0 = *reinterpret_cast<const f32x4*>(a.gamma + c0), gm1 = *reinterpret_cast<const f32x4*>(a.gamma + c0 + 4);
   const f32x4 bt0 = *reinterpret_cast<const f32x4*>(a.beta + c0), bt1 = *reinterpret_cast<const f32x4*>(a.beta + c0 + 4);
   if (a.partial) {
-    gn_group_stats(a.partial, a.MT, n, 1.0f / ((float)a.HW * (float)G), s_stat, tid);
+    lo_gn_group_stats(a.partial, a.MT, n, 1.0f / ((float)a.HW * (float)G), s_stat, tid);
     __syncthreads();
     if (chunk == 0 && tid < 16 && a.stats) a.stats[n * 16 + tid] = s_stat[tid];
   } else {
