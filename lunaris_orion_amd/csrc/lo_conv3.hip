@@ -357,9 +357,14 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 // ONECB: the launch has a single channel block (Cin == 64 for fp16): the second patch buffer is never filled, and without it two
 // workgroups fit on a CU, so that one's prologue / epilogue overlaps the other's tap loop.
 // XF: 0 = none, 1 = the teacher's folded block tail (levels of lrelu(x + k)), 2 = GroupNorm + Mish of the producing layer
-template <int BN, int TH, int TW, int XF, bool F8 = false, bool ONECB = false>
+// PAIR: 8 x 8-pixel maps (the 512-channel stage).  One tile = two whole images side by side: patch columns 0..9 hold image 2p with
+// its halo, columns 10..19 image 2p+1 (the 20-column patch row is exactly two 10-column halos), a 16-pixel fragment is row y of
+// both images, and everything per sample in the epilogue (GroupNorm sums, the fused GroupNorm-backward reduction, addresses)
+// is split by the half of the fragment a row slot belongs to.
+template <int BN, int TH, int TW, int XF, bool F8 = false, bool ONECB = false, bool PAIR = false>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   static_assert(!(XF && F8), "the transform on load works on fp16 patches");
+  static_assert(!PAIR || (TH == 8 && TW == 16 && XF == 0), "PAIR: two 8x8 images per tile, no transform on load");
   constexpr int ES = F8 ? 1 : 2;              // bytes per operand element
   constexpr int CB = 128 / ES;                // channels per 128-byte row = channel block of one step
   constexpr int NW = 8, NTHR = 512, NSB = 4, D = 3;
@@ -396,11 +401,11 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const int grp = wave >> 2;                  // waves w and w+4 share a SIMD
   const int wm = wave & 3, wn = wave >> 2;
   const int H = g.Hin, W = g.Win, Cin = g.Cin;
-  const int tiles_x = W / TW, tiles_y = H / TH, tiles_img = tiles_x * tiles_y;
+  const int tiles_x = PAIR ? 1 : W / TW, tiles_y = PAIR ? 1 : H / TH, tiles_img = tiles_x * tiles_y;
   const int NT = g.Cout / BN;
   const int tile_id = lo_xcd_remap3(blockIdx.x, gridDim.x);
   const int nt_i = tile_id % NT, pt_i = tile_id / NT;
-  const int n_img = pt_i / tiles_img, t_img = pt_i - n_img * tiles_img;
+  const int n_img = PAIR ? pt_i * 2 : pt_i / tiles_img, t_img = PAIR ? 0 : pt_i - n_img * tiles_img;   // PAIR: first image of the two
   const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
   const int n0 = nt_i * BN;
   const int KCB = Cin / CB;
@@ -420,7 +425,13 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int py = pp / PW, px = pp - py * PW;
     int iy = y0 - 1 + py, ix = x0 - 1 + px;
     bool ok = pp < NPIX && px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    p_src[i] = ok ? (((n_img * H + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16) : -1;
+    int img = n_img;
+    if (PAIR) {
+      img = n_img + (px >= 10 ? 1 : 0);
+      ix = (px >= 10 ? px - 10 : px) - 1;
+      ok = pp < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    }
+    p_src[i] = ok ? (((img * H + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16) : -1;
     if (XF == 1 && ok && iy < 8) {
       p_src[i] = (((n_img * 8 + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16);
       p_xc |= 1u << i;
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   };
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int pp00 = (wm * MI + 1) * PW + fr + 1;            // patch pixel of fragment 0 at tap offset (0, 0)
+  const int pp00 = (wm * MI + 1) * PW + fr + 1 + (PAIR && fr >= 8 ? 2 : 0);   // patch pixel of fragment 0 at tap offset (0, 0)
   const int R0 = wn * WN + fr;
   const int fch = fq;                                      // 16-byte chunk of this lane's fragment at kk = 0 (kk = 1: fq + 4)
   const int w00 = R0 * 128 + ((fch ^ lo_swz3(R0)) * 16);   // weight fragment (ni = 0, kk = 0) inside a ring stage
@@ -679,11 +690,13 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
   float gsc[8], gsh[8];   // fused GN-backward reduction: u = v * gsc + gsh for this thread's 8 channels (the tile lies inside one sample)
+  static_assert(!PAIR || ORPP % 16 == 0, "PAIR: a thread's row slots must stay in one half of the fragment");
+  const int my_img = n_img + (PAIR ? (orow & 15) >> 3 : 0);   // the sample this thread's rows belong to
   if (a.gb_v) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = n0 + ochunk * 8 + j, gr = c / G;
-      const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
+      const float mean = a.gb_stats[my_img * 16 + gr * 2], rstd = a.gb_stats[my_img * 16 + gr * 2 + 1];
       gsc[j] = a.gb_gamma[c] * rstd;
       gsh[j] = a.gb_beta[c] - mean * gsc[j];
     }
@@ -694,6 +707,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int ty = ml / TW, tx = ml % TW;
     f16x8 h = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
     size_t off = ((size_t)(n_img * H + y0 + ty) * W + x0 + tx) * g.Cout + n0 + ochunk * 8;
+    if (PAIR) off = ((size_t)(my_img * H + ty) * W + (tx & 7)) * g.Cout + n0 + ochunk * 8;
     if (a.add_src) {
       f16x8 r = *reinterpret_cast<const f16x8*>(a.add_src + off);
 #pragma unroll
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int gr = (n0 + ochunk * 8 + j) / G;
-      const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
+      const float mean = a.gb_stats[my_img * 16 + gr * 2], rstd = a.gb_stats[my_img * 16 + gr * 2 + 1];
       ga2[j] = rstd * (ga2[j] - mean * ga1[j]);
     }
     float* red = reinterpret_cast<float*>(smem + BM * OPITCH);   // [NTHR][16] floats
@@ -756,9 +770,19 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     for (int o = tid; o < BN * 2; o += NTHR) {
       int cl = o >> 1, w = o & 1;
       int ccx = cl >> 3, j = cl & 7;
-      float tot = 0.f;
-      for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
-      dst[o] = tot;
+      if (PAIR) {   // row slots with (r & 15) < 8 belong to image n_img, the others to n_img + 1 (one P1 row per sample)
+        float t0 = 0.f, t1 = 0.f;
+        for (int r = 0; r < ORPP; ++r) {
+          const float x = red[(r * OCPR + ccx) * 16 + j * 2 + w];
+          if ((r & 15) < 8) t0 += x; else t1 += x;
+        }
+        dst[o] = t0;
+        dst[(size_t)g.Cout * 2 + o] = t1;
+      } else {
+        float tot = 0.f;
+        for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
+        dst[o] = tot;
+      }
     }
     if (a.gn_partial) __syncthreads();
   }
@@ -777,21 +801,27 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       red2[part * NV + o] = t;
     }
     __syncthreads();
+    static_assert(!PAIR || (RPP2 <= 8 && 8 % RPP2 == 0), "PAIR: the row slots of a part must stay in one half of the fragment");
     if (tid < NV) {
-      float t = 0.f;
+      float t = 0.f, t1 = 0.f;
 #pragma unroll
-      for (int q = 0; q < P; ++q) t += red2[q * NV + tid];
+      for (int q = 0; q < P; ++q) {
+        if (PAIR && ((q * RPP2) & 15) >= 8) t1 += red2[q * NV + tid];
+        else t += red2[q * NV + tid];
+      }
       red3[tid] = t;
+      if (PAIR) red3[NV + tid] = t1;
     }
     __syncthreads();
     const int ngroups = BN / G;
-    if (tid < ngroups * 2) {
-      int gl = tid >> 1, which = tid & 1;
+    if (tid < ngroups * 2 * (PAIR ? 2 : 1)) {
+      const int half = tid / (ngroups * 2), t2 = tid - half * (ngroups * 2);
+      int gl = t2 >> 1, which = t2 & 1;
       int hc_begin = gl * G / 4, hc_end = (gl + 1) * G / 4;
       float tot = 0.f;
-      for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[(hc >> 1) * 4 + (hc & 1) * 2 + which];
+      for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[half * NV + (hc >> 1) * 4 + (hc & 1) * 2 + which];
       int grp2 = (n0 / G) + gl;
-      a.gn_partial[(((size_t)n_img * tiles_img + t_img) * 8 + grp2) * 2 + which] = tot;
+      a.gn_partial[(((size_t)(n_img + half) * tiles_img + t_img) * 8 + grp2) * 2 + which] = tot;
     }
   }
 #ifdef LO_STAMPS
@@ -812,6 +842,13 @@ static inline int conv3_mode() {
   static const int m = getenv("LO_HALO") ? atoi(getenv("LO_HALO")) : 2;
   return m;
 }
+// 8 x 8 maps, an even batch, GroupNorm groups of at most 64 channels: the two-images-per-tile form of the ping-pong kernel
+static inline bool conv3_pair(const LoGeom& g) {
+  // Measured at batch 64: 48 / 50 us per forward / data-gradient launch against 43 / 45 for lo_igemm_nt -- 128 pixels x 64 channels
+  // per workgroup leaves a wave 8 MFMAs per (tap, channel block) step, too few for the two barriers of a step.  Opt-in.
+  static const int on = getenv("LO_HALO_PAIR") ? atoi(getenv("LO_HALO_PAIR")) : 0;
+  return on && g.Win == 8 && g.Hin == 8 && g.B % 2 == 0 && g.Cout % 64 == 0 && (g.Cout >> 3) <= 64;
+}
 static inline bool conv3_tile(const LoGeom& g, int* th, int* tw, int* bn, int* nw) {
   if (g.n_phase != 1 || g.T[0] != 9 || g.in_stride != 1 || g.out_stride != 1) return false;
   if (g.Cin % 64 || g.Cout % 64) return false;
@@ -821,6 +858,7 @@ static inline bool conv3_tile(const LoGeom& g, int* th, int* tw, int* bn, int* n
   *nw = 4;
   // the 8-wave ping-pong kernel with the tile that gives >= 256 workgroups: 16x16 pixels x 64 channels for Cout = 64, 8x16 x 128
   // when the 16x16 x 128 tile would leave CUs idle (LO_HALO=1 keeps the older choice below, which includes the 4-wave kernels)
+  if (conv3_mode() >= 2 && conv3_pair(g)) { *th = 8; *tw = 16; *bn = 64; *nw = 8; return true; }   // two 8x8 images per tile
   if (conv3_mode() >= 2 && g.Win % 16 == 0 && g.Hin % 16 == 0) {
     const long t16 = (long)g.B * (g.Hin / 16) * (g.Win / 16);
     if (g.Cout % 128 == 0 && t16 * (g.Cout / 128) >= 256) { *th = 16; *tw = 16; *bn = 128; *nw = 8; return true; }
@@ -847,10 +885,12 @@ int lo_conv3_tiles_per_image(const LoGeom& g, bool need_bn) {
     // long grids (>= 4 tiles per CU: the teacher), and, for launches without the BatchNorm epilogue, any tile choice above that
     // puts a workgroup on every CU (the VAE's 64 / 128 / 256-channel ResBlock convolutions at batch 64: 44 -> 36, 34 -> 28,
     // 36 -> 33 us; +1.0 % on the step over three interleaved pairs)
-    const long tiles = (long)g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
+    const bool pair = conv3_pair(g);
+    const long tiles = pair ? (long)(g.B / 2) * (g.Cout / bn) : (long)g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
     const bool long_grid = th == 16 && bn == 128 && tiles >= 1024;
     if (!(long_grid || (!need_bn && tiles >= 256))) return 0;
   }
+  if (conv3_pair(g)) return need_bn ? 0 : 1;   // one row of per-sample sums per image
   return (g.Hin / th) * (g.Win / tw);
 }
 
@@ -875,7 +915,9 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif
-  const int tiles = g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
+  const bool pair = conv3_mode() >= 2 && conv3_pair(g);
+  LO_REQUIRE(!pair || (!xg && !(ex && ex->bn_partial)), "lo_conv3_run: the two-image tile has no transform on load / BatchNorm epilogue");
+  const int tiles = pair ? (g.B / 2) * (g.Cout / bn) : g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
   double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
   double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * (g.Cin + g.Cout) + 9.0 * g.Cin * g.Cout);
   static char name[64];
@@ -883,7 +925,8 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
   if (xg) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cin;   // the by-product store of the normalised activation
   LoProfScope _p(xg ? "lo_conv3x3_pp (GroupNorm + Mish on load)" : name, flops, bytes, st);
   static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;   // 0: lock-step 8-wave kernel (A/B knob)
-  if (xg && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
+  if (pair) hipLaunchKernelGGL((lo_conv3x3_pp<64, 8, 16, 0, false, false, true>), dim3(tiles), dim3(512), 0, st, a);
+  else if (xg && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
   else if (xg && bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, 2, false, true>), dim3(tiles), dim3(512), 0, st, a);
   else if (xg && bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
   else if (xg) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, 2>), dim3(tiles), dim3(512), 0, st, a);

@@ -394,13 +394,15 @@ struct LcBwdArgs {
 //                   v_mfma_f32_16x16x32_f16 (ci 0..15, 16..31); A gathered from dpre with per-lane byte offsets
 //   weight gradient D[co][ci] += sum_px dpre[px][co] a4[px + tap][ci] per tap: K = 32 pixels (two tile rows), A = dpre^T
 //                   (3 of 16 rows used), B by transposed LDS reads of the a4 tile; 18 accumulators kept across the 8 tiles
+template <int TPW>   // tiles per workgroup: 8 = a whole row of tiles; fewer = more workgroups (the partial buffer holds 64 rows per sample)
 __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
   constexpr int SP = 80;                                          // staging pitch of the output tile (bytes per pixel)
   __shared__ __attribute__((aligned(16))) unsigned char tile[LC_TP * LC_TP * LC_PITCH];  // reused as reduction buffer
   __shared__ __attribute__((aligned(16))) f16 dp[LC_TP * LC_TP][8];   // dpre as fp16 hi [0..2] + lo [4..6] (hi + lo ~ 22 bits)
   __shared__ __attribute__((aligned(16))) unsigned char so[256 * SP];
   __shared__ float bred[4][3];
-  const int tid = threadIdx.x, lane = tid & 63, ty = blockIdx.x, n = blockIdx.y;   // one workgroup = one row of 8 tiles
+  constexpr int WPR = 8 / TPW;                                                       // workgroups per row of tiles
+  const int tid = threadIdx.x, lane = tid & 63, ty = blockIdx.x / WPR, tx0 = (blockIdx.x % WPR) * TPW, n = blockIdx.y;
   const int wave = tid >> 6, m = lane & 15, g = lane >> 4;
   const float cf = a.drecon ? a.gscale : *a.coef;
   // ---- data-gradient constants: k = 8g + jj -> (tap, co); A byte offset relative to pixel (py, m) of the tile; B = weights
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
   for (int t = 0; t < 9; ++t) { wacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wacc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float bacc0 = 0.f, bacc1 = 0.f, bacc2 = 0.f;
   const int tq = m >> 2, tsub = (m & 3) * 8;                      // transposed-read lane roles
-  for (int tx = 0; tx < 8; ++tx) {
+  for (int tx = tx0; tx < tx0 + TPW; ++tx) {
     __syncthreads();                     // previous tile fully consumed
     lc_stage_a4(a.a4, tile, n, ty, tx, tid);
     for (int p = tid; p < LC_TP * LC_TP; p += 256) {
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
   bacc0 = lo_wave_sum(bacc0); bacc1 = lo_wave_sum(bacc1); bacc2 = lo_wave_sum(bacc2);
   if (lane == 0) { bred[wave][0] = bacc0; bred[wave][1] = bacc1; bred[wave][2] = bacc2; }
   __syncthreads();
-  float* outp = a.partial + ((size_t)n * gridDim.x + ty) * 867;
+  float* outp = a.partial + ((size_t)n * gridDim.x + blockIdx.x) * 867;
   for (int i = tid; i < 27 * 32; i += 256) {
     const float t = red[i] + red[27 * 32 + i] + red[2 * 27 * 32 + i] + red[3 * 27 * 32 + i];
     const int k = i / 32, ci = i % 32;       // k = tap*3 + co
@@ -560,12 +562,16 @@ int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const f
                       hipStream_t st) {
   LcBwdArgs a{a4, w, recon, target, drecon, coef, gscale, da4, partial};
   LoProfScope _p("lo_final_conv_bwd(+sums)", 4.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 * 2 + 3 * 4 * 2), st);
-  hipLaunchKernelGGL(lo_final_conv_bwd_kernel, dim3(8, B), dim3(256), 0, st, a);
+  static const int tpw = getenv("LO_FINAL_BWD_TPW") ? atoi(getenv("LO_FINAL_BWD_TPW")) : 8;   // 8, 4 or 2 tiles per workgroup
+  const int rows = tpw == 2 ? 32 : (tpw == 4 ? 16 : 8);
+  if (rows == 32) hipLaunchKernelGGL(lo_final_conv_bwd_kernel<2>, dim3(rows, B), dim3(256), 0, st, a);
+  else if (rows == 16) hipLaunchKernelGGL(lo_final_conv_bwd_kernel<4>, dim3(rows, B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(lo_final_conv_bwd_kernel<8>, dim3(rows, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("final_conv_bwd");
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * 8, 864, 867, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * rows, 864, 867, scale);
   LO_LAUNCH_CHECK("final_conv_dw");
   // bias: columns 864..866 of the same partial matrix
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3(1), dim3(256), 0, st, partial + 864, db, B * 8, 3, 867, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3(1), dim3(256), 0, st, partial + 864, db, B * rows, 3, 867, scale);
   LO_LAUNCH_CHECK("final_conv_db");
   return LO_OK;
 }
