@@ -253,26 +253,45 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
   size_t stride = (size_t)gridDim.x * 256;
   const float step_size = lr / bc1;
   size_t n4 = n / 4;
-  for (size_t k = i; k < n4; k += stride) {
-    f32x4 pv = reinterpret_cast<f32x4*>(p)[k];
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[k];
-    f32x4 mv = reinterpret_cast<f32x4*>(m)[k];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[k];
+  // U groups of four elements per thread and iteration, all 4 * U loads issued before the first use: the launch keeps HBM busy
+  // from 256 workgroups (one per CU, 4 of its 32 wave slots): 0.273 ms for the 61 M parameters of the VAE (6.2 TB/s) against
+  // 0.300 ms for the earlier shape, 2048 grid-stride workgroups, which also held EVERY wave slot of the chip for the kernel's
+  // whole life (in the rocprofv3 timeline a main-stream kernel arriving beside a side-stream AdamW launch waits for it).  The
+  // step itself does not change with the shape (LO_ADAMW_BLOCKS = 256 / 512 / 1024 / 2048: 21.1 - 21.5 k sprites/s, no order).
+  constexpr int U = 4;
+  for (size_t k0 = i; k0 < n4; k0 += U * stride) {
+    f32x4 pv[U], gv[U], mv[U], vv[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float gg = gv[j] * coef;
-      float pp = pv[j] * (1.0f - lr * wd);
-      float mm = mv[j] + (gg - mv[j]) * (1.0f - beta1);
-      float v2 = vv[j] * beta2 + (1.0f - beta2) * gg * gg;
-      float denom = sqrtf(v2) / bc2_sqrt + eps;
-      pv[j] = pp - step_size * (mm / denom);
-      mv[j] = mm;
-      vv[j] = v2;
+    for (int u = 0; u < U; ++u) {
+      const size_t k = k0 + u * stride;
+      if (k < n4) {
+        pv[u] = reinterpret_cast<f32x4*>(p)[k];
+        gv[u] = reinterpret_cast<const f32x4*>(g)[k];
+        mv[u] = reinterpret_cast<f32x4*>(m)[k];
+        vv[u] = reinterpret_cast<f32x4*>(v)[k];
+      }
     }
-    reinterpret_cast<f32x4*>(p)[k] = pv;
-    reinterpret_cast<f32x4*>(m)[k] = mv;
-    reinterpret_cast<f32x4*>(v)[k] = vv;
-    if (cast) reinterpret_cast<f16x4*>(cast)[k] = (f16x4){(f16)pv[0], (f16)pv[1], (f16)pv[2], (f16)pv[3]};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = k0 + u * stride;
+      if (k < n4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gg = gv[u][j] * coef;
+          float pp = pv[u][j] * (1.0f - lr * wd);
+          float mm = mv[u][j] + (gg - mv[u][j]) * (1.0f - beta1);
+          float v2 = vv[u][j] * beta2 + (1.0f - beta2) * gg * gg;
+          float denom = sqrtf(v2) / bc2_sqrt + eps;
+          pv[u][j] = pp - step_size * (mm / denom);
+          mv[u][j] = mm;
+          vv[u][j] = v2;
+        }
+        reinterpret_cast<f32x4*>(p)[k] = pv[u];
+        reinterpret_cast<f32x4*>(m)[k] = mv[u];
+        reinterpret_cast<f32x4*>(v)[k] = vv[u];
+        if (cast) reinterpret_cast<f16x4*>(cast)[k] = (f16x4){(f16)pv[u][0], (f16)pv[u][1], (f16)pv[u][2], (f16)pv[u][3]};
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (size_t k = n4 * 4; k < n; ++k) {
@@ -372,8 +391,9 @@ int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float
   double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
   (void)bc1; (void)bc2;
   LoProfScope _p(cast ? "lo_adamw(+fp16 copy)" : "lo_adamw", 0, (cast ? 30.0 : 28.0) * n, st);
+  static const int max_blocks = getenv("LO_ADAMW_BLOCKS") ? atoi(getenv("LO_ADAMW_BLOCKS")) : 256;   // 2048 = the earlier shape
   const size_t want = (n / 4 + 255) / 256;
-  const int nblk = want >= 2048 ? 2048 : (want < 1 ? 1 : (int)want);
+  const int nblk = want >= (size_t)max_blocks ? max_blocks : (want < 1 ? 1 : (int)want);
   hipLaunchKernelGGL(lo_adamw_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
                      (float)bc1d, (float)sqrt(bc2d), cast);
   LO_LAUNCH_CHECK("adamw");

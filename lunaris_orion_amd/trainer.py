@@ -101,6 +101,8 @@ class VAEStepper:
         host synchronisation: the skipped-update counter of the step just enqueued travels to pinned memory behind it; whichever
         earlier copy has landed by now is evaluated.  The host runs a step or two ahead of the GPU, so an overflow is answered
         after that many skipped updates — not after `--log_every` of them, as when only metrics() looked."""
+        if os.environ.get("LO_NO_SKIP_OBSERVE") == "1":      # measurement knob: no per-step device -> host copy at all
+            return
         if self._skip_event is not None and self._skip_event.query():
             self._update_loss_scale(float(self._skip_pinned[0]))
             self._skip_event = None

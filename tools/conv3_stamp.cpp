@@ -21,9 +21,10 @@ int main(int argc, char** argv) {
   hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&o, nx * 2); hipMalloc(&bias, C * 4);
   hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice);
   hipMemset(bias, 0, C * 4);
-  int tiles = B * (H / 16) * (H / 16) * (C / 128);
+  const int bn = C % 128 == 0 ? 128 : 64;   // LO_HALO=3 picks 16x16 pixels x 64 channels for C = 64 (one patch buffer, two workgroups per CU)
+  int tiles = B * (H / 16) * (H / 16) * (C / bn);
   hipMalloc(&st, (size_t)tiles * 8 * 16 * 8); hipMemset(st, 0, (size_t)tiles * 8 * 16 * 8);
-  setenv("LO_HALO", "1", 1);
+  setenv("LO_HALO", "3", 1);
   g_lo_conv3_stamps = st;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) lo_conv_run(g, x, w, bias, nullptr, o, nullptr, nullptr, 1, 0);
@@ -54,7 +55,6 @@ int main(int argc, char** argv) {
   std::vector<double> life;
   for (int t = 0; t < tiles; ++t) life.push_back((double)(hs[(size_t)t * 8 * 16 + 3] - hs[(size_t)t * 8 * 16 + 0]));
   std::sort(life.begin(), life.end());
-  printf("workgroup lifetime median %.0f clocks; kernel %.1f us => clock if 16 serial workgroups per CU: %.2f GHz\n", life[life.size() / 2], ms * 1e3,
-         life[life.size() / 2] * (tiles / 256.0) / (ms * 1e-3) / 1e9);
+  printf("workgroup lifetime median %.0f clocks; kernel %.1f us; %.1f workgroups per CU over the launch\n", life[life.size() / 2], ms * 1e3, tiles / 256.0);
   return 0;
 }

@@ -24,3 +24,13 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host enqueue {1e3 * (t1 - t0) / N:.3f} ms/step   wall {1e3 * (t2 - t0) / N:.3f} ms/step   (queue drained {1e3 * (t2 - t1):.1f} ms after the last enqueue)")
 print("cpus", len(os.sched_getaffinity(0)))
+# burst from an idle GPU: no back-pressure from a full queue can be in these numbers
+for n in (2, 5, 10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        st.step(x, i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"burst of {n:2d} steps from idle: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, drained {1e3 * (t2 - t1):.2f} ms later")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Timeline of one training step from a rocprofv3 --kernel-trace rocpd database: every kernel dispatch between two consecutive
-lo_adamw launches, with start / end relative to the first one and the queue (stream) it ran on.  Shows which stream finishes the
+gradient-norm finalize launches, with start / end relative to the first one and the queue (stream) it ran on.  Shows which stream finishes the
 backward last, i.e. what the step's critical path is.   python tools/timeline.py <results.db> [step_index_from_end]"""
 import sqlite3, sys
 db = sys.argv[1]
@@ -12,9 +12,8 @@ cols = [r[1] for r in c.execute(f"pragma table_info({kt})")]
 sys.stderr.write(f"table {kt} columns {cols}\n")
 qcol = next((x for x in ("queue_id", "stream_id", "queue", "stream") if x in cols), None)
 rows = c.execute(f"select name, start, end, {qcol or 0} from {kt} order by start").fetchall()
-ad = [i for i, r in enumerate(rows) if "lo_adamw" in r[0]]
-# a pipelined step has two lo_adamw launches: take the first of each pair as the step boundary
-bounds = [ad[i] for i in range(0, len(ad), 2)]
+# one lo_gradnorm_finalize launch per step (the AdamW of a pipelined step is several launches): the step boundary
+bounds = [i for i, r in enumerate(rows) if "lo_gradnorm_finalize" in r[0]]
 lo, hi = bounds[-back - 1], bounds[-back]
 t0 = rows[lo][1]
 for name, s, e, q in rows[lo:hi]:
