@@ -7,7 +7,10 @@ export TMPDIR=/tmp
 O=gpurun_out/prof_refresh
 rm -rf $O && mkdir -p $O
 python3 bench.py --steps 50 --warmup 10 --breakdown > $O/bench.json 2> $O/bench_breakdown.txt
+LO_PROF_LAYERS=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --hybrid-steps 0 --fp8-steps 0 --config2-steps 0 --highend-steps 0 --breakdown > /dev/null 2> $O/bench_per_layer.txt
 python3 tools/hybrid_probe.py > $O/hybrid_breakdown.txt 2>&1
+python3 tools/gnb_det.py 8 > $O/gnb_det.log 2>&1
+python3 tools/host_enqueue_probe.py > $O/host_enqueue.txt 2>&1
 for cfg in "64 8 512" "16 32 128" "8 64 64"; do set -- $cfg; python3 tools/op_bench.py --op attn --B $1 --H $2 --Cin $3 2>&1 | grep attn >> $O/selfattn2d_op_bench.txt; done
 echo "bench + probes done" >&2
 # kernel durations are compared with the side stream switched off in BOTH measurements (the library's HIP-event leg always runs
