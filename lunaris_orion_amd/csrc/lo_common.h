@@ -141,7 +141,8 @@ __device__ __forceinline__ void lo_gn_group_stats(const float* partial, int MT, 
 }
 
 
-const char* lo_prof_geom_name(const char* base, const LoGeom& g);   // per-layer profiler names under LO_PROF_LAYERS
+const char* lo_prof_geom_name(const char* base, const LoGeom& g);
+const char* lo_prof_intern(const char* text);   // stable copy of a formatted name while the profiler is on   // per-layer profiler names under LO_PROF_LAYERS
 
 enum LoConvKind {
   LO_CONV3_S1 = 0,        // Conv2d k3 s1 p1 forward

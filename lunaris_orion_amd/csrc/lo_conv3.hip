@@ -923,7 +923,11 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
   static char name[64];
   snprintf(name, sizeof(name), nw == 8 ? "lo_conv3x3_pp<%d,%dx%d>" : "lo_conv3x3_halo<%d,%dx%d>", bn, th, tw);
   if (xg) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cin;   // the by-product store of the normalised activation
-  LoProfScope _p(xg ? "lo_conv3x3_pp (GroupNorm + Mish on load)" : name, flops, bytes, st);
+  // algorithmic bytes of the FUSED op, as in launch_igemm: the residual gradient it adds and the producing layer's raw conv output
+  // that the fused GroupNorm-backward reduction reads, each the size of the output
+  if (add_src) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cout;
+  if (gb) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cout;
+  LoProfScope _p(xg ? "lo_conv3x3_pp (GroupNorm + Mish on load)" : lo_prof_intern(name), flops, bytes, st);
   static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;   // 0: lock-step 8-wave kernel (A/B knob)
   if (pair) hipLaunchKernelGGL((lo_conv3x3_pp<64, 8, 16, 0, false, false, true>), dim3(tiles), dim3(512), 0, st, a);
   else if (xg && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, 2>), dim3(tiles), dim3(512), 0, st, a);

@@ -53,6 +53,15 @@ const char* lo_prof_geom_name(const char* base, const LoGeom& g) {
   table.push_back(new std::string(text));
   return table.back()->c_str();
 }
+// a stable copy of a launcher's formatted kernel name (the records keep the pointer, a static buffer would be overwritten)
+const char* lo_prof_intern(const char* text) {
+  if (!g_lo_prof_on) return text;
+  static std::vector<std::string*> table;
+  for (std::string* e : table)
+    if (*e == text) return e->c_str();
+  table.push_back(new std::string(text));
+  return table.back()->c_str();
+}
 extern "C" void lo_prof_enable(int on) {
   g_lo_prof_on = on != 0;
   if (on) { g_recs.clear(); g_pool_used = 0; }
