@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 REPS=${REPS:-3}
 for r in $(seq $REPS); do
   for kv in "$@"; do
-    if [ "$kv" = "-" ]; then v=$(python3 bench.py --steps 300 --no-cpu-baseline --hybrid-steps 0 --fp8-steps 0 --prof-steps 0 2>/dev/null)
-    else v=$(env $kv python3 bench.py --steps 300 --no-cpu-baseline --hybrid-steps 0 --fp8-steps 0 --prof-steps 0 2>/dev/null); fi
+    if [ "$kv" = "-" ]; then v=$(python3 bench.py --steps 300 --no-cpu-baseline --hybrid-steps 0 --fp8-steps 0 --config2-steps 0 --highend-steps 0 --prof-steps 0 2>/dev/null)
+    else v=$(env $kv python3 bench.py --steps 300 --no-cpu-baseline --hybrid-steps 0 --fp8-steps 0 --config2-steps 0 --highend-steps 0 --prof-steps 0 2>/dev/null); fi
     echo "$kv $(echo "$v" | python3 -c 'import sys,json; print(round(json.loads(sys.stdin.read())["value"]))')"
   done
 done
