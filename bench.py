@@ -203,6 +203,11 @@ def main():
         elapsed = t.item()
     met = st.metrics()
     assert met["grads_finite"] == 1.0 and np.isfinite(met["recon_loss"]), met
+    # the host's own cost of enqueuing a step: a burst of 5 steps into an EMPTY queue, outside the timed region (host_enqueue_ms
+    # above is taken with ~20 steps already queued, where the runtime's back-pressure, not the host, sets the pace)
+    torch.cuda.synchronize()
+    host_idle_s = run(5) / 5
+    torch.cuda.synchronize()
     dp_info = None
     if dist is not None:
         # what actually ran: ranks of the process group and the device each one drove, bytes handed to the exchange per backward
@@ -314,7 +319,8 @@ def main():
                        "global_batch": world * B, "latent_dim": args.latent,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof,
-            "host_enqueue_ms": 1e3 * host_enqueue_s / args.steps,     # host time per step spent enqueuing (launch-bound when >= ms_per_step)
+            "host_enqueue_ms": 1e3 * host_enqueue_s / args.steps,     # host time per step inside the timed region (includes queue back-pressure)
+            "host_enqueue_ms_idle_queue": 1e3 * host_idle_s,          # the host's own cost: 5 steps enqueued into an empty queue (launch-bound only when THIS nears ms_per_step)
             "final_metrics": {k: met[k] for k in ("recon_loss", "kl_loss", "grad_norm")},
         }
         if world > 1:

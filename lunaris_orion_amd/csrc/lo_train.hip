@@ -240,6 +240,21 @@ __global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* 
 }
 // torch.optim.AdamW (decoupled weight decay, eps outside the bias-corrected sqrt) with the clip coefficient folded in.
 // A non-finite gradient norm skips the update (GradScaler semantics).
+// One element: every multiply-add is written out (no compiler contraction inside), so that each of the unrolled copies below and
+// the scalar tail round identically -- the pipelined optimizer step updates the flat buffer in several launches over sub-ranges
+// and must give the bits of the one-launch form (tests/test_vae_gpu.py::test_pipelined_optimizer_step_equals_the_plain_one).
+__device__ __forceinline__ void lo_adamw_elem(float& p, float g, float& m, float& v, float coef, float decay, float omb1, float beta2,
+                                              float omb2, float bc2_sqrt, float eps, float step_size) {
+#pragma clang fp contract(off)
+  const float gg = g * coef;
+  const float pp = p * decay;                              // decay = 1 - lr * wd
+  const float mm = __builtin_fmaf(gg - m, omb1, m);        // m + (g - m)(1 - beta1)
+  const float v2 = __builtin_fmaf(omb2 * gg, gg, v * beta2);
+  const float denom = sqrtf(v2) / bc2_sqrt + eps;
+  p = __builtin_fmaf(-step_size, mm / denom, pp);
+  m = mm;
+  v = v2;
+}
 __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, size_t n, const float* __restrict__ norm,
                                                        float lr, float beta1, float beta2, float eps, float wd, float bc1,
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
   if (!ok) return;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   size_t stride = (size_t)gridDim.x * 256;
-  const float step_size = lr / bc1;
+  const float step_size = lr / bc1, decay = 1.0f - lr * wd, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
   size_t n4 = n / 4;
   // U groups of four elements per thread and iteration, all 4 * U loads issued before the first use: the launch keeps HBM busy
   // from 256 workgroups (one per CU, 4 of its 32 wave slots): 0.273 ms for the 61 M parameters of the VAE (6.2 TB/s) against
@@ -277,14 +292,9 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
       if (k < n4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float gg = gv[u][j] * coef;
-          float pp = pv[u][j] * (1.0f - lr * wd);
-          float mm = mv[u][j] + (gg - mv[u][j]) * (1.0f - beta1);
-          float v2 = vv[u][j] * beta2 + (1.0f - beta2) * gg * gg;
-          float denom = sqrtf(v2) / bc2_sqrt + eps;
-          pv[u][j] = pp - step_size * (mm / denom);
-          mv[u][j] = mm;
-          vv[u][j] = v2;
+          float pe = pv[u][j], me = mv[u][j], ve = vv[u][j];
+          lo_adamw_elem(pe, gv[u][j], me, ve, coef, decay, omb1, beta2, omb2, bc2_sqrt, eps, step_size);
+          pv[u][j] = pe; mv[u][j] = me; vv[u][j] = ve;
         }
         reinterpret_cast<f32x4*>(p)[k] = pv[u];
         reinterpret_cast<f32x4*>(m)[k] = mv[u];
@@ -295,14 +305,10 @@ __global__ __launch_bounds__(256) void lo_adamw_kernel(float* __restrict__ p, co
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (size_t k = n4 * 4; k < n; ++k) {
-      float gg = g[k] * coef;
-      float pp = p[k] * (1.0f - lr * wd);
-      float mm = m[k] + (gg - m[k]) * (1.0f - beta1);
-      float v2 = v[k] * beta2 + (1.0f - beta2) * gg * gg;
-      p[k] = pp - step_size * (mm / (sqrtf(v2) / bc2_sqrt + eps));
-      m[k] = mm;
-      v[k] = v2;
-      if (cast) cast[k] = (f16)p[k];
+      float pe = p[k], me = m[k], ve = v[k];
+      lo_adamw_elem(pe, g[k], me, ve, coef, decay, omb1, beta2, omb2, bc2_sqrt, eps, step_size);
+      p[k] = pe; m[k] = me; v[k] = ve;
+      if (cast) cast[k] = (f16)pe;
     }
 }
 
