@@ -1092,6 +1092,8 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   int ksteps = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
+  if (a.nsplit == 1 && !add_src && !gb && !ex && !xg && lo_convt4_patch_applies(g))
+    return lo_convt4_patch_run(g, in, wp, bias, out, gn_partial, st);   // last transposed conv of the decoder, patch-resident
   if (a.nsplit == 1 && lo_conv3_tiles_per_image(g, ex != nullptr) > 0 && (!gb || lo_conv3_fuses_gnb(g)))
     return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb, xg);   // fused-tap kernel for 3x3 stride-1
   LO_REQUIRE(!xg, "lo_conv_run: GroupNorm on load is only available in the fused-tap kernel (check lo_conv3_fuses_gnb first)");
@@ -1164,6 +1166,8 @@ int lo_conv_gnb_rows(const LoGeom& g) {
 }
 int lo_conv_mt(const LoGeom& g) {
   int t = lo_conv3_tiles_per_image(g);
+  if (t > 0) return t;
+  t = lo_convt4_patch_tiles_per_image(g);
   if (t > 0) return t;
   return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
 }

@@ -993,3 +993,185 @@ int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, c
   LO_LAUNCH_CHECK("conv3x3_pp_f8");
   return LO_OK;
 }
+
+// =============================================================================================
+// Patch-resident forward of the last transposed convolution (ConvTranspose2d k4 s2 p1, 64 -> 32 channels, 64x64 -> 128x128;
+// lunar_generate.py:187).  As four sub-pixel phases on lo_igemm_nt every input pixel crosses the L2 -> LDS path 16 times
+// (4 phases x 4 taps, 537 MB per launch at batch 64) for 17 GFLOP: 66 us against a 12.6 us HBM floor.  Here a workgroup
+// (8 waves) stages the 18 x 18 halo patch of a 16 x 16 input tile ONCE (41 KB) and runs all 16 (phase, tap) products from
+// it, two passes (output row parity py = 0, 1) with that parity's two phases of packed weights in LDS (32 KB, lo_igemm_nt's
+// own packed layout): 75 KB of LDS, two workgroups per CU.
+//   product: D[co][px] = sum_k W[co][k] X[k][px]  (weights are the A operand), so a lane ends up with 4 consecutive output
+//   channels of one output pixel: 8-byte stores, and -- GroupNorm(8, 32) has 4 channels per group -- exactly one group's
+//   members, so the per-(sample, tile) GroupNorm sums come straight from the accumulators (fp16-rounded values, like the other
+//   conv epilogues), reduced over the 16 pixel lanes by shuffles and over waves through LDS in a fixed order.
+//   LDS: patch rows of 128 B (64 channels), 16-byte chunks XOR-swizzled by lo_swz3(pixel); weight rows of 512 B (4 taps x 64
+//   channels), chunk c of row r stored at c ^ (r & 15): the 16 rows of an A fragment land on 16 distinct 16-byte slots.
+// =============================================================================================
+struct ConvT4PatchArgs {
+  const f16* in;        // [B][H][W][64]
+  const f16* w;         // packed by lo_pack_all for the LO_CONVT4_S2 geometry: [phase][32][4 * 64]
+  const float* bias;    // [32] or null
+  f16* out;             // [B][2H][2W][32]
+  float* gn_partial;    // [B][tiles per image][8][2] or null
+  LoGeom g;
+};
+
+__global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArgs a) {
+  constexpr int TH = 16, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;      // 324 patch pixels
+  constexpr int CIN = 64, COUT = 32, KT = 4 * CIN;                        // K per phase
+  constexpr int PQ = (NPIX + 7) / 8;                                      // LDS-DMA instructions of the patch (8 pixels each)
+  constexpr int PATCH_BYTES = PQ * 1024;
+  constexpr int W_BYTES = 2 * COUT * KT * 2;                              // two phases
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[PATCH_BYTES + W_BYTES];
+  __shared__ float s_red[8][8][2];
+  unsigned char* const s_patch = smem;
+  unsigned char* const s_w = smem + PATCH_BYTES;
+  const LoGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = g.Hin, W = g.Win;
+  const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
+  const int tile_id = lo_xcd_remap3(blockIdx.x, gridDim.x);
+  const int n_img = tile_id / tiles_img, t_img = tile_id - n_img * tiles_img;
+  const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
+  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page3);
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
+
+  // ---- patch: instruction q covers pixels 8q .. 8q+7 (lane = pixel * 8 + physical chunk)
+  for (int q = wave; q < PQ; q += 8) {
+    const int pp = q * 8 + (lane >> 3), pos = lane & 7;
+    const int py = pp / PW, px = pp - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = pp < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const unsigned char* src = ok ? inb + ((size_t)((n_img * H + iy) * W + ix) * CIN + ((pos ^ lo_swz3(pp)) * 8)) * 2 : zpage;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s_patch + q * 1024), 16, 0, 0);
+  }
+  // weights of output-row parity `par`: rows r = pw * 32 + co, 512 B each; instruction q covers rows 2q, 2q+1
+  auto issue_w = [&](int par) __attribute__((always_inline)) {
+    for (int q = wave; q < 2 * COUT / 2; q += 8) {
+      const int r = 2 * q + (lane >> 5), pos = lane & 31;
+      const int pw = r >> 5, co = r & 31;
+      const int p = par * 2 + pw;
+      const unsigned char* src = wb + ((size_t)g.wofs[p] + (size_t)co * KT + ((pos ^ (r & 15)) * 8)) * 2;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s_w + q * 1024), 16, 0, 0);
+    }
+  };
+  issue_w(0);
+
+  const int fr = lane & 15, fq = lane >> 4;
+  float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};   // GroupNorm sums of group nf * 4 + fq over this lane's pixels
+  f32x4 bv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (a.bias) { bv[0] = *reinterpret_cast<const f32x4*>(a.bias + 4 * fq); bv[1] = *reinterpret_cast<const f32x4*>(a.bias + 16 + 4 * fq); }
+
+#pragma unroll 1
+  for (int par = 0; par < 2; ++par) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                         // patch (first pass) and this parity's weights have landed for every wave
+    f32x4 acc[2][2][2];                      // [pw][row of the wave][nf]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i >> 2][(i >> 1) & 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw) {
+      const int p = par * 2 + pw;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int dy = g.dy[p][t], dx = g.dx[p][t];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          f16x8 wf[2], xf[2];
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf) {
+            const int r = pw * 32 + nf * 16 + fr;
+            const int chunk = t * 8 + kk * 4 + fq;
+            wf[nf] = *reinterpret_cast<const f16x8*>(s_w + r * 512 + ((chunk ^ (r & 15)) * 16));
+          }
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int pp = (2 * wave + rr + 1 + dy) * PW + fr + 1 + dx;
+            xf[rr] = *reinterpret_cast<const f16x8*>(s_patch + pp * 128 + (((kk * 4 + fq) ^ lo_swz3(pp)) * 16));
+          }
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+              acc[pw][rr][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nf], xf[rr], acc[pw][rr][nf], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue of this parity: D[co = nf*16 + 4 fq + j][px = fr].  The 16 x 32-pixel x 32-channel output block of the parity
+    //      (32 KB) is staged in the weight buffer -- [row][ox][4 chunks of 8 channels], chunk ^ ((ox >> 1) & 3) -- and leaves in
+    //      16-byte stores along the 2 KB contiguous output rows (the direct 8-byte stores from the accumulators: 41 us per launch)
+    __syncthreads();                         // every wave is done with this parity's weights
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * wave + rr, ox = 2 * fr + pw;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const f32x4 v = acc[pw][rr][nf] + bv[nf];
+          const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          const int chunk = nf * 2 + (fq >> 1);
+          *reinterpret_cast<f16x4*>(s_w + row * 2048 + ox * 64 + ((chunk ^ ((ox >> 1) & 3)) * 16) + (fq & 1) * 8) = h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float x = (float)h[j]; gs[nf] += x; gq[nf] += x * x; }
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i, row = c >> 7, k = c & 127, ox = k >> 2, chunk = k & 3;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(s_w + row * 2048 + ox * 64 + ((chunk ^ ((ox >> 1) & 3)) * 16));
+      const int oy = 2 * (y0 + row) + par;
+      *reinterpret_cast<u32x4*>(a.out + ((size_t)(n_img * 2 * H + oy) * (2 * W) + 2 * x0 + ox) * COUT + chunk * 8) = v;
+    }
+    if (par == 0) {
+      __syncthreads();                       // the staged block has been read
+      issue_w(1);
+    }
+  }
+  if (a.gn_partial) {
+    // over the 16 pixel lanes (fixed shuffle tree), then over the 8 waves (fixed order)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { gs[nf] += __shfl_xor(gs[nf], o, 64); gq[nf] += __shfl_xor(gq[nf], o, 64); }
+    if (fr == 0) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) { s_red[wave][nf * 4 + fq][0] = gs[nf]; s_red[wave][nf * 4 + fq][1] = gq[nf]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const int grp = tid >> 1, which = tid & 1;
+      float tot = 0.f;
+      for (int w8 = 0; w8 < 8; ++w8) tot += s_red[w8][grp][which];
+      a.gn_partial[(((size_t)n_img * tiles_img + t_img) * 8 + grp) * 2 + which] = tot;
+    }
+  }
+}
+
+// ConvTranspose2d k4 s2 p1 forward geometry with 64 -> 32 channels on a map of whole 16 x 16 tiles (LO_CONVT_PATCH=0 switches it off)
+bool lo_convt4_patch_applies(const LoGeom& g) {
+  static const int on = getenv("LO_CONVT_PATCH") ? atoi(getenv("LO_CONVT_PATCH")) : 1;
+  if (!on || g.n_phase != 4 || g.in_stride != 1 || g.out_stride != 2 || g.Cin != 64 || g.Cout != 32) return false;
+  for (int p = 0; p < 4; ++p) if (g.T[p] != 4) return false;
+  return g.Hin % 16 == 0 && g.Win % 16 == 0 && g.Hout == 2 * g.Hin && g.Wout == 2 * g.Win;
+}
+int lo_convt4_patch_tiles_per_image(const LoGeom& g) { return lo_convt4_patch_applies(g) ? (g.Hin / 16) * (g.Win / 16) : 0; }
+
+int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, f16* out, float* gn_partial, hipStream_t st) {
+  LO_REQUIRE(lo_convt4_patch_applies(g), "lo_convt4_patch_run: geometry not supported");
+  ConvT4PatchArgs a{in, wp, bias, out, gn_partial, g};
+  const int tiles = g.B * (g.Hin / 16) * (g.Win / 16);
+  double flops = 0;
+  for (int p = 0; p < 4; ++p) flops += 2.0 * g.B * g.GH * g.GW * (double)g.Cout * g.T[p] * g.Cin;
+  const double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + (double)g.B * g.Hout * g.Wout * g.Cout + 16.0 * g.Cin * g.Cout);
+  LoProfScope _p("lo_convt4_patch_fwd", flops, bytes, st);
+  hipLaunchKernelGGL(lo_convt4_patch_fwd_kernel, dim3(tiles), dim3(512), 0, st, a);
+  LO_LAUNCH_CHECK("convt4_patch_fwd");
+  return LO_OK;
+}
