@@ -1092,6 +1092,8 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   int ksteps = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
+  if (a.nsplit == 1 && !gn_partial && !ex && !xg && lo_conv4s2_patch_applies(g))
+    return lo_conv4s2_patch_run(g, in, wp, bias, add_src, out, st, gb);   // ... and its data gradient
   if (a.nsplit == 1 && !add_src && !gb && !ex && !xg && lo_convt4_patch_applies(g))
     return lo_convt4_patch_run(g, in, wp, bias, out, gn_partial, st);   // last transposed conv of the decoder, patch-resident
   if (a.nsplit == 1 && lo_conv3_tiles_per_image(g, ex != nullptr) > 0 && (!gb || lo_conv3_fuses_gnb(g)))
@@ -1161,6 +1163,7 @@ int lo_conv_bn_rows(const LoGeom& g) {
   return (int)(((size_t)g.B * g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase);
 }
 int lo_conv_gnb_rows(const LoGeom& g) {
+  if (lo_conv4s2_patch_applies(g)) return lo_conv4s2_patch_tiles_per_image(g);
   if (lo_conv3_fuses_gnb(g)) return lo_conv3_tiles_per_image(g, false);
   return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
 }

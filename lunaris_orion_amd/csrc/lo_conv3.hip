@@ -1175,3 +1175,176 @@ int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const flo
   LO_LAUNCH_CHECK("convt4_patch_fwd");
   return LO_OK;
 }
+
+// =============================================================================================
+// Patch-resident data gradient of the same layer: din[n, y, x, :] = sum_{r,s} dv[n, 2y-1+r, 2x-1+s, :] W[:, :, r, s], a 4x4
+// stride-2 convolution of the 32-channel gradient at 128x128 down to 64 channels at 64x64 (LO_CONVT4_S2_DGRAD geometry).  On
+// lo_igemm_nt (128 x 64 x 32 tiles, 16 K steps) it takes 65 us for 17 GFLOP and 168 MB.  Here: 8 x 16 output pixels per
+// workgroup, the 18 x 34-pixel patch of dv staged once (39 KB, 64-byte pixel rows, chunks swizzled by (pixel >> 1) & 3: the
+// stride-2 fragment reads are 2-way conflicted at worst), the packed weights in two passes of 8 taps (32 KB each, rows
+// swizzled as in the forward kernel), weights as the A operand; wave w owns output row w of the tile.  Epilogue staged in LDS
+// for 16-byte stores, with the residual add and the fused GroupNorm-backward reduction of the producing layer (same form and
+// summation order rules as lo_igemm_nt's: sum du and sum du*v per channel, statistics re-read after the loop).
+// =============================================================================================
+struct Conv4S2PatchArgs {
+  const f16* in;        // dv [B][2Ho][2Wo][32]
+  const f16* w;         // packed [64][16 * 32]
+  const float* bias;
+  const f16* add_src;   // [B][Ho][Wo][64] or null
+  f16* out;             // [B][Ho][Wo][64]
+  const f16* gb_v; const float* gb_stats; const float* gb_gamma; const float* gb_beta; float* gb_P1;
+  LoGeom g;
+};
+
+__global__ __launch_bounds__(512) void lo_conv4s2_patch_dgrad_kernel(Conv4S2PatchArgs a) {
+  constexpr int TH = 8, TW = 16, PW = 2 * TW + 2, PH = 2 * TH + 2, NPIX = PH * PW;   // 18 x 34 = 612 patch pixels
+  constexpr int CIN = 32, COUT = 64, KT = 16 * CIN;
+  constexpr int PQ = (NPIX + 15) / 16;                                               // 16 pixels of 64 B per LDS-DMA instruction
+  constexpr int PATCH_BYTES = PQ * 1024;
+  constexpr int W_BYTES = COUT * 8 * CIN * 2;                                        // 8 taps per pass
+  static_assert(PATCH_BYTES >= 512 * 16 * 4, "the reduction scratch of the fused epilogue lives in the patch buffer");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[PATCH_BYTES + W_BYTES];
+  unsigned char* const s_patch = smem;
+  unsigned char* const s_w = smem + PATCH_BYTES;
+  const LoGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Ho = g.Hout, Wo = g.Wout, Hi = g.Hin, Wi = g.Win;
+  const int tiles_x = Wo / TW, tiles_img = tiles_x * (Ho / TH);
+  const int tile_id = lo_xcd_remap3(blockIdx.x, gridDim.x);
+  const int n_img = tile_id / tiles_img, t_img = tile_id - n_img * tiles_img;
+  const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
+  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page3);
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
+  auto pswz = [](int pix) { return (pix >> 1) & 3; };
+
+  for (int q = wave; q < PQ; q += 8) {
+    const int pp = q * 16 + (lane >> 2), pos = lane & 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+    const bool ok = pp < NPIX && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+    const unsigned char* src = ok ? inb + ((size_t)((n_img * Hi + iy) * Wi + ix) * CIN + ((pos ^ pswz(pp)) * 8)) * 2 : zpage;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s_patch + q * 1024), 16, 0, 0);
+  }
+  auto issue_w = [&](int pass) __attribute__((always_inline)) {   // rows n (64) x 512 B; instruction q covers rows 2q, 2q+1
+    for (int q = wave; q < COUT / 2; q += 8) {
+      const int r = 2 * q + (lane >> 5), pos = lane & 31;
+      const unsigned char* src = wb + ((size_t)r * KT + pass * 8 * CIN + ((pos ^ (r & 15)) * 8)) * 2;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s_w + q * 1024), 16, 0, 0);
+    }
+  };
+  issue_w(0);
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+      const int t = pass * 8 + tl;
+      const int pix = (2 * wave + g.dy[0][t] + 1) * PW + 2 * fr + g.dx[0][t] + 1;
+      const f16x8 xf = *reinterpret_cast<const f16x8*>(s_patch + pix * 64 + ((fq ^ pswz(pix)) * 16));
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const int r = nf * 16 + fr;
+        const f16x8 wf = *reinterpret_cast<const f16x8*>(s_w + r * 512 + (((tl * 4 + fq) ^ (r & 15)) * 16));
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[nf], 0, 0, 0);
+      }
+    }
+    __syncthreads();                           // every wave is done with this pass's weights
+    if (pass == 0) issue_w(1);
+  }
+  // ---- epilogue: D[n = nf*16 + 4 fq + j][px = fr] of tile row `wave`; staging [128 px][8 chunks of 8 channels], chunk ^ (px & 7)
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) {
+    f32x4 v = acc[nf];
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + nf * 16 + 4 * fq);
+    const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    const int px = wave * 16 + fr, chunk = nf * 2 + (fq >> 1);
+    *reinterpret_cast<f16x4*>(s_w + px * 128 + ((chunk ^ (px & 7)) * 16) + (fq & 1) * 8) = h;
+  }
+  __syncthreads();
+  const int chunk = tid & 7, slot = tid >> 3;      // this thread's 8 channels and its pixel slot (pixels slot, slot + 64)
+  const int G = COUT >> 3;                         // 8 channels per GroupNorm group: a chunk lies in one group
+  float gsc[8], gsh[8], ga1[8], ga2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
+  if (a.gb_v) {
+    const int gr = (chunk * 8) / G;
+    const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gsc[j] = a.gb_gamma[chunk * 8 + j] * rstd;
+      gsh[j] = a.gb_beta[chunk * 8 + j] - mean * gsc[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int px = slot + 64 * i;
+    f16x8 h = *reinterpret_cast<const f16x8*>(s_w + px * 128 + ((chunk ^ (px & 7)) * 16));
+    const size_t off = ((size_t)(n_img * Ho + y0 + (px >> 4)) * Wo + x0 + (px & 15)) * COUT + chunk * 8;
+    if (a.add_src) {
+      const f16x8 r = *reinterpret_cast<const f16x8*>(a.add_src + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (f16)((float)h[j] + (float)r[j]);
+    }
+    *reinterpret_cast<f16x8*>(a.out + off) = h;
+    if (a.gb_v) {
+      const f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float hv = (float)vv[j];
+        const float du = (float)h[j] * lo_mish_grad(hv * gsc[j] + gsh[j]);
+        ga1[j] += du;
+        ga2[j] += du * hv;
+      }
+    }
+  }
+  if (a.gb_v) {
+    const int gr = (chunk * 8) / G;
+    const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];   // re-read after the loop
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ga2[j] = rstd * (ga2[j] - mean * ga1[j]);
+    float* red = reinterpret_cast<float*>(s_patch);   // [512][16] floats; the patch is no longer read
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j * 2] = ga1[j]; red[tid * 16 + j * 2 + 1] = ga2[j]; }
+    __syncthreads();
+    float* dst = a.gb_P1 + ((size_t)n_img * tiles_img + t_img) * COUT * 2;
+    if (tid < COUT * 2) {
+      const int c = tid >> 1, w = tid & 1, ccx = c >> 3, j = c & 7;
+      float tot = 0.f;
+      for (int r = 0; r < 64; ++r) tot += red[(r * 8 + ccx) * 16 + j * 2 + w];
+      dst[tid] = tot;
+    }
+  }
+}
+
+bool lo_conv4s2_patch_applies(const LoGeom& g) {
+  // measured: 64.6 -> 55.7 us for the launch alone, but the step gets 0.5 % SLOWER (four interleaved pairs): two 73 KB workgroups
+  // per CU leave no LDS for the side stream's weight-gradient kernels that run beside the data gradients.  Opt-in.
+  static const int on = getenv("LO_CONV4S2_PATCH") ? atoi(getenv("LO_CONV4S2_PATCH")) : 0;
+  return on && g.n_phase == 1 && g.T[0] == 16 && g.in_stride == 2 && g.out_stride == 1 && g.Cin == 32 && g.Cout == 64 &&
+         g.Hout % 8 == 0 && g.Wout % 16 == 0 && g.Hin == 2 * g.Hout && g.Win == 2 * g.Wout;
+}
+int lo_conv4s2_patch_tiles_per_image(const LoGeom& g) { return lo_conv4s2_patch_applies(g) ? (g.Hout / 8) * (g.Wout / 16) : 0; }
+
+int lo_conv4s2_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out, hipStream_t st,
+                         const LoGnBwdFuse* gb) {
+  LO_REQUIRE(lo_conv4s2_patch_applies(g), "lo_conv4s2_patch_run: geometry not supported");
+  Conv4S2PatchArgs a{in, wp, bias, add_src, out, gb ? gb->v : nullptr, gb ? gb->stats : nullptr, gb ? gb->gamma : nullptr,
+                     gb ? gb->beta : nullptr, gb ? gb->P1 : nullptr, g};
+  const int tiles = g.B * (g.Hout / 8) * (g.Wout / 16);
+  const double flops = 2.0 * g.B * g.Hout * g.Wout * (double)g.Cout * 16 * g.Cin;
+  const double out_bytes = 2.0 * g.B * g.Hout * g.Wout * g.Cout;
+  const double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + 16.0 * g.Cin * g.Cout) + out_bytes + (add_src ? out_bytes : 0.0) + (gb ? out_bytes : 0.0);
+  LoProfScope _p("lo_conv4s2_patch_dgrad", flops, bytes, st);
+  hipLaunchKernelGGL(lo_conv4s2_patch_dgrad_kernel, dim3(tiles), dim3(512), 0, st, a);
+  LO_LAUNCH_CHECK("conv4s2_patch_dgrad");
+  return LO_OK;
+}

@@ -566,7 +566,7 @@ def test_golden_parity_with_the_fused_tap_kernel_forced_on(gn_on_load):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LO_HALO="3", LO_GN_ON_LOAD=gn_on_load, LO_HALO_PAIR="1")   # + the two-images-per-tile form on the 8x8 stage
+    env = dict(os.environ, LO_HALO="3", LO_GN_ON_LOAD=gn_on_load, LO_HALO_PAIR="1", LO_CONV4S2_PATCH="1")   # + the two-images-per-tile form on the 8x8 stage, the patch-resident 4x4 s2 data gradient
     sel = "test_forward_matches_oracle_and_golden or test_gradients_match_the_golden_samples or test_fused_steps_match_golden_trace or test_run_to_run_bitwise_determinism"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_vae_gpu.py"), "-x", "-q", "-m", "gpu", "-k", sel],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
