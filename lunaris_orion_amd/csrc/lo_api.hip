@@ -56,7 +56,7 @@ extern "C" int lo_conv_forward_f8(int kind, int B, int H, int W, int Cin, int Co
   LO_REQUIRE(in8 && wp8 && wscale && out, "lo_conv_forward_f8: null argument");
   LoGeom g;
   LO_TRY(lo_make_geom(&g, kind, B, H, W, Cin, Cout));
-  if (mt_out) *mt_out = lo_conv_mt(g);
+  if (mt_out) *mt_out = lo_conv_mt_f8(g);
   return lo_conv_run_f8(g, (const uint8_t*)in8, (const uint8_t*)wp8, wscale, bias, (const f16*)add_src, (f16*)out, gn_partial, S(stream));
 }
 // the teacher's 3x3 stride-1 convolution kernel (lo_conv3x3_pp) with its epilogue: bias, optional LeakyReLU(0.2), optional
@@ -411,7 +411,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->n_packjobs8_enc = h->pack_blocks8_enc = 0;
   if (h->fp8_fwd) {
     auto enable = [&](ConvLayer& c, size_t* producer_copy) {
-      if (!lo_conv_f8_applies(c.gf)) return;
+      if (!lo_conv_f8_applies(c.gf) || lo_convt4_patch_applies(c.gf)) return;   // a patch-resident fp16 kernel owns the layer (and its partial-sum rows)
       c.f8 = true;
       c.o_wp8 = ar.take(lo_packed_weight_elems(c.gf));
       c.o_wscale = ar.take((size_t)c.gf.n_phase * c.Cout * 4);

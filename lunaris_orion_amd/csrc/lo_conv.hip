@@ -1167,6 +1167,8 @@ int lo_conv_gnb_rows(const LoGeom& g) {
   if (lo_conv3_fuses_gnb(g)) return lo_conv3_tiles_per_image(g, false);
   return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
 }
+// GroupNorm partial rows per sample written by lo_conv_run_f8 (always lo_igemm_nt's tiles, whatever fp16 kernel owns the geometry)
+int lo_conv_mt_f8(const LoGeom& g) { return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase; }
 int lo_conv_mt(const LoGeom& g) {
   int t = lo_conv3_tiles_per_image(g);
   if (t > 0) return t;

@@ -1017,16 +1017,23 @@ struct ConvT4PatchArgs {
   LoGeom g;
 };
 
+// NCB = Cin / 64 channel blocks (1 or 2: all blocks of the patch stay resident), COUT = 32 or 64.  One weight buffer holds the two
+// phases of a (parity, channel block): 2 * COUT rows of 512 B (4 taps x 64 channels); the accumulators run over the channel blocks.
+template <int NCB, int COUT>
 __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArgs a) {
   constexpr int TH = 16, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;      // 324 patch pixels
-  constexpr int CIN = 64, COUT = 32, KT = 4 * CIN;                        // K per phase
-  constexpr int PQ = (NPIX + 7) / 8;                                      // LDS-DMA instructions of the patch (8 pixels each)
+  constexpr int CIN = 64 * NCB, KT = 4 * CIN;                             // K per phase
+  constexpr int NF = COUT / 16;                                           // 16-channel fragments of the output channels
+  constexpr int PQ = (NPIX + 7) / 8;                                      // LDS-DMA instructions of one patch block (8 pixels each)
   constexpr int PATCH_BYTES = PQ * 1024;
-  constexpr int W_BYTES = 2 * COUT * KT * 2;                              // two phases
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[PATCH_BYTES + W_BYTES];
+  constexpr int W_BYTES = 2 * COUT * 512;                                 // two phases of one channel block
+  constexpr int OCH = COUT / 8;                                           // 16-byte chunks per output pixel
+  static_assert(W_BYTES == 16 * 32 * COUT * 2, "the output block of a parity is staged in the weight buffer");
+  static_assert(NCB * PATCH_BYTES + W_BYTES + 512 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NCB * PATCH_BYTES + W_BYTES];
   __shared__ float s_red[8][8][2];
   unsigned char* const s_patch = smem;
-  unsigned char* const s_w = smem + PATCH_BYTES;
+  unsigned char* const s_w = smem + NCB * PATCH_BYTES;
   const LoGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1039,110 +1046,133 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
   const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
   const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
 
-  // ---- patch: instruction q covers pixels 8q .. 8q+7 (lane = pixel * 8 + physical chunk)
-  for (int q = wave; q < PQ; q += 8) {
-    const int pp = q * 8 + (lane >> 3), pos = lane & 7;
+  // ---- patch: instruction q of block cb covers pixels 8q .. 8q+7 (lane = pixel * 8 + physical chunk)
+  for (int q = wave; q < NCB * PQ; q += 8) {
+    const int cb = q / PQ, ql = q - cb * PQ;
+    const int pp = ql * 8 + (lane >> 3), pos = lane & 7;
     const int py = pp / PW, px = pp - py * PW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
     const bool ok = pp < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    const unsigned char* src = ok ? inb + ((size_t)((n_img * H + iy) * W + ix) * CIN + ((pos ^ lo_swz3(pp)) * 8)) * 2 : zpage;
+    const unsigned char* src = ok ? inb + ((size_t)((n_img * H + iy) * W + ix) * CIN + cb * 64 + ((pos ^ lo_swz3(pp)) * 8)) * 2 : zpage;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(s_patch + q * 1024), 16, 0, 0);
   }
-  // weights of output-row parity `par`: rows r = pw * 32 + co, 512 B each; instruction q covers rows 2q, 2q+1
-  auto issue_w = [&](int par) __attribute__((always_inline)) {
-    for (int q = wave; q < 2 * COUT / 2; q += 8) {
+  // weights of output-row parity `par`, channel block cb: rows r = pw * COUT + co, 512 B each (tap t, 64 channels of the block:
+  // 128-byte pieces of the packed row); instruction q covers rows 2q, 2q+1
+  auto issue_w = [&](int par, int cb) __attribute__((always_inline)) {
+    for (int q = wave; q < COUT; q += 8) {
       const int r = 2 * q + (lane >> 5), pos = lane & 31;
-      const int pw = r >> 5, co = r & 31;
+      const int pw = r / COUT, co = r - pw * COUT;
       const int p = par * 2 + pw;
-      const unsigned char* src = wb + ((size_t)g.wofs[p] + (size_t)co * KT + ((pos ^ (r & 15)) * 8)) * 2;
+      const int c = pos ^ (r & 15), t = c >> 3, c8 = c & 7;
+      const unsigned char* src = wb + ((size_t)g.wofs[p] + (size_t)co * KT + t * CIN + cb * 64 + c8 * 8) * 2;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_w + q * 1024), 16, 0, 0);
     }
   };
-  issue_w(0);
+  issue_w(0, 0);
 
   const int fr = lane & 15, fq = lane >> 4;
-  float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};   // GroupNorm sums of group nf * 4 + fq over this lane's pixels
-  f32x4 bv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if (a.bias) { bv[0] = *reinterpret_cast<const f32x4*>(a.bias + 4 * fq); bv[1] = *reinterpret_cast<const f32x4*>(a.bias + 16 + 4 * fq); }
+  float gs[NF], gq[NF];                     // GroupNorm sums of this lane's 4 channels per fragment over its pixels
+  f32x4 bv[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    gs[nf] = 0.f; gq[nf] = 0.f;
+    bv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv[nf] = *reinterpret_cast<const f32x4*>(a.bias + nf * 16 + 4 * fq);
+  }
 
 #pragma unroll 1
   for (int par = 0; par < 2; ++par) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                         // patch (first pass) and this parity's weights have landed for every wave
-    f32x4 acc[2][2][2];                      // [pw][row of the wave][nf]
+    f32x4 acc[2][2][NF];                     // [pw][row of the wave][nf]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i >> 2][(i >> 1) & 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
-    for (int pw = 0; pw < 2; ++pw) {
-      const int p = par * 2 + pw;
+      for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int dy = g.dy[p][t], dx = g.dx[p][t];
+        for (int nf = 0; nf < NF; ++nf) acc[pw][rr][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cb = 0; cb < NCB; ++cb) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                       // the patch (first pass) and this (parity, block)'s weights have landed for every wave
+      const unsigned char* pb = s_patch + cb * PATCH_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          f16x8 wf[2], xf[2];
+      for (int pw = 0; pw < 2; ++pw) {
+        const int p = par * 2 + pw;
 #pragma unroll
-          for (int nf = 0; nf < 2; ++nf) {
-            const int r = pw * 32 + nf * 16 + fr;
-            const int chunk = t * 8 + kk * 4 + fq;
-            wf[nf] = *reinterpret_cast<const f16x8*>(s_w + r * 512 + ((chunk ^ (r & 15)) * 16));
+        for (int t = 0; t < 4; ++t) {
+          const int dy = g.dy[p][t], dx = g.dx[p][t];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            f16x8 wf[NF], xf[2];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+              const int r = pw * COUT + nf * 16 + fr;
+              const int chunk = t * 8 + kk * 4 + fq;
+              wf[nf] = *reinterpret_cast<const f16x8*>(s_w + r * 512 + ((chunk ^ (r & 15)) * 16));
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+              const int pp = (2 * wave + rr + 1 + dy) * PW + fr + 1 + dx;
+              xf[rr] = *reinterpret_cast<const f16x8*>(pb + pp * 128 + (((kk * 4 + fq) ^ lo_swz3(pp)) * 16));
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+              for (int nf = 0; nf < NF; ++nf)
+                acc[pw][rr][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nf], xf[rr], acc[pw][rr][nf], 0, 0, 0);
           }
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            const int pp = (2 * wave + rr + 1 + dy) * PW + fr + 1 + dx;
-            xf[rr] = *reinterpret_cast<const f16x8*>(s_patch + pp * 128 + (((kk * 4 + fq) ^ lo_swz3(pp)) * 16));
-          }
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf)
-              acc[pw][rr][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nf], xf[rr], acc[pw][rr][nf], 0, 0, 0);
         }
       }
+      __syncthreads();                       // every wave is done with this block's weights
+      if (cb + 1 < NCB) issue_w(par, cb + 1);
     }
-    // ---- epilogue of this parity: D[co = nf*16 + 4 fq + j][px = fr].  The 16 x 32-pixel x 32-channel output block of the parity
-    //      (32 KB) is staged in the weight buffer -- [row][ox][4 chunks of 8 channels], chunk ^ ((ox >> 1) & 3) -- and leaves in
-    //      16-byte stores along the 2 KB contiguous output rows (the direct 8-byte stores from the accumulators: 41 us per launch)
-    __syncthreads();                         // every wave is done with this parity's weights
+    // ---- epilogue of this parity: D[co = nf*16 + 4 fq + j][px = fr].  The 16 x 32-pixel x COUT output block of the parity is
+    //      staged in the weight buffer -- [row][ox][OCH chunks of 8 channels], chunk ^ ((ox >> 1) & (OCH - 1)) -- and leaves in
+    //      16-byte stores along the contiguous output rows (direct 8-byte stores from the accumulators: 41 instead of 36 us)
 #pragma unroll
     for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         const int row = 2 * wave + rr, ox = 2 * fr + pw;
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
           const f32x4 v = acc[pw][rr][nf] + bv[nf];
           const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
           const int chunk = nf * 2 + (fq >> 1);
-          *reinterpret_cast<f16x4*>(s_w + row * 2048 + ox * 64 + ((chunk ^ ((ox >> 1) & 3)) * 16) + (fq & 1) * 8) = h;
+          *reinterpret_cast<f16x4*>(s_w + (row * 32 + ox) * (COUT * 2) + ((chunk ^ ((ox >> 1) & (OCH - 1))) * 16) + (fq & 1) * 8) = h;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const float x = (float)h[j]; gs[nf] += x; gq[nf] += x * x; }
         }
       }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i, row = c >> 7, k = c & 127, ox = k >> 2, chunk = k & 3;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(s_w + row * 2048 + ox * 64 + ((chunk ^ ((ox >> 1) & 3)) * 16));
+    for (int i = 0; i < OCH; ++i) {
+      const int c = tid + 512 * i, chunk = c % OCH, k = c / OCH, ox = k & 31, row = k >> 5;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(s_w + (row * 32 + ox) * (COUT * 2) + ((chunk ^ ((ox >> 1) & (OCH - 1))) * 16));
       const int oy = 2 * (y0 + row) + par;
       *reinterpret_cast<u32x4*>(a.out + ((size_t)(n_img * 2 * H + oy) * (2 * W) + 2 * x0 + ox) * COUT + chunk * 8) = v;
     }
     if (par == 0) {
       __syncthreads();                       // the staged block has been read
-      issue_w(1);
+      issue_w(1, 0);
     }
   }
   if (a.gn_partial) {
-    // over the 16 pixel lanes (fixed shuffle tree), then over the 8 waves (fixed order)
+    // over the 16 pixel lanes (fixed shuffle tree; COUT = 64: a group is 8 channels = the lane pairs fq, fq ^ 1), then over the
+    // 8 waves (fixed order).  Group of (nf, fq): COUT = 32 -> nf * 4 + fq, COUT = 64 -> nf * 2 + (fq >> 1)
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
+    for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { gs[nf] += __shfl_xor(gs[nf], o, 64); gq[nf] += __shfl_xor(gq[nf], o, 64); }
-    if (fr == 0) {
+      if (COUT == 64) { gs[nf] += __shfl_xor(gs[nf], 16, 64); gq[nf] += __shfl_xor(gq[nf], 16, 64); }
+    }
+    if (fr == 0 && (COUT == 32 || (fq & 1) == 0)) {
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf) { s_red[wave][nf * 4 + fq][0] = gs[nf]; s_red[wave][nf * 4 + fq][1] = gq[nf]; }
+      for (int nf = 0; nf < NF; ++nf) {
+        const int grp = COUT == 32 ? nf * 4 + fq : nf * 2 + (fq >> 1);
+        s_red[wave][grp][0] = gs[nf]; s_red[wave][grp][1] = gq[nf];
+      }
     }
     __syncthreads();
     if (tid < 16) {
@@ -1154,10 +1184,12 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
   }
 }
 
-// ConvTranspose2d k4 s2 p1 forward geometry with 64 -> 32 channels on a map of whole 16 x 16 tiles (LO_CONVT_PATCH=0 switches it off)
+// ConvTranspose2d k4 s2 p1 forward geometry with 64 -> 32 or 128 -> 64 channels on a map of whole 16 x 16 tiles (LO_CONVT_PATCH=0: off)
 bool lo_convt4_patch_applies(const LoGeom& g) {
   static const int on = getenv("LO_CONVT_PATCH") ? atoi(getenv("LO_CONVT_PATCH")) : 1;
-  if (!on || g.n_phase != 4 || g.in_stride != 1 || g.out_stride != 2 || g.Cin != 64 || g.Cout != 32) return false;
+  static const int wide = getenv("LO_CONVT_PATCH_WIDE") ? atoi(getenv("LO_CONVT_PATCH_WIDE")) : 1;   // the 128 -> 64 layer as well
+  if (!on || g.n_phase != 4 || g.in_stride != 1 || g.out_stride != 2) return false;
+  if (!((g.Cin == 64 && g.Cout == 32) || (wide && g.Cin == 128 && g.Cout == 64))) return false;
   for (int p = 0; p < 4; ++p) if (g.T[p] != 4) return false;
   return g.Hin % 16 == 0 && g.Win % 16 == 0 && g.Hout == 2 * g.Hin && g.Wout == 2 * g.Win;
 }
@@ -1171,7 +1203,8 @@ int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const flo
   for (int p = 0; p < 4; ++p) flops += 2.0 * g.B * g.GH * g.GW * (double)g.Cout * g.T[p] * g.Cin;
   const double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + (double)g.B * g.Hout * g.Wout * g.Cout + 16.0 * g.Cin * g.Cout);
   LoProfScope _p("lo_convt4_patch_fwd", flops, bytes, st);
-  hipLaunchKernelGGL(lo_convt4_patch_fwd_kernel, dim3(tiles), dim3(512), 0, st, a);
+  if (g.Cin == 64) hipLaunchKernelGGL((lo_convt4_patch_fwd_kernel<1, 32>), dim3(tiles), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((lo_convt4_patch_fwd_kernel<2, 64>), dim3(tiles), dim3(512), 0, st, a);
   LO_LAUNCH_CHECK("convt4_patch_fwd");
   return LO_OK;
 }

@@ -28,6 +28,7 @@ int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStrea
 int lo_pack_f8_one(const LoGeom& g, const f16* wp, uint8_t* w8, float* wscale, hipStream_t st);
 int lo_quantize_f8(const f16* x, uint8_t* x8, size_t n, hipStream_t st);
 int lo_conv_tile_m(const LoGeom& g);
+int lo_conv_mt_f8(const LoGeom& g);   // the same for lo_conv_run_f8
 int lo_conv_mt(const LoGeom& g);   // GroupNorm partial rows per sample the conv epilogue writes for this geometry
 int lo_conv3_tiles_per_image(const LoGeom& g, bool need_bn = false);
 int lo_conv_bn_rows(const LoGeom& g);
