@@ -349,8 +349,9 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   LO_TRY(lo_make_geom(&h->g_head_d, LO_LINEAR, B, 1, 1, 2 * L, 32768));   // dxflat = dml Wt^T  (Wt = W^T packed)
   LO_TRY(lo_make_geom(&h->g_dfc, LO_LINEAR, B, 1, 1, L, 32768));          // y = z Wd^T
   LO_TRY(lo_make_geom(&h->g_dfc_d, LO_LINEAR, B, 1, 1, 32768, L));        // dz = dy Wdt^T
-  h->head_split = 32;
-  h->dfcd_split = 32;
+  h->head_split = getenv("LO_HEAD_SPLIT") ? atoi(getenv("LO_HEAD_SPLIT")) : 32;     // K splits of the two K = 32768 Linear GEMMs (tuning knobs)
+  h->dfcd_split = getenv("LO_DFCD_SPLIT") ? atoi(getenv("LO_DFCD_SPLIT")) : 32;
+  LO_REQUIRE(h->head_split >= 1 && h->head_split <= 128 && h->dfcd_split >= 1 && h->dfcd_split <= 128, "LO_HEAD_SPLIT / LO_DFCD_SPLIT out of range");
   h->o_wp_head = ar.take((size_t)2 * L * 32768 * 2);
   h->o_wp_head_t = ar.take((size_t)2 * L * 32768 * 2);
   h->o_wp_dfc = ar.take((size_t)L * 32768 * 2);
