@@ -79,6 +79,113 @@ __global__ __launch_bounds__(256) void lo_first_conv_fwd_kernel(const float* __r
   }
 }
 
+// The same forward on MFMA, ROWS output rows per workgroup.  D[co][px] = sum_k W[co][k] X[k][px], k = (ci, r, s) < 27 padded to 32:
+//   A (weights) : fp32 split into fp16 hi + lo halves, the four 16-channel fragments of a lane built once per workgroup
+//   B (im2col)  : lane (px, k group g) gathers its eight k values from the staged fp32 input rows (eight ds_read_b32 at per-lane
+//                 constant offsets + 2 * px), split into hi + lo as well; three MFMAs per 16 x 16 block (hi*hi + lo*hi + hi*lo)
+//                 keep fp32-input accuracy (the direct kernel above spends 27 broadcast LDS reads x 16 FMAs per thread: 36 us)
+//   wave w owns pixels 16 w .. 16 w + 15 of every row; a lane ends with 4 consecutive channels of one pixel per fragment; the row
+//   is staged in LDS for 16-byte stores; GroupNorm sums (groups of 8 channels = the lane pairs g, g ^ 1) by shuffles, then waves
+//   in fixed order.  The 2 ROWS + 1 input rows of the workgroup are staged once.
+template <int ROWS>
+__global__ __launch_bounds__(256) void lo_first_conv_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, f16* __restrict__ v,
+                                                                     float* __restrict__ gn_partial) {
+  constexpr int NR = 2 * ROWS + 1, RP = FC_W + 2;
+  __shared__ float xs[3][NR][RP];
+  __shared__ float ws[FC_CO * 27];
+  __shared__ __attribute__((aligned(16))) unsigned char so[FC_OW * 144];   // one output row: 64 px x (128 B + 16 B pad)
+  __shared__ float red[4][8][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int oy0 = blockIdx.x * ROWS, n = blockIdx.y;
+  for (int i = tid; i < 3 * NR * RP; i += 256) {
+    const int col = i % RP, r = (i / RP) % NR, ci = i / (RP * NR);
+    const int iy = 2 * oy0 - 1 + r, ix = col - 1;
+    float val = 0.f;
+    if ((unsigned)iy < 128u && (unsigned)ix < 128u) val = x[(((size_t)n * 3 + ci) * 128 + iy) * 128 + ix];
+    xs[ci][r][col] = val;
+  }
+  for (int i = tid; i < FC_CO * 27; i += 256) ws[i] = w[i];
+  __syncthreads();
+  // A fragments: lane (row co = 16 mf + m, k = 8 g .. 8 g + 7)
+  f16x8 wh[4], wl[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * g + j;
+      const float wv = k < 27 ? ws[(16 * mf + m) * 27 + k] : 0.f;
+      const f16 hi = (f16)wv;
+      wh[mf][j] = hi;
+      wl[mf][j] = (f16)(wv - (float)hi);
+    }
+  // B gather offsets of this lane's eight k (floats relative to xs[0][0][2 * px]); k >= 27 reads a valid address and is zeroed
+  int koff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * g + j, kk = k < 27 ? k : 0;
+    const int ci = kk / 9, r = (kk % 9) / 3, sx = kk % 3;
+    koff[j] = (ci * NR + r) * RP + sx;
+  }
+  f32x4 bv[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) bv[mf] = *reinterpret_cast<const f32x4*>(bias + 16 * mf + 4 * g);
+  const float* xbase = &xs[0][0][0];
+  const int px = 16 * wave + m;
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS; ++rr) {
+    f16x8 xh, xl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xv = xbase[koff[j] + 2 * rr * RP + 2 * px];
+      if (8 * g + j >= 27) xv = 0.f;
+      const f16 hi = (f16)xv;
+      xh[j] = hi;
+      xl[j] = (f16)(xv - (float)hi);
+    }
+    float gs[4], gq[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+      f32x4 acc = bv[mf];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mf], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mf], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mf], xl, acc, 0, 0, 0);
+      // D[co = 16 mf + 4 g + j][px]
+      const f16x4 h = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+      *reinterpret_cast<f16x4*>(so + px * 144 + (16 * mf + 4 * g) * 2) = h;
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float a = (float)h[j]; s_ += a; q_ += a * a; }
+      gs[mf] = s_; gq[mf] = q_;
+    }
+    // GroupNorm sums of this row: over the 16 pixel lanes, then the lane pair (g, g ^ 1) = one group of 8 channels
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) { gs[mf] += __shfl_xor(gs[mf], o, 64); gq[mf] += __shfl_xor(gq[mf], o, 64); }
+    }
+    if (m == 0 && (g & 1) == 0) {
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) { red[wave][2 * mf + (g >> 1)][0] = gs[mf]; red[wave][2 * mf + (g >> 1)][1] = gq[mf]; }
+    }
+    __syncthreads();
+    const int oy = oy0 + rr;
+    {   // 64 px x 8 chunks of 16 B = 512 chunks: two per thread, 128 contiguous bytes per pixel
+      f16* dst = v + (((size_t)n * 64 + oy) * 64) * FC_CO;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, p = c >> 3, ch = c & 7;
+        *reinterpret_cast<u32x4*>(dst + p * FC_CO + ch * 8) = *reinterpret_cast<const u32x4*>(so + p * 144 + ch * 16);
+      }
+    }
+    if (tid < 16) {
+      const int grp = tid >> 1, which = tid & 1;
+      gn_partial[(((size_t)n * 64 + oy) * 8 + grp) * 2 + which] = red[0][grp][which] + red[1][grp][which] + red[2][grp][which] + red[3][grp][which];
+    }
+    __syncthreads();                       // `so` and `red` are rewritten by the next row
+  }
+}
+
 // first conv weight gradient: partial[wg][co*27 + k] over 8 output rows per workgroup
 __global__ __launch_bounds__(256) void lo_first_conv_wgrad_kernel(const float* __restrict__ x, const f16* __restrict__ dv,
                                                                   float* __restrict__ partial) {
@@ -527,7 +634,9 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
 // =============================================================================================
 int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v, float* gn_partial, int B, hipStream_t st) {
   LoProfScope _p("lo_first_conv_fwd", 2.0 * B * 4096 * 64 * 27, (double)B * (3 * 16384 * 4 + 4096 * 64 * 2), st);
-  hipLaunchKernelGGL(lo_first_conv_fwd_kernel, dim3(64, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
+  static const bool direct = getenv("LO_FIRST_FWD_DIRECT") && atoi(getenv("LO_FIRST_FWD_DIRECT")) != 0;   // A/B knob: the fp32 VALU kernel
+  if (direct) hipLaunchKernelGGL(lo_first_conv_fwd_kernel, dim3(64, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
+  else hipLaunchKernelGGL((lo_first_conv_fwd_mfma_kernel<4>), dim3(16, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
   LO_LAUNCH_CHECK("first_conv_fwd");
   return LO_OK;
 }
