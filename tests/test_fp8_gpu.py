@@ -208,7 +208,8 @@ def test_fp8_mode_loss_parity_at_batch64_latent512():
     d_rec = abs(first["fp8"]["recon_loss"] - first["fp16"]["recon_loss"])
     d_kl = abs(first["fp8"]["kl_loss"] - first["fp16"]["kl_loss"])
     print("B=64 / L=512 fp8 vs fp16: d recon_loss", d_rec, "d kl_loss", d_kl, first)
-    assert 0 < d_rec <= 3e-3 and d_kl <= 3e-3
+    # the mode must be active (some loss moves: the two recon losses can coincide in fp32, they differ by a few 1e-6) and close
+    assert d_rec + d_kl > 0 and d_rec <= 3e-3 and d_kl <= 3e-3
     assert abs(first["fp8"]["grad_norm"] - first["fp16"]["grad_norm"]) <= 2e-2 * first["fp16"]["grad_norm"]
 
 
