@@ -24,3 +24,13 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"hybrid: host enqueue {1e3 * (t1 - t0) / N:.3f} ms/step   wall {1e3 * (t2 - t0) / N:.3f} ms/step")
+# burst from an idle GPU: the host's own cost of enqueuing a hybrid step (no queue back-pressure in these numbers)
+for n in (1, 2, 4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        hs.step(x, i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"burst of {n} hybrid steps from idle: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, drained {1e3 * (t2 - t1):.2f} ms later")
