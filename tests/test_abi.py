@@ -72,3 +72,19 @@ def test_module_surface_matches_reference_contract():
     assert sum(p.numel() for p in m.parameters()) == 60_978_563      # SURVEY §6, latent 512
     assert all(p.dtype == torch.float32 for p in m.parameters())
     assert len(list(m.buffers())) == 0
+
+
+def test_every_environment_knob_is_documented():
+    """Every LO_* variable the library or the Python host code reads appears in the knob table of tools/README.md (the A/B
+    switches are part of what DESIGN.md's measurements refer to; an undocumented one is a measurement nobody can repeat)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    knobs = set()
+    for f in glob.glob(os.path.join(root, "lunaris_orion_amd", "csrc", "*")):
+        knobs |= set(re.findall(r'getenv\("(LO_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(root, "lunaris_orion_amd", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "train_hybrid.py")]:
+        knobs |= set(re.findall(r'environ\.get\("(LO_[A-Z0-9_]+)"', open(f).read()))
+    doc = open(os.path.join(root, "tools", "README.md")).read()
+    missing = sorted(k for k in knobs if k not in doc)
+    assert len(knobs) > 30 and not missing, missing
