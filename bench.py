@@ -131,7 +131,8 @@ def main():
     ap.add_argument("--min-warmup", type=int, default=MIN_WARMUP_STEPS, help="warm-up steps are topped up to this count (tests pass 0)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank control flow on one GPU)")
-    ap.add_argument("--dp-fp16", action="store_true", help="fp16 wire format for the gradient all-reduce (off: fp32)")
+    ap.add_argument("--dp-fp16", action="store_true", help="fp16 wire format for the gradient exchange (the default with --dp-exchange direct)")
+    ap.add_argument("--dp-fp32", action="store_true", help="fp32 wire format (the default with --dp-exchange allreduce)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--precision", choices=["fp16", "fp8"], default="fp16",
                     help="operand format of the forward convs in the timed leg (fp8 = BASELINE config 5 mode; the headline number is fp16)")
@@ -139,9 +140,11 @@ def main():
     ap.add_argument("--hybrid-steps", type=int, default=20, help="extra leg (N=1): full hybrid VAE+teacher steps, BASELINE config 3 (0 = skip)")
     ap.add_argument("--highend-steps", type=int, default=3, help="extra leg (N=1): full hybrid steps of the README High-End recipe, --feature_dim 512 (0 = skip)")
     ap.add_argument("--config2-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps at batch 32 / latent 256, BASELINE config 2 (0 = skip)")
-    ap.add_argument("--dp-exchange", choices=["allreduce", "direct"], default="allreduce",
-                    help="N > 1: gradient exchange = RCCL all-reduce (default) or the direct all-to-all reduce-scatter + all-gather over all xGMI links")
+    ap.add_argument("--dp-exchange", choices=["allreduce", "direct"], default=os.environ.get("LO_DP_EXCHANGE", "direct"),
+                    help="N > 1: gradient exchange = the direct all-to-all reduce-scatter + all-gather over all xGMI links (default; fp16 wire) "
+                         "or one RCCL all-reduce per hand-over range (fp32 wire); every range is exchanged on a communication stream behind the backward")
     args = ap.parse_args()
+    args.dp_fp16 = (args.dp_fp16 or args.dp_exchange == "direct") and not args.dp_fp32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -216,9 +219,9 @@ def main():
         dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
                                      "exposed_ms": grad_sync.exposed_ms_per_step()})
         dp_info = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": [d["device"] for d in ids],
-                   "device_names": sorted(set(d["name"] for d in ids)), "exchange": args.dp_exchange,
+                   "device_names": sorted(set(d["name"] for d in ids)), "exchange": grad_sync.mode_used or args.dp_exchange,
                    "wire": "fp16" if args.dp_fp16 else "fp32", "bytes_per_phase": grad_sync.bytes_per_phase(),
-                   "exchange_exposed_ms": max(d["exposed_ms"] for d in ids)}
+                   "exchange_exposed_ms": max((d["exposed_ms"] for d in ids if d["exposed_ms"] is not None), default=None)}
 
     out = None
     if rank == 0:
@@ -288,6 +291,49 @@ def main():
             others.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                            "ms_per_step": ms / max(args.prof_steps, 1), "launches_per_step": n / max(args.prof_steps, 1)})
         roof["by_kernel"] = others
+        # ---- the graded region (BASELINE north_star / SURVEY 8d): the encoder conv stack = its 12 convolutions x {forward, data
+        # gradient, weight gradient (+ slab reduce)}, 8 649.18 MFLOP per image and step.  Same HIP-event method, second pass with
+        # per-layer record names (lo_prof_enable(2)); kernels run one after the other on the launch stream while profiling, so this
+        # is the sum of their own durations.  Encoder layers are kind 0 (3x3 s1) / kind 1 (3x3 s2); the first conv has its own kernels.
+        if args.prof_steps > 0:
+            import re
+            saved_sync, st.grad_sync = st.grad_sync, None
+            _lib.lib.lo_prof_enable(2)
+            run(args.prof_steps)
+            torch.cuda.synchronize()
+            lrows = collect_profile(_lib.lib)
+            _lib.lib.lo_prof_enable(0)
+            st.grad_sync = saved_sync
+            pat = re.compile(r"^(fwd|dgrad L\d+|wgrad L\d+) kind[01] ")
+            parts = {"forward": 0.0, "data_gradient": 0.0, "weight_gradient": 0.0}
+            n_launch = 0
+            for k, r in lrows.items():
+                which = None
+                if pat.match(k):
+                    which = "forward" if k.startswith("fwd") else ("data_gradient" if k.startswith("dgrad") else "weight_gradient")
+                elif k.startswith("lo_first_conv_fwd"):
+                    which = "forward"
+                elif k.startswith("lo_first_conv_wgrad"):
+                    which = "weight_gradient"
+                if which:
+                    parts[which] += r[0] / args.prof_steps
+                    n_launch += r[1]
+            enc_ms = sum(parts.values())
+            enc_flops = 8649.18e6 * B
+            if enc_ms > 0:
+                roof["encoder_conv_stack"] = {"flops": enc_flops, "ms": enc_ms, "tflops": enc_flops / (enc_ms * 1e-3) / 1e12,
+                                              "frac": enc_flops / (enc_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, "peak": PEAK_MFMA_F16_TFLOPS,
+                                              "ms_by_pass": parts, "launches_per_step": n_launch / args.prof_steps,
+                                              "note": "12 encoder convs x {fwd, dgrad, wgrad + slab reduce}; HIP events per launch, serial on the launch stream; "
+                                                      "GroupNorm / Mish passes not included (fused epilogues are)"}
+            if args.breakdown:
+                for k, r in sorted(lrows.items(), key=lambda kv: -kv[1][0]):
+                    floor_ms = 1e3 * max(r[2] / (PEAK_MFMA_F16_TFLOPS * 1e12), r[3] / (PEAK_HBM_GBS * 1e9))
+                    sys.stderr.write(f"[layer] {k:52s} {r[0] / args.prof_steps:9.4f} ms/step  n={r[1] // args.prof_steps:3d}  "
+                                     f"{(r[2] / (r[0] * 1e-3) / 1e12 if r[0] > 0 else 0):8.1f} TFLOP/s  "
+                                     f"{(r[3] / (r[0] * 1e-3) / 1e9 if r[0] > 0 else 0):8.1f} GB/s  "
+                                     f"floor {floor_ms / args.prof_steps:7.4f} ms ({(floor_ms / r[0] if r[0] > 0 else 0):4.2f} of floor)\n")
+                sys.stderr.write(f"[layer] sum of kernel time {sum(r[0] for r in lrows.values()) / args.prof_steps:.4f} ms/step\n")
         if args.breakdown:
             # floor = the larger of flops / MFMA peak and algorithmic bytes / HBM peak for the launches of the row; "of floor" is how
             # close the measured time comes to it (LO_PROF_LAYERS=1 splits the conv rows per layer geometry)
@@ -423,6 +469,10 @@ def main():
                                            "traffic": None, "kernel": "lo_conv3x3_pp (teacher 3x3 convs 128->128 at 128x128)",
                                            "launches_per_step": c_n / prof_steps, "avg_launch_ms": c_ms / max(c_n, 1),
                                            "share_of_kernel_time": c_ms / tot, "kernel_ms_per_step": tot / prof_steps}
+                        # the teacher's conv stack as a region (the counterpart of roofline.encoder_conv_stack): every 3x3 convolution of
+                        # both teacher forwards of the step, algorithmic FLOPs of the launches that ran
+                        leg["roofline"]["teacher_conv_stack"] = {"flops": c_fl / prof_steps, "ms": c_ms / prof_steps, "tflops": ach,
+                                                                 "frac": ach / PEAK_MFMA_F16_TFLOPS, "launches_per_step": c_n / prof_steps}
                 leg["first_step"] = {k: first[k] for k in ("recon_loss", "kl_loss", "quality_scores", "teacher_loss", "baseline", "grad_norm")}
                 del hs, teacher, vae_m
                 torch.cuda.empty_cache()

@@ -28,7 +28,9 @@ const char* lo_last_error(void);
 int lo_version(void);
 
 /* Per-launch timing with HIP events recorded on the launch stream (used by bench.py's roofline leg).  Enable, run,
- * synchronise the stream, then read record i: kernel name, elapsed ms, algorithmic FLOPs and bytes of that launch. */
+ * synchronise the stream, then read record i: kernel name, elapsed ms, algorithmic FLOPs and bytes of that launch.
+ * on = 1: records carry the kernel name; on = 2: conv / GroupNorm launches of the VAE step are named per layer
+ * ("fwd kind<k> HxW Cin->Cout", "dgrad L<n> ...", "wgrad L<n> ..."), which is how bench.py sums the encoder conv stack. */
 void lo_prof_enable(int on);
 int lo_prof_count(void);
 int lo_prof_get(int i, char* name, int name_cap, double* ms, double* flops, double* bytes);
@@ -167,6 +169,24 @@ int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, co
                    float* recon, float* mu, float* logvar, const float* target, void* stream);
 /* decoder only, without skip connections: LunarisCoreVAE.sample (lunar_generate.py:278-291).  z fp32 [B,L]. */
 int lo_vae_decode(LoVae* h, const float* z, const float* flat_params, void* ws, float* recon, void* stream);
+/* The two halves of that forward as the reference's sub-modules expose them (lunar_generate.py:273-275 calls them in turn;
+ * callers may too).  Encoder.forward (:127-153): mu, logvar [B,L] and the skip list [B,64,64,64], [B,128,32,32], [B,256,16,16]
+ * (fp32 NCHW; NULL = not wanted).  Decoder.forward(z, skips) (:194-229): n_skips = len(skips) in 0..3 with the reference's
+ * guards (skips[2] is added after up1 when len >= 3, skips[1] after up2 when len >= 2, skips[0] after up3 when len >= 1). */
+int lo_vae_encode(LoVae* h, const float* x, const float* flat_params, void* ws, float* mu, float* logvar, float* skip0, float* skip1,
+                  float* skip2, void* stream);
+int lo_vae_decode_skips(LoVae* h, const float* z, int n_skips, const float* skip0, const float* skip1, const float* skip2,
+                        const float* flat_params, void* ws, float* recon, void* stream);
+/* Their backward passes (autograd of the same lines).  lo_vae_decoder_backward follows lo_vae_decode_skips (or lo_vae_forward):
+ * drecon [B,3,128,128] -> dz [B,L], the gradients of the skip maps (fp32 NCHW, NULL = not wanted) and the decoder's parameter
+ * gradients (decoder.fc.weight to the end of flat_grads; nothing before it is written except the alignment gaps).
+ * lo_vae_encoder_backward follows lo_vae_encode (or lo_vae_forward): upstream gradients of mu / logvar [B,L] and of the skip maps
+ * (NULL = zero) -> the encoder's parameter gradients ([0, decoder.fc.weight) of flat_grads).  All gradients leave un-scaled. */
+int lo_vae_decoder_backward(LoVae* h, const float* flat_params, void* ws, const float* recon, const float* drecon, float loss_scale,
+                            float* dz, float* dskip0, float* dskip1, float* dskip2, float* flat_grads, void* stream);
+int lo_vae_encoder_backward(LoVae* h, const float* x, const float* flat_params, void* ws, const float* gmu, const float* glv,
+                            const float* gskip0, const float* gskip1, const float* gskip2, float loss_scale, float* flat_grads,
+                            void* stream);
 /* reduce the loss partial sums of the last forward; losses_dev[4] = recon_loss, kl_loss, vae_loss, pg_loss.
  * vae_loss = (recon_weight*recon + kl_weight*kl - mean_advantage*recon)/accum  (train_hybrid.py:886-889,895).
  * adv_dev (device scalar) overrides mean_advantage when not NULL.  Also prepares the gradient seeds for
@@ -229,6 +249,17 @@ int lo_dropout_mask(uint64_t drop_seed, int site, float dropout_p, size_t n, uin
 int lo_teacher_grad_range(const LoTeacher* h, size_t* begin_elem, size_t* end_elem);
 int lo_teacher_heads_backward(LoTeacher* h, const float* flat_state, void* ws, const float* expert_weights, float coef,
                               float* rows, float* flat_grads, void* stream);
+/* The same backward for arbitrary upstream gradients, i.e. what autograd needs to make quality_scores / expert_weights
+ * differentiable outputs of LunarMoETeacher.forward (the reference calls teacher_loss.backward() on them,
+ * train_hybrid.py:891-904; lunar_evaluator.py:417,431-432,455-462): d_quality [B][4] / d_weights [B][E] (either may be NULL =
+ * zero).  The head inputs of the forward being differentiated are passed explicitly — lo_teacher_heads_saved says where
+ * lo_teacher_forward left them inside the workspace (byte offsets and element counts of pooled extractor features [B][128],
+ * pooled expert features [E][B][F], pre-weighting quality logits [B][E][4]), so a caller may copy them and run this backward
+ * after later forward calls — together with that call's dropout_p (0 in eval mode) and drop_seed. */
+int lo_teacher_heads_saved(const LoTeacher* h, size_t* byte_offsets3, size_t* elems3);
+int lo_teacher_heads_backward_ex(LoTeacher* h, const float* flat_state, const float* pooled_f, const float* pooled_e,
+                                 const float* raw_q, const float* expert_weights, const float* d_quality, const float* d_weights,
+                                 float dropout_p, uint64_t drop_seed, float* rows, float* flat_grads, void* stream);
 /* reward / baseline / advantage bookkeeping of _process_batch (train_hybrid.py:870-892) on the device; state2 =
  * {baseline, initialised}; out7 = quality_loss, semantic_reward, quality_reward, baseline, advantage, teacher_loss,
  * mean(quality_scores); adv_dev = mean advantage (input of lo_vae_loss). */
@@ -250,6 +281,14 @@ int lo_vae_phase1_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_ele
  * gradient bytes; its range below is complete afterwards), then phase 4 (stages 3..1; [0, stage-4 begin) complete).  Phase 2
  * = 3 + 4 in one call. */
 int lo_vae_stage4_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_elem);
+
+/* ---- data-parallel gradient exchange helpers (lunaris_orion_amd/parallel.py; the reference has no distributed code) ---------
+ * One streaming pass each around the RCCL calls of the direct (all-to-all reduce-scatter + all-gather) exchange:
+ * wire[i] = fp16(g[i] * scale);  share[i] = mean over the `world` received chunks recv[r * chunk + i] (fp32 accumulation, ranks in
+ * order; fp16 or fp32 elements);  g[i] = float(wire[i]) * inv_scale. */
+int lo_dp_pack_f16(const float* g, void* wire, size_t n, float scale, void* stream);
+int lo_dp_unpack_f16(const void* wire, float* g, size_t n, float inv_scale, void* stream);
+int lo_dp_sum_shares(const void* recv, void* share, int world, size_t chunk, int is_f16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,8 @@ SIGNATURES = {
     "lo_dropout_mask": (i32, [u64, i32, flt, sz, vp, vp]),
     "lo_teacher_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lo_teacher_heads_backward": (i32, [vp, f32p, vp, f32p, flt, f32p, f32p, vp]),
+    "lo_teacher_heads_saved": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lo_teacher_heads_backward_ex": (i32, [vp, f32p, f32p, f32p, f32p, f32p, f32p, f32p, flt, u64, f32p, f32p, vp]),
     "lo_hybrid_reward": (i32, [f32p, f32p, i32, flt, flt, flt, flt, flt, f32p, f32p, f32p, vp]),
     "lo_vae_create": (i32, [i32, i32, C.POINTER(C.c_void_p)]),
     "lo_vae_create_ex": (i32, [i32, i32, C.c_uint, C.POINTER(C.c_void_p)]),
@@ -86,12 +88,19 @@ SIGNATURES = {
     "lo_vae_pack": (i32, [vp, f32p, vp, vp]),
     "lo_vae_forward": (i32, [vp, f32p, f32p, u64, f32p, vp, f32p, f32p, f32p, f32p, vp]),
     "lo_vae_decode": (i32, [vp, f32p, f32p, vp, f32p, vp]),
+    "lo_vae_encode": (i32, [vp, f32p, f32p, vp, f32p, f32p, f32p, f32p, f32p, vp]),
+    "lo_vae_decode_skips": (i32, [vp, f32p, i32, f32p, f32p, f32p, f32p, vp, f32p, vp]),
+    "lo_vae_decoder_backward": (i32, [vp, f32p, vp, f32p, f32p, flt, f32p, f32p, f32p, f32p, f32p, vp]),
+    "lo_vae_encoder_backward": (i32, [vp, f32p, f32p, vp, f32p, f32p, f32p, f32p, f32p, flt, f32p, vp]),
     "lo_vae_loss": (i32, [vp, vp, flt, flt, flt, f32p, flt, flt, f32p, vp]),
     "lo_vae_backward": (i32, [vp, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),
     "lo_vae_backward_phase": (i32, [vp, i32, f32p, f32p, vp, f32p, f32p, i32, f32p, f32p, f32p, flt, f32p, vp]),
     "lo_vae_linear_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lo_vae_phase1_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lo_vae_debug_tensor": (i32, [vp, i32, i32, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "lo_dp_pack_f16": (i32, [f32p, vp, sz, flt, vp]),
+    "lo_dp_unpack_f16": (i32, [vp, f32p, sz, flt, vp]),
+    "lo_dp_sum_shares": (i32, [vp, vp, i32, sz, i32, vp]),
     "lo_vae_stage4_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 

@@ -158,6 +158,20 @@ extern "C" int lo_selfattn2d_backward(const float* x, const float* wq, const flo
   return lo_selfattn2d_bwd(x, wq, wk, wv, gamma, q, k, v, dy, scratch, dx, dwq, dbq, dwk, dbk, dwv, dbv, dgamma, B, C, N, S(stream));
 }
 
+// data-parallel gradient exchange helpers (see lo_train.hip)
+extern "C" int lo_dp_pack_f16(const float* g, void* wire, size_t n, float scale, void* stream) {
+  LO_REQUIRE(g && wire, "lo_dp_pack_f16: null argument");
+  return lo_dp_pack_f16_run(g, (f16*)wire, n, scale, S(stream));
+}
+extern "C" int lo_dp_unpack_f16(const void* wire, float* g, size_t n, float inv_scale, void* stream) {
+  LO_REQUIRE(g && wire, "lo_dp_unpack_f16: null argument");
+  return lo_dp_unpack_f16_run((const f16*)wire, g, n, inv_scale, S(stream));
+}
+extern "C" int lo_dp_sum_shares(const void* recv, void* share, int world, size_t chunk, int is_f16, void* stream) {
+  LO_REQUIRE(recv && share && world >= 1, "lo_dp_sum_shares: bad argument");
+  return lo_dp_sum_shares_run(recv, share, world, chunk, is_f16, 1.0f / (float)world, S(stream));
+}
+
 // =============================================================================================
 // VAE executor
 // =============================================================================================
@@ -203,6 +217,7 @@ struct LoVae {
   ConvLayer enc[4][3];
   ConvLayer dec[4];
   size_t o_eout[4];          // ResBlock outputs (stage outputs)
+  size_t o_skipin[3];        // skip feature maps handed to Decoder.forward from outside (lo_vae_decode_skips), fp16 NHWC
   // latent
   LoGeom g_head, g_head_d, g_dfc, g_dfc_d;
   int head_split, dfcd_split;
@@ -220,6 +235,8 @@ struct LoVae {
   size_t ws_bytes;
   int idx_fc_mu_w, idx_fc_mu_b, idx_fc_lv_w, idx_fc_lv_b, idx_dfc_w, idx_dfc_b, idx_final_w, idx_final_b;
   bool forward_done, loss_done;
+  bool enc_done, dec_done;   // activations of an encoder / decoder forward are in the workspace (split module calls)
+  int dec_skips;             // how many skip maps the last decoder forward added (3 inside lo_vae_forward)
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
   hipEvent_t ev_dv[2], ev_join, ev_pre;
@@ -286,7 +303,8 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   LO_REQUIRE(L >= 64 && L % 64 == 0 && L <= 4096, "lo_vae_create: latent_dim %d must be a multiple of 64", L);
   LoVae* h = new LoVae();
   h->B = B; h->L = L;
-  h->forward_done = h->loss_done = false;
+  h->forward_done = h->loss_done = h->enc_done = h->dec_done = false;
+  h->dec_skips = 0;
   // ---- parameter table in state_dict order (lunar_generate.py:91-125, 162-192)
   std::vector<size_t> numel;
   const int ench[5] = {3, 64, 128, 256, 512};
@@ -344,6 +362,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     LO_TRY(setup_conv_layer(h->dec[s], LO_CONVT4_S2, B, Hs, Hs, dech[s], dech[s + 1], dec_first + 4 * s, ar, false));
     Hs *= 2;
   }
+  for (int k = 0; k < 3; ++k) h->o_skipin[k] = ar.take((size_t)B * (64 >> k) * (64 >> k) * (64 << k) * 2);
   // latent
   LO_TRY(lo_make_geom(&h->g_head, LO_LINEAR, B, 1, 1, 32768, 2 * L));     // [mu|logvar] = xflat W^T
   LO_TRY(lo_make_geom(&h->g_head_d, LO_LINEAR, B, 1, 1, 2 * L, 32768));   // dxflat = dml Wt^T  (Wt = W^T packed)
@@ -767,7 +786,7 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
                    hipStream_t st, size_t o_in8 = 0, size_t o_y8 = 0, ConvLayer* xprod = nullptr, bool defer_gn = false) {
   static char ftag[64][64];
   static int fcount = 0;
-  if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
+  if (g_lo_prof_on && g_lo_prof_layers) {
     char* tg = ftag[fcount++ & 63];
     snprintf(tg, 64, "fwd kind%d %dx%d %d->%d", c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
     g_lo_prof_tag = tg;
@@ -793,7 +812,8 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
 
 // decoder (lunar_generate.py:194-229) from the latent z (fp16, in the workspace); use_skips=false is the `skips=[]`
 // call of LunarisCoreVAE.sample (:278-291)
-static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* ws, float* recon, const float* target,
+// skips[k] (fp16 NHWC, k = 0: 64 x 64 x 64, 1: 32 x 32 x 128, 2: 16 x 16 x 256) is added after up(3-k); NULL = not added
+static int vae_decoder_forward(LoVae* h, const f16* const skips[3], const float* P, void* ws, float* recon, const float* target,
                                hipStream_t st) {
   const int B = h->B;
   LO_TRY(vae_wait_level(h, st, 4));
@@ -804,19 +824,35 @@ static int vae_decoder_forward(LoVae* h, bool use_skips, const float* P, void* w
   size_t cur8 = h->o_h08;
   for (int s = 0; s < 4; ++s) {
     ConvLayer& c = h->dec[s];
-    const f16* skip = (use_skips && s < 3) ? WSP(f16, h->o_eout[2 - s]) : nullptr;
+    const f16* skip = s < 3 ? skips[2 - s] : nullptr;
     LO_TRY(conv_gn(h, c, cur, skip, WSP(f16, c.o_a), skip ? 1 : 0, P, ws, st, cur8, c.o_a8));
     cur = WSP(f16, c.o_a);
     cur8 = c.o_a8;
   }
+  h->dec_done = true;
+  h->dec_skips = (skips[0] ? 1 : 0) + (skips[1] ? 1 : 0) + (skips[2] ? 1 : 0);
   return lo_final_conv_fwd(cur, PRM(h->idx_final_w), PRM(h->idx_final_b), target, recon, target ? WSP(float, h->o_msep) : nullptr,
                            B, st);
 }
+
+static int vae_encoder_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* P, void* ws, float* mu,
+                               float* logvar, hipStream_t st);
 
 extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* P, void* ws,
                               float* recon, float* mu, float* logvar, const float* target, void* stream) {
   LO_REQUIRE(h && x && P && ws && recon && mu && logvar, "lo_vae_forward: null argument");
   hipStream_t st = S(stream);
+  LO_TRY(vae_encoder_forward(h, x, eps, seed, P, ws, mu, logvar, st));
+  const f16* skips[3] = {WSP(f16, h->o_eout[0]), WSP(f16, h->o_eout[1]), WSP(f16, h->o_eout[2])};
+  LO_TRY(vae_decoder_forward(h, skips, P, ws, recon, target, st));
+  h->forward_done = true;
+  h->loss_done = false;
+  return LO_OK;
+}
+
+// encoder + heads + reparameterisation (lunar_generate.py:127-153, 259-261): stage outputs in o_eout, mu / logvar / z / eps / KL partials
+static int vae_encoder_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* P, void* ws, float* mu,
+                               float* logvar, hipStream_t st) {
   const int B = h->B, L = h->L;
   // ---- encoder (lunar_generate.py:127-153)
   const f16* cur = nullptr;
@@ -857,9 +893,39 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
   LO_REQUIRE(h->p_off[h->idx_fc_lv_b] == h->p_off[h->idx_fc_mu_b] + (size_t)L, "flat layout: head biases not adjacent");
   LO_TRY(lo_head_reduce(WSP(float, h->o_slab_head), PRM(h->idx_fc_mu_b), eps, seed, WSP(float, h->o_mu), WSP(float, h->o_lv),
                         WSP(f16, h->o_z), WSP(float, h->o_eps), WSP(float, h->o_klp), B, L, h->head_split, st, mu, logvar));
-  LO_TRY(vae_decoder_forward(h, true, P, ws, recon, target, st));
-  h->forward_done = true;
-  h->loss_done = false;
+  h->enc_done = true;
+  return LO_OK;
+}
+
+// Encoder.forward (lunar_generate.py:127-153) on its own: mu, logvar and the skip list as fp32 NCHW tensors (NULL = not wanted)
+extern "C" int lo_vae_encode(LoVae* h, const float* x, const float* P, void* ws, float* mu, float* logvar, float* skip0, float* skip1,
+                             float* skip2, void* stream) {
+  LO_REQUIRE(h && x && P && ws && mu && logvar, "lo_vae_encode: null argument");
+  hipStream_t st = S(stream);
+  LO_TRY(vae_encoder_forward(h, x, nullptr, 0, P, ws, mu, logvar, st));     // the z it leaves in the workspace is not used
+  float* sk[3] = {skip0, skip1, skip2};
+  for (int k = 0; k < 3; ++k)
+    if (sk[k]) LO_TRY(lo_nhwc_f16_to_nchw_f32(WSP(f16, h->o_eout[k]), sk[k], h->B, (64 >> k) * (64 >> k), 64 << k, 1.0f, st));
+  h->forward_done = false;   // a fused backward needs a whole lo_vae_forward
+  return LO_OK;
+}
+
+// Decoder.forward(z, skips) (lunar_generate.py:194-229).  n_skips = len(skips): the reference adds skips[2] after up1 when
+// len >= 3, skips[1] after up2 when len >= 2, skips[0] after up3 when len >= 1.  skip maps: fp32 NCHW.
+extern "C" int lo_vae_decode_skips(LoVae* h, const float* z, int n_skips, const float* skip0, const float* skip1, const float* skip2,
+                                   const float* P, void* ws, float* recon, void* stream) {
+  LO_REQUIRE(h && z && P && ws && recon && n_skips >= 0 && n_skips <= 3, "lo_vae_decode_skips: bad argument");
+  const float* sk[3] = {skip0, skip1, skip2};
+  for (int k = 0; k < n_skips; ++k) LO_REQUIRE(sk[k], "lo_vae_decode_skips: skip %d is NULL but n_skips = %d", k, n_skips);
+  hipStream_t st = S(stream);
+  LO_TRY(lo_cast_f32_f16(z, WSP(f16, h->o_z), (size_t)h->B * h->L, st));
+  const f16* skips[3] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < n_skips; ++k) {
+    LO_TRY(lo_nchw_f32_to_nhwc_f16(sk[k], WSP(f16, h->o_skipin[k]), h->B, (64 >> k) * (64 >> k), 64 << k, 1.0f, st));
+    skips[k] = WSP(f16, h->o_skipin[k]);
+  }
+  LO_TRY(vae_decoder_forward(h, skips, P, ws, recon, nullptr, st));
+  h->forward_done = false;
   return LO_OK;
 }
 
@@ -867,8 +933,9 @@ extern "C" int lo_vae_decode(LoVae* h, const float* z, const float* P, void* ws,
   LO_REQUIRE(h && z && P && ws && recon, "lo_vae_decode: null argument");
   hipStream_t st = S(stream);
   LO_TRY(lo_cast_f32_f16(z, WSP(f16, h->o_z), (size_t)h->B * h->L, st));
-  LO_TRY(vae_decoder_forward(h, false, P, ws, recon, nullptr, st));
-  h->forward_done = false;   // activations no longer belong to a full forward: a backward must not follow
+  const f16* skips[3] = {nullptr, nullptr, nullptr};
+  LO_TRY(vae_decoder_forward(h, skips, P, ws, recon, nullptr, st));
+  h->forward_done = false;   // activations no longer belong to a full forward: a fused backward must not follow
   return LO_OK;
 }
 
@@ -905,7 +972,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
     LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
   } else {
     static char wtag[32][64];
-    if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
+    if (g_lo_prof_on && g_lo_prof_layers) {
       snprintf(wtag[k & 31], 64, "wgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
       g_lo_prof_tag = wtag[k & 31];
     }
@@ -922,7 +989,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       gbp = &gb;
     }
     static char dtag[32][64];
-    if (g_lo_prof_on && getenv("LO_PROF_LAYERS")) {
+    if (g_lo_prof_on && g_lo_prof_layers) {
       snprintf(dtag[k & 31], 64, "dgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gd.Cin, c.gd.Cout);
       g_lo_prof_tag = dtag[k & 31];
     }
@@ -933,9 +1000,12 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   return LO_OK;
 }
 
+// phase 5 / 6 = Decoder / Encoder backward on their own (the module boundary: lo_vae_decoder_backward / lo_vae_encoder_backward);
+// the feature-map gradients cross as fp32 NCHW tensors
+struct LoSplitBwd { float* dz; float* dskip[3]; const float* gskip[3]; };
 static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon, const float* target,
                              int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
-                             float* G, void* stream);
+                             float* G, void* stream, const LoSplitBwd* sp = nullptr);
 
 extern "C" int lo_vae_backward(LoVae* h, const float* x, const float* P, void* ws, const float* recon, const float* target,
                                int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
@@ -1018,9 +1088,12 @@ static int vae_zero_gaps(LoVae* h, float* G, hipStream_t st) {
 
 static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P, void* ws, const float* recon, const float* target,
                              int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
-                             float* G, void* stream) {
-  LO_REQUIRE(h && x && P && ws && recon && G, "lo_vae_backward: null argument");
-  if (!h->forward_done) { lo_set_error("lo_vae_backward: forward has not run"); return LO_ERR_STATE; }
+                             float* G, void* stream, const LoSplitBwd* sp) {
+  LO_REQUIRE(h && P && ws && G && (phase == 5 || x) && (phase == 6 || recon), "lo_vae_backward: null argument");
+  if (phase == 5 ? !h->dec_done : (phase == 6 ? !h->enc_done : !h->forward_done)) {
+    lo_set_error("lo_vae_backward: the forward this backward belongs to has not run");
+    return LO_ERR_STATE;
+  }
   if (fused && (!h->loss_done || !target)) { lo_set_error("lo_vae_backward: fused mode needs lo_vae_loss and a target"); return LO_ERR_STATE; }
   LO_REQUIRE(loss_scale > 0.f, "lo_vae_backward: loss_scale must be positive");
   hipStream_t st = S(stream);
@@ -1031,9 +1104,11 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   f16* Gb = WSP(f16, h->o_G[1]);
   f16* Gc = WSP(f16, h->o_G[2]);
   f16* Gd = WSP(f16, h->o_G[3]);
-  if (phase == 0 || phase == 1) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
-  h->bwd_layer = 0;
-  for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) h->enc[s][k].np1 = 0; h->dec[s].np1 = 0; }
+  if (phase == 0 || phase == 1 || phase == 5 || phase == 6) {
+    h->bwd_layer = 0;
+    for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) h->enc[s][k].np1 = 0; h->dec[s].np1 = 0; }
+  }
+  if (phase == 0 || phase == 1 || phase == 5) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
   // padding elements of the flat gradient buffer are zero afterwards; every other element is overwritten (never accumulated
   // into) by exactly one gradient kernel
   LO_TRY(vae_zero_gaps(h, G, st));
@@ -1065,7 +1140,19 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gb, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, st));
   LO_TRY(lo_conv_run(h->g_dfc_d, Gb, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
                      h->dfcd_split, st));
-  LO_TRY(lo_splitk_reduce(WSP(float, h->o_slab_dz), nullptr, nullptr, WSP(f16, h->o_dz), B, L, h->dfcd_split, st));
+  LO_TRY(lo_splitk_reduce(WSP(float, h->o_slab_dz), nullptr, phase == 5 ? sp->dz : nullptr, WSP(f16, h->o_dz), B, L, h->dfcd_split, st));
+  if (phase == 5) {
+    // Decoder.forward's backward ends here: dz and the skip-map gradients leave un-scaled as fp32 (the gradient of skips[k] is
+    // the gradient of the sum it was added into, which the data gradient of the next transposed conv has left in skipg[k])
+    LO_TRY(lo_scale_f32(sp->dz, (size_t)B * L, inv, st));
+    for (int k = 0; k < 3; ++k)
+      if (sp->dskip[k]) LO_TRY(lo_nhwc_f16_to_nchw_f32(WSP(f16, h->o_skipg[k]), sp->dskip[k], B, (64 >> k) * (64 >> k), 64 << k, inv, st));
+    if (h->overlap && !g_lo_prof_on) {
+      LO_HIP(hipEventRecord(h->ev_join, h->side));
+      LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+    return vae_gn_finalize(h, 0u, true, G, ws, inv, st);
+  }
   // ---- latent: KL + reparameterisation backward (train_hybrid.py:862; lunar_generate.py:259-261)
   LO_TRY(lo_latent_bwd(WSP(f16, h->o_dz), WSP(float, h->o_mu), WSP(float, h->o_lv), WSP(float, h->o_eps),
                        fused ? WSP(float, h->o_coefs) : nullptr, fused ? nullptr : gmu, fused ? nullptr : glv, loss_scale,
@@ -1076,6 +1163,22 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
   LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
   }                   // ---------------- end of part A
+  if (phase == 6) {
+    // Encoder.forward's backward on its own: upstream gradients of mu / logvar and of the three skip maps (fp32 NCHW; NULL = zero)
+    LO_TRY(vae_zero_gaps(h, G, st));
+    for (int k = 0; k < 3; ++k) {
+      const size_t n = (size_t)B * (64 >> k) * (64 >> k) * (64 << k);
+      if (sp->gskip[k]) LO_TRY(lo_nchw_f32_to_nhwc_f16(sp->gskip[k], WSP(f16, h->o_skipg[k]), B, (64 >> k) * (64 >> k), 64 << k, loss_scale, st));
+      else LO_HIP(hipMemsetAsync(WSP(f16, h->o_skipg[k]), 0, n * 2, st));
+    }
+    LO_HIP(hipMemsetAsync(WSP(f16, h->o_dz), 0, (size_t)B * L * 2, st));      // no decoder behind the latent: dz = 0
+    LO_TRY(lo_latent_bwd(WSP(f16, h->o_dz), WSP(float, h->o_mu), WSP(float, h->o_lv), WSP(float, h->o_eps), nullptr, gmu, glv, loss_scale,
+                         WSP(f16, h->o_dml), B, L, st));
+    LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, st));
+    LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, st));
+    LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
+    LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));
+  }
   if (phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on) {
     // everything from fc_mu.weight on is final once the decoder's side-stream weight gradients are: order the early
     // sum of squares after both streams' part A and let it run on the side stream beside the encoder backward
@@ -1094,7 +1197,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     }
     return vae_gn_finalize(h, 0u, true, G, ws, inv, st);
   }
-  // ---- encoder stages 4..1 (phase 3: stage 4 only; phase 4: the rest)
+  // ---- encoder stages 4..1 (phase 3: stage 4 only; phase 4: the rest; phase 6: all of them)
   const int s_hi = phase == 4 ? 2 : 3, s_lo = phase == 3 ? 3 : 0;
   for (int s = s_hi; s >= s_lo; --s) {
     ConvLayer& c0 = h->enc[s][0];
@@ -1123,4 +1226,22 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   const bool early_norm = phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on;   // decoder layers finalized above
   LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0 && !early_norm, G, ws, inv, st));
   return LO_OK;
+}
+
+// Backward of lo_vae_decode_skips (Decoder.forward, lunar_generate.py:194-229): drecon [B,3,128,128] -> dz [B,L], the gradients
+// of the skip maps that were added (fp32 NCHW, NULL = not wanted) and the decoder's parameter gradients (decoder.fc.weight to
+// the end of flat_grads; the encoder range is not written).
+extern "C" int lo_vae_decoder_backward(LoVae* h, const float* P, void* ws, const float* recon, const float* drecon, float loss_scale,
+                                       float* dz, float* dskip0, float* dskip1, float* dskip2, float* G, void* stream) {
+  LO_REQUIRE(h && drecon && dz, "lo_vae_decoder_backward: null argument");
+  LoSplitBwd sp{dz, {dskip0, dskip1, dskip2}, {nullptr, nullptr, nullptr}};
+  return vae_backward_impl(h, 5, nullptr, P, ws, recon, nullptr, 0, drecon, nullptr, nullptr, loss_scale, G, stream, &sp);
+}
+// Backward of lo_vae_encode (Encoder.forward, lunar_generate.py:127-153): upstream gradients of mu, logvar [B,L] and of the skip
+// maps (fp32 NCHW; any of them may be NULL = zero) -> the encoder's parameter gradients ([0, decoder.fc.weight) of flat_grads).
+extern "C" int lo_vae_encoder_backward(LoVae* h, const float* x, const float* P, void* ws, const float* gmu, const float* glv,
+                                       const float* gskip0, const float* gskip1, const float* gskip2, float loss_scale, float* G,
+                                       void* stream) {
+  LoSplitBwd sp{nullptr, {nullptr, nullptr, nullptr}, {gskip0, gskip1, gskip2}};
+  return vae_backward_impl(h, 6, x, P, ws, nullptr, nullptr, 0, nullptr, gmu, glv, loss_scale, G, stream, &sp);
 }

@@ -51,6 +51,7 @@ int lo_check_hip(hipError_t e, const char* what);
 // one predictable branch per launcher.
 // ---------------------------------------------------------------------------------------------
 extern bool g_lo_prof_on;
+extern bool g_lo_prof_layers;
 extern const char* g_lo_prof_tag;   // when set, replaces the name of the records opened while it is set (per-call-site breakdowns)
 void lo_prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void lo_prof_end(hipStream_t st);

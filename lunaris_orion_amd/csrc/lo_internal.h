@@ -75,6 +75,8 @@ int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float
 int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st);
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
 int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st, uint8_t* dst8 = nullptr);
+int lo_nhwc_f16_to_nchw_f32(const f16* src, float* dst, int B, int HW, int C, float scale, hipStream_t st);   // module-boundary forms
+int lo_nchw_f32_to_nhwc_f16(const float* src, f16* dst, int B, int HW, int C, float scale, hipStream_t st);
 
 // lo_edge.hip
 int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v, float* gn_partial, int B, hipStream_t st);
@@ -97,6 +99,10 @@ int lo_latent_bwd(const f16* dz, const float* mu, const float* logvar, const flo
                   const float* gmu, const float* glv, float gscale, f16* dml, int B, int L, hipStream_t st);
 int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream_t st);
 int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st);
+int lo_scale_f32(float* x, size_t n, float scale, hipStream_t st);
+int lo_dp_pack_f16_run(const float* g, f16* wire, size_t n, float scale, hipStream_t st);     // data-parallel exchange helpers
+int lo_dp_unpack_f16_run(const f16* wire, float* g, size_t n, float inv_scale, hipStream_t st);
+int lo_dp_sum_shares_run(const void* recv, void* share, int world, size_t chunk, int is_f16, float inv_world, hipStream_t st);
 int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st);
 int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st);
 int lo_sumsq_range(const float* g, size_t begin, size_t end, float* partial, hipStream_t st);   // -> partial[512 .. 1024)

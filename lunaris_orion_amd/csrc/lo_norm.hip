@@ -442,8 +442,7 @@ __global__ __launch_bounds__(256) void lo_transpose_tile_kernel(const f16* __res
 // ---------------------------------------------------------------------------------------------
 // profiler name of a launch: the kernel name, or "<kernel> C<channels> HW<pixels> m<mode>" under LO_PROF_LAYERS
 static const char* gn_layer_name(const char* base, int C, int HW, int mode) {
-  static const bool per_layer = getenv("LO_PROF_LAYERS") != nullptr;
-  if (!per_layer || !g_lo_prof_on) return base;
+  if (!g_lo_prof_layers || !g_lo_prof_on) return base;
   struct Entry { const char* base; int C, HW, mode; char text[56]; };
   static Entry table[96];             // one stable string per distinct (kernel, shape, mode): the profiler keeps the pointer
   static int used = 0;
@@ -532,5 +531,34 @@ int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStrea
   LoProfScope _p("lo_layout_transpose", 0, 4.0 * B * HW * C, st);
   hipLaunchKernelGGL(lo_transpose_tile_kernel, dim3(HW / 64, C / 64, B), dim3(256), 0, st, src, dst, dst8, C, HW);
   LO_LAUNCH_CHECK("nchw_to_nhwc");
+  return LO_OK;
+}
+
+// Boundary forms of the same per-sample transpose [R][Cc] -> [Cc][R] with a type change and a scale (off the step's hot path):
+// TI / TO = f16 or float.  Used where feature maps cross the nn.Module boundary as fp32 NCHW tensors (Encoder.forward's skip list,
+// Decoder.forward's skips argument: lunar_generate.py:139-145, 211-222) while the library keeps fp16 NHWC.  R % 64 == 0, Cc % 64 == 0.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void lo_transpose_convert_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int R, int Cc, float scale) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const TI* s = src + (size_t)n * R * Cc;
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) tile[tr + 4 * p][tc] = (float)s[(size_t)(r0 + tr + 4 * p) * Cc + c0 + tc] * scale;
+  __syncthreads();
+  TO* d = dst + (size_t)n * R * Cc;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) d[(size_t)(c0 + tr + 4 * p) * R + r0 + tc] = (TO)tile[tc][tr + 4 * p];
+}
+int lo_nhwc_f16_to_nchw_f32(const f16* src, float* dst, int B, int HW, int C, float scale, hipStream_t st) {
+  LO_REQUIRE(HW % 64 == 0 && C % 64 == 0, "lo_nhwc_f16_to_nchw_f32: HW=%d, C=%d must be multiples of 64", HW, C);
+  hipLaunchKernelGGL((lo_transpose_convert_kernel<f16, float>), dim3(C / 64, HW / 64, B), dim3(256), 0, st, src, dst, HW, C, scale);
+  LO_LAUNCH_CHECK("nhwc_f16_to_nchw_f32");
+  return LO_OK;
+}
+int lo_nchw_f32_to_nhwc_f16(const float* src, f16* dst, int B, int HW, int C, float scale, hipStream_t st) {
+  LO_REQUIRE(HW % 64 == 0 && C % 64 == 0, "lo_nchw_f32_to_nhwc_f16: HW=%d, C=%d must be multiples of 64", HW, C);
+  hipLaunchKernelGGL((lo_transpose_convert_kernel<float, f16>), dim3(HW / 64, C / 64, B), dim3(256), 0, st, src, dst, C, HW, scale);
+  LO_LAUNCH_CHECK("nchw_f32_to_nhwc_f16");
   return LO_OK;
 }

@@ -1031,6 +1031,8 @@ struct HeadsBwdArgs {
   size_t o_g_w1, o_g_b1, o_g_w2, o_g_b2;            // offsets inside a row
   size_t o_q[8][6];                                 // ln_w, ln_b, w1, b1, w2, b2
   float scale;                                      // -(quality_weight/accum) / (B*4)
+  const float* dq_up;                               // [B][4] upstream gradient of quality_scores (NULL: the constant `scale`)
+  const float* dw_up;                               // [B][E] upstream gradient of expert_weights (NULL: none)
   int B, E, I, F;
   uint32_t thr; float inv_keep;                     // the forward's dropout (same call seed): gate and quality-head hidden layers
   LoDropSite ds_gate, ds_q[8];
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
     float t = 0.f;
     for (int e = 0; e < a.E; ++e) t += a.raw_q[((size_t)n * a.E + e) * 4 + tid] * wts[e];
     float y = 1.f / (1.f + __expf(-t));
-    float dwq = a.scale * y * (1.f - y);
+    float dwq = (a.dq_up ? a.dq_up[n * 4 + tid] : a.scale) * y * (1.f - y);
     for (int e = 0; e < a.E; ++e) dq[e][tid] = dwq * wts[e];
     scratch[tid] = dwq;
   }
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
   if (tid < a.E) {
     float t = 0.f;
     for (int j = 0; j < 4; ++j) t += scratch[j] * a.raw_q[((size_t)n * a.E + tid) * 4 + j];
-    dw[tid] = t;
+    dw[tid] = a.dw_up ? t + a.dw_up[n * a.E + tid] : t;
   }
   __syncthreads();
   if (tid < a.E) {
@@ -1770,16 +1772,24 @@ extern "C" int lo_teacher_grad_range(const LoTeacher* h, size_t* begin, size_t* 
   return LO_OK;
 }
 // rows: B * (end - begin) floats of scratch.  grads: flat gradient buffer of the teacher state layout (only [begin,end) is
-// written).  coef = quality_weight / accum.  Must follow lo_teacher_forward on the evaluated batch (uses its pooled features).
-extern "C" int lo_teacher_heads_backward(LoTeacher* h, const float* P, void* ws, const float* expert_weights, float coef,
-                                         float* rows, float* grads, void* stream) {
-  LO_REQUIRE(h && P && ws && expert_weights && rows && grads, "lo_teacher_heads_backward: null argument");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// written).  The general form takes the upstream gradients of quality_scores [B][4] / expert_weights [B][E] (either may be
+// NULL) and the head inputs of the forward call it differentiates (pooled features, pre-weighting logits, dropout stream), so
+// that it may follow any number of later forward calls; lo_teacher_heads_saved says where lo_teacher_forward leaves them.
+extern "C" int lo_teacher_heads_saved(const LoTeacher* h, size_t* byte_offsets3, size_t* elems3) {
+  LO_REQUIRE(h && byte_offsets3 && elems3, "lo_teacher_heads_saved: null argument");
+  byte_offsets3[0] = h->o_pool_f; elems3[0] = (size_t)h->B * 128;
+  byte_offsets3[1] = h->o_pool_e; elems3[1] = (size_t)h->E * h->B * h->F;
+  byte_offsets3[2] = h->o_rawq;   elems3[2] = (size_t)h->B * h->E * 4;
+  return LO_OK;
+}
+static int t_heads_backward(LoTeacher* h, const float* P, const float* pooled_f, const float* pooled_e, const float* raw_q,
+                            const float* expert_weights, const float* dq_up, const float* dw_up, float coef, float drop_p,
+                            uint64_t drop_seed, float* rows, float* grads, hipStream_t st) {
   size_t b0, b1;
   LO_TRYT(lo_teacher_grad_range(h, &b0, &b1));
   HeadsBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.pooled_f = TW(float, h->o_pool_f); a.pooled_e = TW(float, h->o_pool_e); a.weights = expert_weights; a.raw_q = TW(float, h->o_rawq);
+  a.pooled_f = pooled_f; a.pooled_e = pooled_e; a.weights = expert_weights; a.raw_q = raw_q;
   a.g_w1 = TP("gate.2.weight"); a.g_b1 = TP("gate.2.bias"); a.g_w2 = TP("gate.5.weight"); a.g_b2 = TP("gate.5.bias");
   a.o_g_w1 = h->off[t_idx(h, "gate.2.weight")] - b0; a.o_g_b1 = h->off[t_idx(h, "gate.2.bias")] - b0;
   a.o_g_w2 = h->off[t_idx(h, "gate.5.weight")] - b0; a.o_g_b2 = h->off[t_idx(h, "gate.5.bias")] - b0;
@@ -1791,16 +1801,33 @@ extern "C" int lo_teacher_heads_backward(LoTeacher* h, const float* P, void* ws,
   }
   a.rows = rows; a.row_len = b1 - b0;
   a.scale = -coef / ((float)h->B * 4.f);
+  a.dq_up = dq_up; a.dw_up = dw_up;
   a.B = h->B; a.E = h->E; a.I = h->I; a.F = h->F;
-  a.thr = h->last_p > 0.f ? (uint32_t)lrintf(h->last_p * 65536.f) : 0u;
-  if (h->last_p > 0.f && a.thr == 0) a.thr = 1;
-  a.inv_keep = h->last_p > 0.f ? 1.0f / (1.0f - h->last_p) : 1.0f;
-  a.ds_gate = lo_drop_site_keys(h->last_seed, LO_DS_GATE);
-  for (int e = 0; e < h->E; ++e) a.ds_q[e] = lo_drop_site_keys(h->last_seed, LO_DS_QUALITY(e));
+  a.thr = drop_p > 0.f ? (uint32_t)lrintf(drop_p * 65536.f) : 0u;
+  if (drop_p > 0.f && a.thr == 0) a.thr = 1;
+  a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  a.ds_gate = lo_drop_site_keys(drop_seed, LO_DS_GATE);
+  for (int e = 0; e < h->E; ++e) a.ds_q[e] = lo_drop_site_keys(drop_seed, LO_DS_QUALITY(e));
   LO_HIP(hipMemsetAsync(rows, 0, (size_t)h->B * a.row_len * sizeof(float), st));   // alignment padding inside the rows
   hipLaunchKernelGGL(lo_t_heads_bwd_kernel, dim3(h->B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("t_heads_bwd");
   return lo_colsum(rows, grads + b0, h->B, (int)a.row_len, (int)a.row_len, 1.0f, st);
+}
+// coef = quality_weight / accum.  Must follow lo_teacher_forward on the evaluated batch (uses its pooled features and masks).
+extern "C" int lo_teacher_heads_backward(LoTeacher* h, const float* P, void* ws, const float* expert_weights, float coef,
+                                         float* rows, float* grads, void* stream) {
+  LO_REQUIRE(h && P && ws && expert_weights && rows && grads, "lo_teacher_heads_backward: null argument");
+  return t_heads_backward(h, P, TW(float, h->o_pool_f), TW(float, h->o_pool_e), TW(float, h->o_rawq), expert_weights, nullptr, nullptr,
+                          coef, h->last_p, h->last_seed, rows, grads, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int lo_teacher_heads_backward_ex(LoTeacher* h, const float* P, const float* pooled_f, const float* pooled_e, const float* raw_q,
+                                            const float* expert_weights, const float* d_quality, const float* d_weights, float dropout_p,
+                                            uint64_t drop_seed, float* rows, float* grads, void* stream) {
+  LO_REQUIRE(h && P && pooled_f && pooled_e && raw_q && expert_weights && rows && grads && (d_quality || d_weights),
+             "lo_teacher_heads_backward_ex: null argument");
+  // a NULL d_quality means "no gradient arrives through quality_scores": coef 0 makes the constant seed vanish
+  return t_heads_backward(h, P, pooled_f, pooled_e, raw_q, expert_weights, d_quality, d_weights, 0.f, dropout_p, drop_seed, rows, grads,
+                          reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int lo_hybrid_reward(const float* quality, const float* semantic, int B, float semantic_weight, float reward_scale,
                                 float momentum, float quality_weight, float accum, float* state2, float* out7, float* adv_dev,

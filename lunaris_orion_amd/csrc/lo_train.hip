@@ -350,6 +350,16 @@ int lo_colsum_f16(const f16* x, float* out, int M, int N, float scale, hipStream
   LO_LAUNCH_CHECK("colsum_f16");
   return LO_OK;
 }
+// x[i] *= scale (a few thousand elements: the latent gradient leaving lo_vae_decoder_backward un-scaled)
+__global__ void lo_scale_f32_kernel(float* __restrict__ x, size_t n, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= scale;
+}
+int lo_scale_f32(float* x, size_t n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(lo_scale_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, scale);
+  LO_LAUNCH_CHECK("scale_f32");
+  return LO_OK;
+}
 int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st) {
   LO_REQUIRE(n % 4 == 0, "lo_cast_f32_f16: n must be a multiple of 4");
   size_t n4 = n / 4;
@@ -411,5 +421,69 @@ int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st) {
   LoProfScope _p("lo_decode_sprites", 0, 15.0 * n, st);
   hipLaunchKernelGGL(lo_decode_sprites_kernel, dim3((n + 255) / 256), dim3(256), 0, st, u8, out, n);
   LO_LAUNCH_CHECK("decode_sprites");
+  return LO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data-parallel gradient exchange helpers (lunaris_orion_amd/parallel.py, mode "direct": all-to-all reduce-scatter + all-gather
+// over all xGMI links; no reference counterpart -- the reference has no distributed code).  One streaming pass each:
+//   pack:    wire[i] = fp16(g[i] * scale)                       (fp16 wire format: halves the xGMI bytes)
+//   shares:  share[i] = (sum_r recv[r * chunk + i]) * inv_world (this rank's share of the reduce-scatter; fp32 accumulation, ranks
+//            added in rank order: the same bits on every run)
+//   unpack:  g[i] = float(wire[i]) * inv_scale
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lo_dp_pack_f16_kernel(const float* __restrict__ g, f16* __restrict__ wire, size_t n, float scale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      f16x4 o = {(f16)(v.x * scale), (f16)(v.y * scale), (f16)(v.z * scale), (f16)(v.w * scale)};
+      *reinterpret_cast<f16x4*>(wire + i) = o;
+    } else {
+      for (size_t j = i; j < n; ++j) wire[j] = (f16)(g[j] * scale);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void lo_dp_unpack_f16_kernel(const f16* __restrict__ wire, float* __restrict__ g, size_t n, float inv_scale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const f16x4 v = *reinterpret_cast<const f16x4*>(wire + i);
+      *reinterpret_cast<float4*>(g + i) = make_float4((float)v[0] * inv_scale, (float)v[1] * inv_scale, (float)v[2] * inv_scale, (float)v[3] * inv_scale);
+    } else {
+      for (size_t j = i; j < n; ++j) g[j] = (float)wire[j] * inv_scale;
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lo_dp_sum_shares_kernel(const T* __restrict__ recv, T* __restrict__ share, int world, size_t chunk, float inv_world) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunk; i += stride) {
+    float t = 0.f;
+    for (int r = 0; r < world; ++r) t += (float)recv[(size_t)r * chunk + i];
+    share[i] = (T)(t * inv_world);
+  }
+}
+static inline int lo_dp_blocks(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+int lo_dp_pack_f16_run(const float* g, f16* wire, size_t n, float scale, hipStream_t st) {
+  LoProfScope _p("lo_dp_pack_f16", 0, 6.0 * n, st);
+  hipLaunchKernelGGL(lo_dp_pack_f16_kernel, dim3(lo_dp_blocks((n + 3) / 4)), dim3(256), 0, st, g, wire, n, scale);
+  LO_LAUNCH_CHECK("dp_pack_f16");
+  return LO_OK;
+}
+int lo_dp_unpack_f16_run(const f16* wire, float* g, size_t n, float inv_scale, hipStream_t st) {
+  LoProfScope _p("lo_dp_unpack_f16", 0, 6.0 * n, st);
+  hipLaunchKernelGGL(lo_dp_unpack_f16_kernel, dim3(lo_dp_blocks((n + 3) / 4)), dim3(256), 0, st, wire, g, n, inv_scale);
+  LO_LAUNCH_CHECK("dp_unpack_f16");
+  return LO_OK;
+}
+int lo_dp_sum_shares_run(const void* recv, void* share, int world, size_t chunk, int is_f16, float inv_world, hipStream_t st) {
+  LoProfScope _p("lo_dp_sum_shares", 0, (is_f16 ? 2.0 : 4.0) * (world + 1) * chunk, st);
+  if (is_f16) hipLaunchKernelGGL((lo_dp_sum_shares_kernel<f16>), dim3(lo_dp_blocks(chunk)), dim3(256), 0, st, (const f16*)recv, (f16*)share, world, chunk, inv_world);
+  else hipLaunchKernelGGL((lo_dp_sum_shares_kernel<float>), dim3(lo_dp_blocks(chunk)), dim3(256), 0, st, (const float*)recv, (float*)share, world, chunk, inv_world);
+  LO_LAUNCH_CHECK("dp_sum_shares");
   return LO_OK;
 }

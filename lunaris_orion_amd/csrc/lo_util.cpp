@@ -17,6 +17,7 @@ int lo_check_hip(hipError_t e, const char* what) {
 #include <string>
 #include <vector>
 bool g_lo_prof_on = false;
+bool g_lo_prof_layers = false;     // per-layer record names (lo_prof_enable(2), or LO_PROF_LAYERS in the environment)
 const char* g_lo_prof_tag = nullptr;
 namespace {
 struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
@@ -43,8 +44,7 @@ void lo_prof_end(hipStream_t st) {
 // Under LO_PROF_LAYERS a conv-like launch is named "<kernel> <Cin>><Cout> <Hin>><Hout> T<taps>": one interned string per distinct
 // (kernel, geometry), since the records keep the pointer.  Without it (or with the profiler off) the kernel name itself.
 const char* lo_prof_geom_name(const char* base, const LoGeom& g) {
-  static const bool per_layer = getenv("LO_PROF_LAYERS") != nullptr;
-  if (!per_layer || !g_lo_prof_on) return base;
+  if (!g_lo_prof_layers || !g_lo_prof_on) return base;
   static std::vector<std::string*> table;
   char text[96];
   snprintf(text, sizeof(text), "%s %d>%d %d>%d T%d", base, g.Cin, g.Cout, g.Hin, g.Hout, g.T[0] * (g.n_phase > 1 ? -g.n_phase : 1));
@@ -64,6 +64,7 @@ const char* lo_prof_intern(const char* text) {
 }
 extern "C" void lo_prof_enable(int on) {
   g_lo_prof_on = on != 0;
+  g_lo_prof_layers = on == 2 || getenv("LO_PROF_LAYERS") != nullptr;
   if (on) { g_recs.clear(); g_pool_used = 0; }
 }
 extern "C" int lo_prof_count(void) { return (int)g_recs.size(); }

@@ -140,13 +140,33 @@ def _default_teacher(args):
     key = (int(a.get("num_experts", 4)), int(a.get("feature_dim", 128)), int(a.get("embedding_dim", 64)))
     if key not in _DEFAULT_TEACHER:
         from .teacher import LunarMoETeacher
-        with torch.random.fork_rng(devices=[]):
+        # fork_rng() with its default device list saves and restores the CPU generator AND every CUDA generator: manual_seed
+        # below reseeds all of them (with devices=[] the CUDA streams of the run were reseeded for good)
+        with torch.random.fork_rng():
             torch.manual_seed(int(a.get("seed", 42)))
             m = LunarMoETeacher(num_experts=key[0], feature_dim=key[1], embedding_dim=key[2])
         _DEFAULT_TEACHER[key] = ({k: v.detach().clone() for k, v in m.state_dict().items()},
                                  OrderedDict((k, p.detach()) for k, p in m.named_parameters()))
     sd, tp = _DEFAULT_TEACHER[key]
     return sd, tp, float(a.get("teacher_lr", 1e-4))
+
+
+def prune_periodic_checkpoints(ckpt_dir: Path, keep: int) -> list:
+    """`--keep_n_checkpoints` (train_hybrid.py:1115, parsed and never read by the reference): of the periodic `step_<N>.pt` files
+    written under `--save_every`, keep the `keep` with the highest step numbers; returns the paths removed.  `latest.pt` /
+    `best.pt` are never touched."""
+    found = []
+    for p in Path(ckpt_dir).glob("step_*.pt"):
+        try:
+            found.append((int(p.stem.split("_", 1)[1]), p))
+        except ValueError:
+            continue
+    found.sort()
+    removed = []
+    for _, p in found[:max(0, len(found) - max(0, int(keep)))]:
+        p.unlink(missing_ok=True)
+        removed.append(p)
+    return removed
 
 
 def checkpoint_dict(stepper, vae, teacher, global_step: int, best_loss: float, args: dict) -> dict:
@@ -184,14 +204,31 @@ def checkpoint_dict(stepper, vae, teacher, global_step: int, best_loss: float, a
         # and `teacher_scheduler.load_state_dict` (train_hybrid.py:808-822) and gives up on a dict without parameter groups, so
         # write the state of a freshly constructed teacher: default-initialised weights, one parameter group over all of its
         # parameters with no moments yet, the scheduler at step 0
-        t0_, tp, t_lr = _default_teacher(args)
-        ck["teacher_state_dict"] = t0_
-        ck["teacher_optimizer"] = adamw_state_dict(tp, torch.zeros(1), torch.zeros(1), {k: 0 for k in tp}, 0, getattr(stepper, "teacher_base_lr", 1e-4),
-                                                   float(args.get("teacher_lr", 1e-4)) if isinstance(args, dict) else 1e-4, stepper.betas, stepper.eps,
-                                                   stepper.weight_decay)
-        ck["teacher_scheduler"] = scheduler_state_dict(stepper.t0, 2, stepper.min_lr, float(args.get("teacher_lr", 1e-4)) if isinstance(args, dict) else 1e-4, 0, t_lr)
-        extra["teacher_untrained"] = True
+        try:
+            t0_, tp, t_lr = _default_teacher(args)
+        except NotImplementedError as e:
+            # a VAE-only run never builds the teacher, so its flags were never validated (e.g. --feature_dim 64): the run must not
+            # die at its first save.  Keep the empty teacher entries; the reference cannot resume its teacher from
+            # this file, the VAE half loads either side
+            import warnings
+            warnings.warn(f"checkpoint written without teacher entries: {e}")
+            extra["teacher_untrained"] = True
+            extra["teacher_entries_omitted"] = str(e)
+        else:
+            ck["teacher_state_dict"] = t0_
+            ck["teacher_optimizer"] = adamw_state_dict(tp, torch.zeros(1), torch.zeros(1), {k: 0 for k in tp}, 0, getattr(stepper, "teacher_base_lr", 1e-4),
+                                                       float(args.get("teacher_lr", 1e-4)) if isinstance(args, dict) else 1e-4, stepper.betas, stepper.eps,
+                                                       stepper.weight_decay)
+            ck["teacher_scheduler"] = scheduler_state_dict(stepper.t0, 2, stepper.min_lr, float(args.get("teacher_lr", 1e-4)) if isinstance(args, dict) else 1e-4, 0, t_lr)
+            extra["teacher_untrained"] = True
     extra["loss_scale"] = float(vae.loss_scale)          # the reference's GradScaler state is not checkpointed either side: keep ours
+    # positions in the two counter-RNG streams (reparameterisation noise, teacher dropout masks): calls drawn so far.  Each stream
+    # is keyed by (torch seed, rank), so on resume every rank re-derives its own stream and advances it by the recorded count
+    # (vae.lcg_advance) -- the run continues with the noise / masks it would have drawn uninterrupted (the reference does not
+    # checkpoint its RNG state: SURVEY §5)
+    extra["noise_calls"] = int(getattr(vae, "noise_calls", 0))
+    if teacher is not None:
+        extra["drop_calls"] = int(getattr(teacher, "drop_calls", 0))
     ck["lunaris_amd_extra"] = extra
     return ck
 
@@ -216,4 +253,8 @@ def restore_checkpoint(ck: dict, stepper, vae, teacher) -> Tuple[int, float]:
         vae.loss_scale = float(extra["loss_scale"])
     if teacher is not None and "reward_state" in extra:
         stepper.reward_state.copy_(extra["reward_state"])
+    if "noise_calls" in extra:
+        vae._seed, vae.noise_calls = None, int(extra["noise_calls"])          # re-derived (and advanced) at the next forward
+    if teacher is not None and "drop_calls" in extra:
+        teacher._drop_seed, teacher.drop_calls = None, int(extra["drop_calls"])
     return int(ck.get("global_step", 0)), float(ck.get("best_loss", float("inf")))

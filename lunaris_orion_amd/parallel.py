@@ -4,22 +4,27 @@ The reference has no distributed code (no `distributed`, `nccl`, `LO
 behaviour to match except: N ranks at per-rank batch B give the single-process result at global batch N*B.
 GroupNorm is per-sample and MSE / KL are means, so averaging the per-rank gradients is exactly that (VAE-only).
 
-All 72 gradients live in ONE flat fp32 buffer (lunaris_orion_amd.vae), so the exchange is a single collective on a
-contiguous buffer — no bucketing logic, no per-tensor launches.  `FlatGradSync`:
-  * backend "nccl" (= RCCL on ROCm): asynchronous `all_reduce(AVG)` (RCCL's own stream, ordered after the producing
-    kernels), joined before clip+AdamW.  VAEStepper splits the backward in three native calls so that the exchange of
-    everything from fc_mu.weight to the end of the flat buffer (Linear layers, decoder and final convs: 90 % of the
-    bytes, final after phase 1) overlaps the encoder backward, and that of the encoder's last stage (94 % of the rest)
-    overlaps stages 3..1; only their 7.7 MB are exchanged after the backward has ended.  Optional
-    fp16 wire format (halves the xGMI bytes; g * 1024 on the wire so that small gradients stay in the normal fp16
-    range; the sum is then taken in fp16, so it is off by default to keep DP == single-process to fp32 rounding);
-  * backend "gloo" (CPU tests): SUM then divide (gloo has no AVG);
-  * `mode="direct"`: the xGMI-shaped exchange of SURVEY §8(e).  xGMI is a full mesh of point-to-point links (7 per GPU), so a
-    ring all-reduce moves 2(N-1)/N of the buffer over ONE link per GPU (2.8 ms for 244 MB at 8 ranks).  Direct form: every rank
-    sends chunk j of its buffer straight to rank j (`all_to_all_single`: N-1 concurrent peer transfers, one per link), sums the N
-    chunks it received (its share of the reduce-scatter), and the shares are gathered back (`all_gather_into_tensor`): each
-    link carries 2/N of the buffer.  Behind a flag (`bench.py --dp-exchange direct`) until an 8-GPU node has measured it.
-The module is pure host logic on top of torch.distributed and is exercised by world-size-2 gloo tests on CPU.
+All 72 gradients live in ONE flat fp32 buffer (lunaris_orion_amd.vae), so a hand-over is a contiguous range of it — no
+bucketing logic, no per-tensor launches.  VAEStepper splits the backward into three native calls and hands each range over
+(`begin`) the moment it is final: everything from fc_mu.weight to the end of the buffer (Linear layers, decoder and final convs:
+90 % of the bytes) after phase 1, the encoder's last stage (94 % of the rest) after phase 3, the remaining 7.7 MB at the end.
+
+`FlatGradSync.begin(range)` enqueues the WHOLE exchange of that range on a communication stream that waits only for the work
+already on the compute stream (one event): wire pack -> collective(s) -> share sum -> gather -> unpack, every step chained in
+stream order, nothing left for `finish()` but one event wait per range.  So the exchange of a range overlaps whatever the
+backward still has to do, and only the last range (7.7 MB) is exposed.  Two forms:
+  * `mode="direct"` (default for N > 1 in bench.py / train_hybrid.py): the xGMI-shaped exchange of SURVEY §8(e).  xGMI is a full
+    mesh of point-to-point links (7 per GPU, ≈153 GB/s each), so a ring all-reduce moves 2(N-1)/N of the buffer over ONE link per
+    GPU.  Direct form: every rank sends chunk j of the range straight to rank j (`all_to_all_single`: N-1 concurrent peer
+    transfers, one per link), sums the N chunks it received in fp32 (`lo_dp_sum_shares`: its share of the reduce-scatter, ranks in
+    order -> reproducible), and the shares are gathered back (`all_gather_into_tensor`): each link carries 2/N of the range.
+  * `mode="allreduce"`: one RCCL `all_reduce(AVG)` per range (ring / tree as RCCL chooses).
+  fp16 wire format (`compress_fp16`, default with "direct"): g * 1024 in fp16 on the wire (`lo_dp_pack_f16` / `lo_dp_unpack_f16`;
+  typical gradient elements 1e-5 .. 1e-3 sit at the bottom of the fp16 range), halves the xGMI bytes; the share sum accumulates in
+  fp32 either way.  fp32 wire keeps DP == single-process to fp32 rounding.
+DESIGN.md §6 has the bandwidth model (bytes per link per phase, expected exposed time at N = 2 / 4 / 8).
+Backend "gloo" with CPU tensors (tests only): the same sequence of collectives, synchronously, with torch ops in place of the
+library kernels (gloo has no AVG: SUM then divide) — the world-size-2 tests exercise the ordering and the arithmetic.
 """
 from __future__ import annotations
 
@@ -30,13 +35,10 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    """Averages (slices of) the flat gradient buffer across ranks.
+    """Averages ranges of the flat gradient buffer across ranks.
 
-    `sync(flat)` = one blocking-in-stream-order exchange.  `begin(slice)` ... `finish()` = asynchronous exchanges
-    (torch.distributed `async_op=True`: the collective is ordered after the work already enqueued on the current
-    stream and runs on the backend's own stream; `finish()` makes the current stream wait for all of them), used by
-    VAEStepper to overlap the exchange of the Linear-layer gradients with the encoder backward.
-    """
+    `begin(range)` ... `finish()`: each `begin` enqueues the complete exchange of one range behind the work already on the current
+    stream; `finish()` makes the current stream wait for all of them.  `sync(flat)` = `begin` + `finish`."""
 
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, compress_fp16: bool = False, force: bool = False,
                  wire_scale: float = 1024.0, mode: str = "allreduce", time_exposed: bool = False):
@@ -46,85 +48,117 @@ class FlatGradSync:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.compress = compress_fp16
-        # fp16 wire: typical gradient elements (1e-5 .. 1e-3) sit at the bottom of the fp16 range; the wire carries
-        # g * wire_scale (overflow needs an element > 64) and the result is divided again
-        self.wire_scale = float(wire_scale)
-        self.force = force              # tests: issue the collectives even in a one-rank group
-        self._pending = []          # (work, wire_or_None, destination)
-        self._wire = {}
+        self.wire_scale = float(wire_scale)      # overflow on the wire needs a gradient element > 64
+        self.force = force                       # tests: issue the collectives even in a one-rank group
         if mode not in ("allreduce", "direct"):
             raise ValueError(f"unknown exchange mode {mode!r}")
         self.mode = mode
-        self._stage = {}            # direct mode: (receive buffer, share) per exchanged slice
+        self.mode_used = None       # what the last exchange ran as (gloo cannot carry all-to-all / all-gather on GPU tensors)
+        self._pending = []          # per begin(): a CUDA event (GPU path) or None (CPU path: already complete)
+        self._wire, self._stage = {}, {}
+        self._comm: Optional[torch.cuda.Stream] = None
         # bookkeeping for the bench line: bytes handed over per begin() of a step, HIP events around finish()
         self.time_exposed = time_exposed
         self._phase_bytes, self._phase_log = [], None
         self._events, self._finishes = [], 0
 
-    def _op(self):
-        # gloo has no AVG: SUM, divide in finish()
-        return dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM
+    # ---- the pieces: library kernels on the GPU, torch ops for the CPU tests -------------------------------------------------
+    def _avg_op(self):
+        return dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM       # gloo has no AVG: SUM, divide afterwards
 
+    def _pack(self, g: torch.Tensor) -> torch.Tensor:
+        key = (g.data_ptr(), g.numel())
+        wire = self._wire.get(key)
+        if wire is None:
+            wire = self._wire[key] = torch.empty(g.numel(), dtype=torch.float16, device=g.device)
+        if g.is_cuda:
+            from . import _lib
+            _lib.check(_lib.lib.lo_dp_pack_f16(g.data_ptr(), wire.data_ptr(), g.numel(), self.wire_scale, _lib.stream_ptr()), "lo_dp_pack_f16")
+        else:
+            torch.mul(g, self.wire_scale, out=wire)
+        return wire
+
+    def _unpack(self, wire: torch.Tensor, g: torch.Tensor) -> None:
+        if g.is_cuda:
+            from . import _lib
+            _lib.check(_lib.lib.lo_dp_unpack_f16(wire.data_ptr(), g.data_ptr(), g.numel(), 1.0 / self.wire_scale, _lib.stream_ptr()), "lo_dp_unpack_f16")
+        else:
+            g.copy_(wire)
+            g.div_(self.wire_scale)
+
+    def _sum_shares(self, recv: torch.Tensor, share: torch.Tensor) -> None:
+        if recv.is_cuda:
+            from . import _lib
+            _lib.check(_lib.lib.lo_dp_sum_shares(recv.data_ptr(), share.data_ptr(), self.world, share.numel(),
+                                                 1 if recv.dtype == torch.float16 else 0, _lib.stream_ptr()), "lo_dp_sum_shares")
+        else:
+            acc = recv.view(self.world, -1).float().sum(dim=0) / self.world
+            share.copy_(acc)
+
+    def _exchange(self, buf: torch.Tensor) -> None:
+        """The collectives of one range, issued on the CURRENT stream (sync-in-stream calls: the stream, not the host, waits)."""
+        # gloo implements all_to_all / all_gather for CPU tensors only: the two-rank rehearsals on one GPU (gloo + GPU tensors) fall
+        # back to the all-reduce form; RCCL and the CPU tests run what was asked for
+        direct = self.mode == "direct" and not (self.backend == "gloo" and buf.is_cuda)
+        self.mode_used = "direct" if direct else "allreduce"
+        if direct:
+            n, w = buf.numel(), self.world
+            chunk = n // w
+            if chunk > 0:
+                key = (buf.data_ptr(), n, buf.dtype)
+                st = self._stage.get(key)
+                if st is None:
+                    st = self._stage[key] = (torch.empty(chunk * w, dtype=buf.dtype, device=buf.device),
+                                             torch.empty(chunk, dtype=buf.dtype, device=buf.device))
+                recv, share = st
+                body = buf[: chunk * w]
+                dist.all_to_all_single(recv, body, group=self.group)          # recv[j] = rank j's chunk `rank`
+                self._sum_shares(recv, share)                                 # this rank's share of the reduce-scatter
+                dist.all_gather_into_tensor(body, share, group=self.group)
+            if n > chunk * w:                                                 # remainder (< world elements): plain all-reduce
+                tail = buf[chunk * w:]
+                dist.all_reduce(tail, op=self._avg_op(), group=self.group)
+                if self.backend != "nccl":
+                    tail.div_(w)
+        else:
+            dist.all_reduce(buf, op=self._avg_op(), group=self.group)
+            if self.backend != "nccl":
+                buf.div_(self.world)
+
+    def _run(self, g: torch.Tensor) -> None:
+        wire = self._pack(g) if self.compress else None
+        self._exchange(wire if wire is not None else g)
+        if wire is not None:
+            self._unpack(wire, g)
+
+    # ---- public ---------------------------------------------------------------------------------------------------------------
     def begin(self, g: torch.Tensor) -> None:
         if (self.world == 1 and not self.force) or g.numel() == 0:
             return
-        wire = None
-        if self.compress and g.is_cuda:
-            key = (g.data_ptr(), g.numel())
-            wire = self._wire.get(key)
-            if wire is None:
-                wire = self._wire[key] = torch.empty(g.numel(), dtype=torch.float16, device=g.device)
-            torch.mul(g, self.wire_scale, out=wire)
-        buf = wire if wire is not None else g
-        self._phase_bytes.append(buf.numel() * buf.element_size())
-        if self.mode == "direct" and (self.world > 1 or self.force):
-            self._pending.append((self._begin_direct(buf), wire, g))
+        self._phase_bytes.append(g.numel() * (2 if self.compress else g.element_size()))
+        if not g.is_cuda:
+            self._run(g)                                  # CPU tensors (gloo tests): synchronous
+            self._pending.append(None)
             return
-        work = dist.all_reduce(buf, op=self._op(), group=self.group, async_op=True)
-        self._pending.append((work, wire, g))
-
-    def _begin_direct(self, buf: torch.Tensor):
-        """all-to-all reduce-scatter + all-gather on the largest prefix divisible by the world size (+ a tiny all-reduce for
-        the remainder).  Returns the list of waits finish() has to perform, in order."""
-        n, w = buf.numel(), self.world
-        chunk = n // w
-        body = buf[: chunk * w]
-        key = (buf.data_ptr(), n, buf.dtype)
-        st = self._stage.get(key)
-        if st is None:
-            st = self._stage[key] = (torch.empty(chunk * w, dtype=buf.dtype, device=buf.device), torch.empty(chunk, dtype=buf.dtype, device=buf.device))
-        recv, share = st
-        steps = []
-        if chunk > 0:
-            a2a = dist.all_to_all_single(recv, body, group=self.group, async_op=True)      # recv[j] = rank j's chunk `rank`
-            steps.append(("a2a", a2a, recv, share, body))
-        if n > chunk * w:
-            steps.append(("tail", dist.all_reduce(buf[chunk * w:], op=self._op(), group=self.group, async_op=True), None, None, None))
-        return steps
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=g.device)
+        ready = torch.cuda.Event()
+        ready.record()                                    # `g` is final once the work enqueued so far has run
+        self._comm.wait_event(ready)
+        with torch.cuda.stream(self._comm):
+            self._run(g)
+            done = torch.cuda.Event()
+            done.record()
+        self._pending.append(done)
 
     def finish(self) -> None:
         ev = None
-        if self.time_exposed and self._pending and torch.cuda.is_available() and self._pending[0][2].is_cuda:
+        if self.time_exposed and any(p is not None for p in self._pending):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        for work, wire, g in self._pending:
-            if isinstance(work, list):                       # direct mode
-                buf = wire if wire is not None else g
-                for kind, wk, recv, share, body in work:
-                    wk.wait()
-                    if kind == "a2a":                        # this rank's share of the reduce-scatter, then the gather
-                        torch.sum(recv.view(self.world, -1), dim=0, out=share)
-                        share.div_(self.world)
-                        dist.all_gather_into_tensor(body, share, group=self.group)
-                    elif self.backend != "nccl":             # remainder: plain all-reduce (gloo: SUM, so divide)
-                        buf[(buf.numel() // self.world) * self.world:].div_(self.world)
-            else:
-                work.wait()                      # NCCL: the current stream waits; gloo: the host waits
-            if wire is not None:
-                g.copy_(wire)
-                g.div_(self.wire_scale)
-            if self.backend != "nccl" and not isinstance(work, list):
-                g.div_(self.world)
+        for done in self._pending:
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)
         if ev is not None:
             ev[1].record()
             if len(self._events) < 4096:
@@ -139,22 +173,26 @@ class FlatGradSync:
         self._events, self._finishes = [], 0
 
     def exposed_ms_per_step(self) -> Optional[float]:
-        """Mean time the current stream spent between entering finish() and having every exchanged range back (HIP events on
-        the stream; includes the wait for the collectives and the fp16-wire unpack): the part of the exchange the backward did
-        not hide.  Call after torch.cuda.synchronize()."""
+        """Mean time the current stream spent inside finish() waiting for exchanges that had not completed yet (HIP events on the
+        stream): the part of the exchange the backward did not hide.  Call after torch.cuda.synchronize()."""
         if not self._events:
             return None
         return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
 
     def bytes_per_phase(self):
-        """Bytes handed to the exchange by each begin() of the last step, in hand-over order."""
+        """Bytes handed to the exchange (on the wire format) by each begin() of the last step, in hand-over order."""
         return list(self._phase_log or [])
+
+    def _small(self, t: torch.Tensor, op) -> None:
+        """A few scalars, blocking in stream order on the CURRENT stream (never the communication stream: its queue may hold
+        gradient ranges of this step, and the scalars are needed now)."""
+        dist.all_reduce(t, op=op, group=self.group)
 
     def average_small(self, t: torch.Tensor) -> None:
         """Average a few fp32 scalars in place (never compressed): the batch means behind the reward baseline."""
         if self.world == 1 and not self.force:
             return
-        dist.all_reduce(t, op=self._op(), group=self.group)
+        self._small(t, self._avg_op())
         if self.backend != "nccl":
             t.div_(self.world)
 
@@ -162,7 +200,7 @@ class FlatGradSync:
         """Element-wise maximum over ranks, in place (control flags: e.g. "some rank received SIGINT")."""
         if self.world == 1 and not self.force:
             return
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self._small(t, dist.ReduceOp.MAX)
 
     def __call__(self, flat_grads: torch.Tensor) -> None:
         """Average `flat_grads` in place across ranks; the result is ordered on the current stream."""

@@ -14,8 +14,12 @@ train mode all six sites are applied on the device with torch semantics (``nn.Dr
 site, element) — ``oracle/dropout_ref.py`` regenerates them bit-exactly, which is how the parity tests run the CPU oracle
 and the reference itself on the same masks.  With dropout the native forward runs every 3x3 convolution in full (the
 constant-field shortcuts of the p = 0 path do not survive ``proj_drop``); eval mode and ``dropout_rate=0`` take the
-shortcut path.  The gate / quality-head gradients of ``teacher_loss`` are ``lo_teacher_heads_backward``
-(driven by ``trainer.HybridStepper``).
+shortcut path.  ``quality_scores`` and ``expert_weights`` are autograd-visible outputs: with gradients enabled the forward is an
+autograd node over the gate / quality-head parameters — the only ones that receive gradients in the reference, whose reentrant
+checkpoints cut the experts and the feature extractor from the graph — so the reference's own
+``teacher_loss.backward()`` (train_hybrid.py:891-904) fills their ``.grad`` (``lo_teacher_heads_backward_ex``, replaying the
+call's dropout masks).  ``trainer.HybridStepper`` drives the same kernel directly (``lo_teacher_heads_backward``).  In-place
+parameter updates by any optimizer are noticed through the parameters' version counters (re-pack before the next forward).
 
 ``feature_dim``: 128 (the CLI default: folded attention + constant-field shortcuts when no dropout is active) or 256 / 512 (the
 README's High-End recipe, /root/reference/README.md:102-118: a generic path with every tensor at full resolution and the
@@ -85,7 +89,7 @@ class _TeacherEngine:
                                                  1 if model.mfma_precision == "fp8" else 0, C.byref(h)), "lo_teacher_create_ex")
         self.handle = h
         self.ws = torch.empty(_lib.lib.lo_teacher_workspace_bytes(h), dtype=torch.uint8, device=model._flat.device)
-        self.packed_version = -1
+        self.packed_version = None
 
     def __iter__(self):          # (handle, workspace, packed version): the tuple form older call sites unpack
         return iter((self.handle, self.ws, self.packed_version))
@@ -97,6 +101,49 @@ class _TeacherEngine:
                 _lib.lib.lo_teacher_destroy(h)
             except Exception:
                 pass
+
+
+class _TeacherFunction(torch.autograd.Function):
+    """LunarMoETeacher.forward as an autograd node over the gate / quality-head parameters (lunar_evaluator.py:353-373, 417,
+    431-432): differentiable outputs quality_scores [B,4] and expert_weights [B,E]; the embeddings and the semantic score are
+    returned without a graph (nothing in the reference step differentiates them).  The head inputs of THIS call (pooled
+    features, pre-weighting logits, dropout stream) are copied out of the workspace, so later forward calls do not disturb it."""
+
+    @staticmethod
+    def forward(ctx, model, x, *live):
+        out, eng, p, seed = model._native_forward(x)
+        offs, elems = (C.c_size_t * 3)(), (C.c_size_t * 3)()
+        _lib.check(_lib.lib.lo_teacher_heads_saved(eng.handle, offs, elems), "lo_teacher_heads_saved")
+        saved = [eng.ws[offs[i]:offs[i] + 4 * elems[i]].view(torch.float32).clone() for i in range(3)]
+        ctx.model, ctx.eng, ctx.drop = model, eng, (p, seed)
+        ctx.live_offsets = [(t.data_ptr() - model._flat.data_ptr()) // 4 for t in live]
+        ctx.live_shapes = [t.shape for t in live]
+        ctx.save_for_backward(out["expert_weights"], *saved)
+        ctx.mark_non_differentiable(out["style_embedding"], out["prompt_embedding"], out["semantic_score"])
+        return out["quality_scores"], out["expert_weights"], out["style_embedding"], out["prompt_embedding"], out["semantic_score"]
+
+    @staticmethod
+    def backward(ctx, gq, gw, *_):
+        model, eng = ctx.model, ctx.eng
+        w, pooled_f, pooled_e, raw_q = ctx.saved_tensors
+        cont = lambda t: None if t is None else t.contiguous().float()
+        gq, gw = cont(gq), cont(gw)
+        b, e = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib.lo_teacher_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_teacher_grad_range")
+        rows = torch.empty(w.shape[0] * (e.value - b.value), dtype=torch.float32, device=w.device)
+        grads = torch.zeros_like(model._flat)
+        if gq is not None or gw is not None:
+            _lib.check(_lib.lib.lo_teacher_heads_backward_ex(eng.handle, model._flat.data_ptr(), pooled_f.data_ptr(), pooled_e.data_ptr(),
+                                                             raw_q.data_ptr(), w.data_ptr(), _lib.ptr(gq), _lib.ptr(gw), float(ctx.drop[0]),
+                                                             int(ctx.drop[1]), rows.data_ptr(), grads.data_ptr(), _lib.stream_ptr()),
+                       "lo_teacher_heads_backward_ex")
+        out = []
+        for o, shape in zip(ctx.live_offsets, ctx.live_shapes):
+            n = 1
+            for d in shape:
+                n *= int(d)
+            out.append(grads[o:o + n].view(shape))
+        return (None, None) + tuple(out)
 
 
 class LunarMoETeacher(nn.Module):
@@ -142,6 +189,7 @@ class LunarMoETeacher(nn.Module):
         self._engines: Dict[int, "_TeacherEngine"] = {}
         self._weights_version = 0
         self._drop_seed: Optional[int] = None     # counter-RNG stream of the dropout masks; derived at the first train-mode forward
+        self.drop_calls = 0                        # train-mode forwards drawn from the stream so far (checkpointed)
         self.last_drop_seed: Optional[int] = None  # the seed the last forward ran with (tests regenerate its masks from it)
 
     @staticmethod
@@ -219,10 +267,17 @@ class LunarMoETeacher(nn.Module):
         if eng is None:
             eng = _TeacherEngine(self, batch)
             self._engines[batch] = eng
-        if eng.packed_version != self._weights_version:
+        # in-place updates by any optimizer move the parameters' version counters (the native head update writes through raw
+        # pointers instead and touches only tensors the head kernels read in fp32: nothing to re-pack)
+        version = (self._weights_version, sum(p._version for p in self.parameters()))
+        if eng.packed_version != version:
             _lib.check(_lib.lib.lo_teacher_pack(eng.handle, self._flat.data_ptr(), eng.ws.data_ptr(), _lib.stream_ptr()), "lo_teacher_pack")
-            eng.packed_version = self._weights_version
+            eng.packed_version = version
         return eng
+
+    def live_parameters(self):
+        """The parameters that receive gradients in the reference step (gate.*, quality_heads.*: SURVEY §3.2), state_dict order."""
+        return [p for k, p in self.named_parameters() if k.startswith("gate.") or k.startswith("quality_heads.")]
 
     # ---- dropout stream -----------------------------------------------------------------------------------
     def set_dropout_stream(self, seed: int, exact_next: bool = False) -> None:
@@ -238,10 +293,13 @@ class LunarMoETeacher(nn.Module):
             import torch.distributed as dist
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
             self._drop_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0xD209 + 0xD1B54A32D192ED03 * rank) & 0xFFFFFFFFFFFFFFFF
+            from .vae import lcg_advance
+            self._drop_seed = lcg_advance(self._drop_seed, self.drop_calls)     # > 0 after a resume: same stream, same position
         if getattr(self, "_drop_exact", False):
             self._drop_exact = False
         else:
             self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            self.drop_calls += 1
         self.last_drop_seed = self._drop_seed
         return self._drop_seed
 
@@ -267,9 +325,8 @@ class LunarMoETeacher(nn.Module):
         with torch.no_grad():
             self._nbt += 1
 
-    def forward(self, x: torch.Tensor, prompt_embedding=None):
-        """lunar_evaluator.py:408-462.  ``prompt_embedding`` is accepted and ignored exactly like the reference does
-        (it is overwritten at :438 before any use)."""
+    def _native_forward(self, x: torch.Tensor):
+        """One `lo_teacher_forward`.  Returns (outputs, engine, dropout_p, call seed)."""
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
             raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
@@ -282,12 +339,25 @@ class LunarMoETeacher(nn.Module):
         pr = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
         sem = torch.empty(B, 1, dtype=torch.float32, device=dev)
         p = float(self.dropout_rate) if self.training else 0.0
+        seed = self._next_drop_seed() if p > 0 else 0
         _lib.check(_lib.lib.lo_teacher_forward(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), 1 if self.training else 0,
-                                               p, self._next_drop_seed() if p > 0 else 0,
-                                               q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
+                                               p, seed, q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
                                                _lib.stream_ptr()), "lo_teacher_forward")
         if self.training:
             with torch.no_grad():
                 self._nbt += 1
-        return {"quality_scores": q, "expert_weights": w, "style_embedding": st, "prompt_embedding": pr,
-                "semantic_score": sem, "feature_maps": None}
+        return ({"quality_scores": q, "expert_weights": w, "style_embedding": st, "prompt_embedding": pr,
+                 "semantic_score": sem, "feature_maps": None}, eng, p, seed)
+
+    def forward(self, x: torch.Tensor, prompt_embedding=None):
+        """lunar_evaluator.py:408-462.  ``prompt_embedding`` is accepted and ignored exactly like the reference does
+        (it is overwritten at :438 before any use).  With gradients enabled, ``quality_scores`` / ``expert_weights`` carry a
+        graph over the gate / quality-head parameters (see `_TeacherFunction`)."""
+        self._ensure_flat()
+        if torch.is_grad_enabled():
+            live = [p for p in self.live_parameters() if p.requires_grad]
+            if live:
+                q, w, st, pr, sem = _TeacherFunction.apply(self, x.detach(), *live)
+                return {"quality_scores": q, "expert_weights": w, "style_embedding": st, "prompt_embedding": pr,
+                        "semantic_score": sem, "feature_maps": None}
+        return self._native_forward(x)[0]

@@ -35,7 +35,36 @@ def cosine_warm_restarts_lr(base_lr: float, eta_min: float, t0: int, t_mult: int
     return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t_cur / t_i)) / 2.0
 
 
+class LossScalePolicy:
+    """GradScaler's policy (torch.cuda.amp.GradScaler, used by train_hybrid.py:917-923) for observations that LAG the device.
+
+    `observe(scale, skipped_total, at, now)`: `skipped_total` = the device's count of skipped updates (non-finite gradient norm)
+    after optimizer step `at`; `now` = the step the host has enqueued up to.  The host enqueues a step or two ahead of what it
+    observes, so after one genuine overflow the steps already in the queue overflow too — at the OLD scale.  Those are the same
+    overflow, not new ones (counting them cost 2-3 halvings and lost updates per event where GradScaler.update() costs
+    one): of the updates skipped since the last observation, as many as ran before the last scale change are ignored; any beyond
+    that ran at the current scale and halve it once.  `growth_interval` steps without a skip double it again, up to `init`."""
+
+    def __init__(self, init: float = 65536.0, growth_interval: int = 2000):
+        self.init, self.growth_interval = init, growth_interval
+        self.skipped_seen, self.changed_at, self.last_obs = 0, 0, 0
+
+    def observe(self, scale: float, skipped_total: int, at: int, now: int) -> float:
+        new = skipped_total - self.skipped_seen
+        at_old_scale = max(0, min(at, self.changed_at) - self.last_obs)      # steps of this window that ran before the change
+        self.skipped_seen, self.last_obs = max(skipped_total, self.skipped_seen), max(at, self.last_obs)
+        if new > at_old_scale:
+            self.changed_at = now               # every step enqueued from now on runs at the new scale
+            return max(1.0, scale * 0.5)
+        if new <= 0 and scale < self.init and now - self.changed_at >= self.growth_interval:
+            self.changed_at = now
+            return min(self.init, scale * 2.0)
+        return scale
+
+
 class VAEStepper:
+    _DP_LAG = 2     # data parallel: an observation is evaluated this many optimizer steps after it was enqueued
+
     def __init__(self, vae: LunarisCoreVAE, lr: float = 1e-4, min_lr: float = 1e-6, scheduler_t0: int = 10,
                  weight_decay: float = 0.01, max_grad_norm: float = 1.0, recon_weight: float = 1.0, kl_weight: float = 0.1,
                  gradient_accumulation_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8,
@@ -63,11 +92,16 @@ class VAEStepper:
         self.losses = torch.zeros(4, dtype=torch.float32, device=flat.device)       # recon, kl, vae_loss, pg_loss
         self.opt_steps = 0
         self.last = None
-        self._skipped_seen, self._scale_changed_at = 0, 0
-        # GradScaler policy without a host sync: the device's skipped-update counter is copied to pinned memory after every
-        # optimizer step (asynchronously) and looked at when the copy has landed, i.e. one or two steps later
-        self._skip_pinned = torch.zeros(1, dtype=torch.float32).pin_memory()
-        self._skip_event: Optional[torch.cuda.Event] = None
+        self._scale_policy = LossScalePolicy()
+        # GradScaler policy without a host sync: the device's skipped-update counter is copied to pinned memory after optimizer
+        # steps (asynchronously) and evaluated when the copy has landed, i.e. one or two steps later.  Each observation carries the
+        # optimizer-step index it was taken after, so that updates skipped at a scale that has since been changed are not counted
+        # again (see _update_loss_scale).  Data parallel: the ranks must change the scale at the SAME step (the scale multiplies
+        # fp16 activation gradients, a rank at a higher scale can overflow alone), so there the observation taken `_DP_LAG` steps
+        # earlier is waited for instead of polled -- a fixed lag, identical on every rank (the counters are: every rank sees the
+        # same averaged gradients).
+        self._skip_slots = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(self._DP_LAG + 1)]
+        self._skip_inflight = []      # (event, pinned slot, optimizer-step index), oldest first
         self._presummed_begin: Optional[int] = None   # set by a backward that left the early part of the gradient norm in the scratch
 
     @property
@@ -98,18 +132,29 @@ class VAEStepper:
 
     def _observe_skipped_updates(self) -> None:
         """Runs the loss-scale policy every optimizer step (the reference's GradScaler.update(), train_hybrid.py:917-923) with no
-        host synchronisation: the skipped-update counter of the step just enqueued travels to pinned memory behind it; whichever
-        earlier copy has landed by now is evaluated.  The host runs a step or two ahead of the GPU, so an overflow is answered
-        after that many skipped updates — not after `--log_every` of them, as when only metrics() looked."""
+        host synchronisation in the single-process case: the skipped-update counter of the step just enqueued travels to pinned
+        memory behind it; whichever earlier copy has landed by now is evaluated.  The host runs a step or two ahead of the GPU, so
+        an overflow is answered after that many skipped updates — not after `--log_every` of them, as when only metrics() looked."""
         if os.environ.get("LO_NO_SKIP_OBSERVE") == "1":      # measurement knob: no per-step device -> host copy at all
             return
-        if self._skip_event is not None and self._skip_event.query():
-            self._update_loss_scale(float(self._skip_pinned[0]))
-            self._skip_event = None
-        if self._skip_event is None:
-            self._skip_pinned.copy_(self.scratch[1027:1028], non_blocking=True)
-            self._skip_event = torch.cuda.Event()
-            self._skip_event.record()
+        dp = self.grad_sync is not None and getattr(self.grad_sync, "world", 1) > 1
+        if dp:
+            # fixed lag: wait for the observation of `_DP_LAG` steps ago (long finished unless the host runs further ahead than that)
+            while len(self._skip_inflight) >= self._DP_LAG:
+                ev, slot, at = self._skip_inflight.pop(0)
+                ev.synchronize()
+                self._update_loss_scale(float(slot[0]), at)
+        else:
+            while self._skip_inflight and self._skip_inflight[0][0].query():
+                ev, slot, at = self._skip_inflight.pop(0)
+                self._update_loss_scale(float(slot[0]), at)
+        if len(self._skip_inflight) < len(self._skip_slots):
+            busy = {id(s_) for _, s_, _ in self._skip_inflight}
+            slot = next(s_ for s_ in self._skip_slots if id(s_) not in busy)
+            slot.copy_(self.scratch[1027:1028], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._skip_inflight.append((ev, slot, self.opt_steps))
 
     def _backward_and_exchange(self, eng, images: torch.Tensor, recon: torch.Tensor, st) -> None:
         """Native backward of the fused loss into ``self.grads`` (+ the data-parallel exchange, overlapped with it)."""
@@ -168,7 +213,7 @@ class VAEStepper:
                                                       self.exp_avg_sq.data_ptr(), eng.ws.data_ptr(), *args[:7], self.scratch.data_ptr(),
                                                       1 if pre is not None else 0, st), "lo_vae_optimizer_step")
             self.vae.mark_weights_changed()
-            eng.packed_version = self.vae._weights_version     # this engine's operand copies were refreshed by the call itself
+            eng.packed_version = self.vae._current_version()     # this engine's operand copies were refreshed by the call itself
             self._pipelined_engine = eng
             return
         if pre is not None:
@@ -188,18 +233,10 @@ class VAEStepper:
                    "lo_decode_sprites_u8")
         return out
 
-    def _update_loss_scale(self, skipped_total: float) -> None:
-        """GradScaler policy (torch.cuda.amp.GradScaler, used by train_hybrid.py:917-923), fed by _observe_skipped_updates after
-        every optimizer step and by metrics(): an observation that finds new skipped updates (non-finite gradient norm) halves the
-        fp16 loss scale ONCE — the updates skipped between two observations all ran at the same scale, so they are one overflow,
-        not several; 2000 optimizer steps without one double it again, up to the initial 2**16."""
-        skipped = int(skipped_total)
-        if skipped > self._skipped_seen:
-            self.vae.loss_scale = max(1.0, self.vae.loss_scale * 0.5)
-            self._skipped_seen, self._scale_changed_at = skipped, self.opt_steps
-        elif self.vae.loss_scale < 65536.0 and self.opt_steps - self._scale_changed_at >= 2000:
-            self.vae.loss_scale = min(65536.0, self.vae.loss_scale * 2.0)
-            self._scale_changed_at = self.opt_steps
+    def _update_loss_scale(self, skipped_total: float, observed_after_step: Optional[int] = None) -> None:
+        """Feed one observation of the device's skipped-update counter to the loss-scale policy (`LossScalePolicy`)."""
+        at = self.opt_steps if observed_after_step is None else int(observed_after_step)
+        self.vae.loss_scale = self._scale_policy.observe(self.vae.loss_scale, int(skipped_total), at, self.opt_steps)
 
     def metrics(self) -> Dict[str, float]:
         """Host copy of the last step's scalars (this synchronises the stream)."""
@@ -277,7 +314,7 @@ class HybridStepper(VAEStepper):
         recon, mu, logvar, eng = vae._native_forward(images, eps, target=images)
         if self.run_dead_teacher_call:
             t.update_statistics_only(images)            # train_hybrid.py:853-855 (side effects only)
-        tout = t(recon)                                 # train_hybrid.py:865
+        tout = t._native_forward(recon)[0]              # train_hybrid.py:865 (no autograd node: the head gradients are taken below)
         self.last_teacher_out = tout
         h, ws = self._teacher_setup(B)
         q_rows, s_rows, n_rows = tout["quality_scores"], tout["semantic_score"], B

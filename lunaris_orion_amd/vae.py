@@ -11,20 +11,43 @@ Drop-in contract (reference: /root/reference/lunar_generate.py):
     a single fused kernel and a data-parallel gradient exchange is one contiguous buffer); any
     optimizer that works on ``model.parameters()`` still works.
 
-The sub-modules are parameter containers only: ``forward`` never calls them.  It hands the flat
-parameter buffer to the native step executor (``lo_vae_forward`` / ``lo_vae_backward``), which
-enqueues every kernel of the pass on PyTorch's current HIP stream.  There is no PyTorch/CPU fallback:
-on a machine without the GPU library the import of ``_lib`` fails.
+``LunarisCoreVAE.forward`` hands the flat parameter buffer to the native step executor
+(``lo_vae_forward`` / ``lo_vae_backward``: one call each), which enqueues every kernel of the pass on
+PyTorch's current HIP stream.  ``model.encoder(x) -> (mu, logvar, skips)`` and ``model.decoder(z, skips)``
+(lunar_generate.py:127-153, 194-229, called in turn at :273-275 and with ``skips=[]`` at :290) are
+callable on their own as well: each is one native call (``lo_vae_encode`` / ``lo_vae_decode_skips``)
+with its own autograd node (``lo_vae_encoder_backward`` / ``lo_vae_decoder_backward``); the leaf
+modules below them (``Conv2d``, ``GroupNorm`` ...) are parameter containers.  Parameter updates made
+by a foreign optimizer (``torch.optim.AdamW(model.parameters())``) are noticed through the
+parameters' version counters: the fp16 operand copies are re-packed before the next forward without
+any call from the user.  There is no PyTorch/CPU fallback: on a machine without the GPU library the
+import of ``_lib`` fails.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Tuple
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+_LCG_A, _LCG_C, _M64 = 6364136223846793005, 1442695040888963407, 0xFFFFFFFFFFFFFFFF
+
+
+def lcg_advance(seed: int, n: int) -> int:
+    """`n` steps of the 64-bit LCG both counter-RNG streams advance by per call (noise of the reparameterisation, teacher dropout
+    masks), in O(log n): how a resumed run re-enters its streams at the position the checkpoint recorded."""
+    a, c, ra, rc = _LCG_A, _LCG_C, 1, 0          # (ra, rc) = the affine map composed so far; (a, c) = the map for 2**k steps
+    while n > 0:
+        if n & 1:
+            ra, rc = (ra * a) & _M64, (rc * a + c) & _M64
+        a, c = (a * a) & _M64, (c * a + c) & _M64
+        n >>= 1
+    return (seed * ra + rc) & _M64
+
 
 _ENC = ((3, 64), (64, 128), (128, 256), (256, 512))
 _DEC = ((512, 256), (256, 128), (128, 64), (64, 32))
@@ -107,8 +130,28 @@ class _SelfAttnFunction(torch.autograd.Function):
         return dx, dwq.view(s[0]), dbq.view(s[1]), dwk.view(s[2]), dbk.view(s[3]), dwv.view(s[4]), dbv.view(s[5]), dg
 
 
-class Encoder(nn.Module):
-    """Parameter container: 4 x (Conv k3 s2 -> GN -> Mish -> ResBlock), fc_mu, fc_logvar (lunar_generate.py:84-125)."""
+def _owner_of(mod: nn.Module) -> "LunarisCoreVAE":
+    ref = getattr(mod, "_owner", None)
+    owner = ref() if ref is not None else None
+    if owner is None:
+        raise _lib.LunarisHipError(f"{type(mod).__name__} runs through the LunarisCoreVAE that owns it (flat parameter buffer, native "
+                                   "plan); construct it as part of a LunarisCoreVAE")
+    return owner
+
+
+class _OwnedByVAE:
+    """Pickling / copying support for the sub-modules' weak back-reference to their LunarisCoreVAE (re-bound by the owner)."""
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_owner", None)
+        return d
+
+
+class Encoder(_OwnedByVAE, nn.Module):
+    """4 x (Conv k3 s2 -> GN -> Mish -> ResBlock), fc_mu, fc_logvar (lunar_generate.py:84-125).  ``forward(x) -> (mu, logvar,
+    skips)`` (:127-153) is one native call (``lo_vae_encode``); with gradients enabled it is an autograd node whose backward is
+    ``lo_vae_encoder_backward``."""
 
     def __init__(self, latent_dim: int = 256):
         super().__init__()
@@ -119,9 +162,21 @@ class Encoder(nn.Module):
         self.fc_mu = nn.Linear(512 * 8 * 8, latent_dim)
         self.fc_logvar = nn.Linear(512 * 8 * 8, latent_dim)
 
+    def forward(self, x: torch.Tensor):
+        vae = _owner_of(self)
+        vae._ensure_flat()
+        x = x.detach().contiguous().float()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            mu, logvar, s0, s1, s2 = _EncoderFunction.apply(vae, x, *self.parameters())
+        else:
+            mu, logvar, s0, s1, s2, _ = vae._native_encode(x)
+        return mu, logvar, [s0, s1, s2]
 
-class Decoder(nn.Module):
-    """Parameter container: fc, 4 x (ConvTranspose k4 s2 -> GN -> Mish), final_conv (lunar_generate.py:155-192)."""
+
+class Decoder(_OwnedByVAE, nn.Module):
+    """fc, 4 x (ConvTranspose k4 s2 -> GN -> Mish), final_conv (lunar_generate.py:155-192).  ``forward(z, skips)`` (:194-229, with
+    the reference's ``len(skips) >= k`` guards; ``skips=[]`` is the sampling call of :290) is one native call
+    (``lo_vae_decode_skips``); with gradients enabled it is an autograd node whose backward is ``lo_vae_decoder_backward``."""
 
     def __init__(self, latent_dim: int = 256):
         super().__init__()
@@ -130,6 +185,68 @@ class Decoder(nn.Module):
             setattr(self, f"up{i}", nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1),
                                                   nn.GroupNorm(8, cout), nn.Mish()))
         self.final_conv = nn.Conv2d(32, 3, kernel_size=3, padding=1)
+
+    def forward(self, z: torch.Tensor, skips: Sequence[torch.Tensor]):
+        vae = _owner_of(self)
+        vae._ensure_flat()
+        skips = list(skips)[:3]
+        needs_grad = torch.is_grad_enabled() and (z.requires_grad or any(t.requires_grad for t in skips)
+                                                  or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return _DecoderFunction.apply(vae, len(skips), z, *skips, *self.parameters())
+        return vae._native_decode(z, skips)[0]
+
+
+class _EncoderFunction(torch.autograd.Function):
+    """Encoder.forward / its backward as one native call each."""
+
+    @staticmethod
+    def forward(ctx, vae, x, *params):
+        mu, logvar, s0, s1, s2, eng = vae._native_encode(x)
+        ctx.vae, ctx.eng, ctx.nparam = vae, eng, len(params)
+        ctx.save_for_backward(x)
+        return mu, logvar, s0, s1, s2
+
+    @staticmethod
+    def backward(ctx, g_mu, g_lv, g0, g1, g2):
+        vae, eng = ctx.vae, ctx.eng
+        (x,) = ctx.saved_tensors
+        cont = lambda t: None if t is None else t.contiguous().float()
+        g_mu, g_lv, g0, g1, g2 = (cont(t) for t in (g_mu, g_lv, g0, g1, g2))
+        flat_g = torch.zeros_like(vae._flat)
+        _lib.check(_lib.lib.lo_vae_encoder_backward(eng.handle, x.data_ptr(), vae._flat.data_ptr(), eng.ws.data_ptr(), _lib.ptr(g_mu),
+                                                    _lib.ptr(g_lv), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(g2), float(vae.loss_scale),
+                                                    flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_encoder_backward")
+        grads = tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in vae._layout[:ctx.nparam])
+        return (None, None) + grads
+
+
+class _DecoderFunction(torch.autograd.Function):
+    """Decoder.forward / its backward as one native call each."""
+
+    @staticmethod
+    def forward(ctx, vae, n_skips, z, *rest):
+        skips, params = rest[:n_skips], rest[n_skips:]
+        recon, eng = vae._native_decode(z, skips)
+        ctx.vae, ctx.eng, ctx.n_skips, ctx.nparam = vae, eng, n_skips, len(params)
+        ctx.save_for_backward(recon)
+        return recon
+
+    @staticmethod
+    def backward(ctx, g_recon):
+        vae, eng, ns = ctx.vae, ctx.eng, ctx.n_skips
+        (recon,) = ctx.saved_tensors
+        g_recon = g_recon.contiguous().float()
+        B, dev = recon.shape[0], recon.device
+        flat_g = torch.zeros_like(vae._flat)
+        dz = torch.empty(B, vae.latent_dim, dtype=torch.float32, device=dev)
+        dsk = [torch.empty(B, 64 << k, 64 >> k, 64 >> k, dtype=torch.float32, device=dev) if k < ns else None for k in range(3)]
+        _lib.check(_lib.lib.lo_vae_decoder_backward(eng.handle, vae._flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(), g_recon.data_ptr(),
+                                                    float(vae.loss_scale), dz.data_ptr(), _lib.ptr(dsk[0]), _lib.ptr(dsk[1]), _lib.ptr(dsk[2]),
+                                                    flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_decoder_backward")
+        first = len(vae._layout) - ctx.nparam                    # the decoder's parameters are the tail of the state_dict order
+        grads = tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in vae._layout[first:])
+        return (None, None, dz) + tuple(dsk[:ns]) + grads
 
 
 class _Engine:
@@ -140,7 +257,7 @@ class _Engine:
         _lib.check(_lib.lib.lo_vae_create_ex(batch, latent_dim, flags, C.byref(self.handle)), "lo_vae_create_ex")
         self.batch, self.latent_dim, self.device = batch, latent_dim, device
         self.ws = torch.empty(_lib.lib.lo_vae_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
-        self.packed_version = -1
+        self.packed_version = None      # (explicit version, sum of the parameters' version counters) of the last pack
 
     def __del__(self):
         try:
@@ -189,12 +306,18 @@ class LunarisCoreVAE(nn.Module):
         self.latent_dim = latent_dim
         self.encoder = Encoder(latent_dim=latent_dim)
         self.decoder = Decoder(latent_dim=latent_dim)
+        for sub in (self.encoder, self.decoder):                 # not a registered attribute: no module cycle, nothing in state_dict
+            object.__setattr__(sub, "_owner", weakref.ref(self))
         self.loss_scale = 65536.0      # fp16 gradient range (the reference's GradScaler starts at 2**16 too)
         self._flat: Optional[torch.Tensor] = None
         self._layout: List[Tuple[int, int, torch.Size]] = []
         self._engines: Dict[Tuple[int, str], _Engine] = {}
         self._weights_version = 0      # bumped whenever the fp32 parameters may have changed
         self._seed: Optional[int] = None   # counter-RNG stream of the reparameterisation noise; derived at the first forward
+        self.noise_calls = 0               # forwards drawn from the stream so far (checkpointed: a resumed run continues the stream)
+        #: parity runs: N(0,1) noise [B, latent_dim] consumed by the NEXT forward that is not given `eps` explicitly (a caller whose
+        #: step calls `vae(images)` like train_hybrid.py:850 cannot pass it; the fixture generator patches `randn_like` the same way)
+        self.next_eps: Optional[torch.Tensor] = None
 
     # ---- flat parameter buffer ------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
@@ -209,8 +332,38 @@ class LunarisCoreVAE(nn.Module):
         return out
 
     def mark_weights_changed(self) -> None:
-        """Call after modifying parameters in place (optimizer step, manual edits): the fp16 operand copies are re-packed."""
+        """The fp16 operand copies are re-packed before the next forward.  Needed only after writing the flat buffer through a raw
+        pointer (the native optimizer step does that and calls this itself): in-place updates through the parameters — any
+        ``torch.optim`` optimizer, ``p.data.add_(...)``, ``p.copy_(...)`` under ``no_grad`` — bump the parameters' version counters,
+        which ``_engine`` checks."""
         self._weights_version += 1
+
+    def _params_version(self) -> int:
+        """Sum of the 72 parameters' autograd version counters: moves on every in-place update of any of them (the views of the
+        flat buffer keep their own counters, and `torch.optim.AdamW.step()` bumps them; tests/test_module_boundary_gpu.py)."""
+        return sum(p._version for p in self.parameters())
+
+    def _current_version(self):
+        """What `_Engine.packed_version` is compared with: (explicit counter, sum of the parameters' version counters)."""
+        return (self._weights_version, self._params_version())
+
+    # copies and pickles carry the parameters, not the native plans / flat buffer (rebuilt lazily), and get their own back-references
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_flat"], d["_layout"], d["_engines"] = None, [], {}
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for sub in (self.encoder, self.decoder):
+            object.__setattr__(sub, "_owner", weakref.ref(self))
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__({k: copy.deepcopy(v, memo) for k, v in self.__getstate__().items()})
+        return new
 
     def _ensure_flat(self) -> None:
         params = list(self.parameters())
@@ -255,9 +408,10 @@ class LunarisCoreVAE(nn.Module):
         if eng is None:
             eng = _Engine(batch, self.latent_dim, self._flat.device, self.MFMA_PRECISIONS[self.mfma_precision])
             self._engines[key] = eng
-        if eng.packed_version != self._weights_version:
+        version = self._current_version()
+        if eng.packed_version != version:
             _lib.check(_lib.lib.lo_vae_pack(eng.handle, self._flat.data_ptr(), eng.ws.data_ptr(), _lib.stream_ptr()), "lo_vae_pack")
-            eng.packed_version = self._weights_version
+            eng.packed_version = version
         return eng
 
     # ---- forward --------------------------------------------------------------------------
@@ -281,17 +435,55 @@ class LunarisCoreVAE(nn.Module):
             import torch.distributed as dist
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
             self._seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5EED + 0xD1B54A32D192ED03 * rank) & 0xFFFFFFFFFFFFFFFF
-        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            self._seed = lcg_advance(self._seed, self.noise_calls)       # > 0 after a resume: this rank's stream, same position
+        self._seed = (self._seed * _LCG_A + _LCG_C) & _M64
+        self.noise_calls += 1
         _lib.check(_lib.lib.lo_vae_forward(eng.handle, x.data_ptr(), _lib.ptr(eps), self._seed, self._flat.data_ptr(),
                                            eng.ws.data_ptr(), recon.data_ptr(), mu.data_ptr(), logvar.data_ptr(),
                                            _lib.ptr(target), _lib.stream_ptr()), "lo_vae_forward")
         return recon, mu, logvar, eng
+
+    def _native_encode(self, x: torch.Tensor):
+        """Encoder.forward (lunar_generate.py:127-153): mu, logvar, the three skip maps (fp32 NCHW) and the engine that holds the
+        activations."""
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
+            raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B, dev = x.shape[0], x.device
+        eng = self._engine(B)
+        mu = torch.empty(B, self.latent_dim, dtype=torch.float32, device=dev)
+        logvar = torch.empty_like(mu)
+        sk = [torch.empty(B, 64 << k, 64 >> k, 64 >> k, dtype=torch.float32, device=dev) for k in range(3)]
+        _lib.check(_lib.lib.lo_vae_encode(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), mu.data_ptr(),
+                                          logvar.data_ptr(), sk[0].data_ptr(), sk[1].data_ptr(), sk[2].data_ptr(), _lib.stream_ptr()),
+                   "lo_vae_encode")
+        return mu, logvar, sk[0], sk[1], sk[2], eng
+
+    def _native_decode(self, z: torch.Tensor, skips: Sequence[torch.Tensor]):
+        """Decoder.forward(z, skips) (lunar_generate.py:194-229) with 0..3 skip maps."""
+        z = z.detach().contiguous().float()
+        if z.dim() != 2 or z.shape[1] != self.latent_dim:
+            raise ValueError("z must have shape [B, latent_dim]")
+        B = z.shape[0]
+        sk = []
+        for k, t in enumerate(list(skips)[:3]):
+            if tuple(t.shape) != (B, 64 << k, 64 >> k, 64 >> k):
+                raise ValueError(f"skips[{k}] must have shape {(B, 64 << k, 64 >> k, 64 >> k)}, got {tuple(t.shape)}")
+            sk.append(t.detach().contiguous().float())
+        eng = self._engine(B)
+        recon = torch.empty(B, 3, 128, 128, dtype=torch.float32, device=z.device)
+        p = [_lib.ptr(sk[k]) if k < len(sk) else None for k in range(3)]
+        _lib.check(_lib.lib.lo_vae_decode_skips(eng.handle, z.data_ptr(), len(sk), p[0], p[1], p[2], self._flat.data_ptr(), eng.ws.data_ptr(),
+                                                recon.data_ptr(), _lib.stream_ptr()), "lo_vae_decode_skips")
+        return recon, eng
 
     def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
         """(reconstruction, mu, logvar), lunar_generate.py:263-276.  ``eps`` optionally injects the N(0,1) noise of
         ``reparameterize`` (parity runs); by default it is drawn on the device."""
         self._ensure_flat()
         x = x.detach().contiguous().float()
+        if eps is None and self.next_eps is not None:
+            eps, self.next_eps = self.next_eps, None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _VAEFunction.apply(self, x, eps, *self.parameters())
         recon, mu, logvar, _ = self._native_forward(x, eps, None)

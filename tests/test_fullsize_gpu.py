@@ -172,6 +172,37 @@ def test_teacher_train_batch64_sparse_equals_dense(tmp_path):
         assert d <= t * max(1.0, outs["1"][k].abs().max().item()), (k, d)
 
 
+def test_teacher_train_batch64_default_dropout_matches_the_oracle():
+    """The configuration BASELINE config 3 TIMES, checked directly: batch 64, train mode, the reference's default
+    dropout 0.1, default kernel selection -- every 3x3 convolution in full on the fused-tap kernel (`last_path == 2`), the
+    long-grid tile choices of the U / proj / pointwise GEMMs -- against the CPU oracle on the same masks (all 64 samples: train-mode
+    BatchNorm couples them; ~1 min of CPU), outputs and the running statistics the call leaves behind."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from oracle import dropout_ref as D
+    B, seed, p = B_FULL, 0x64640BADC0FFEE01, 0.1
+    S = T.closed_form_teacher_state(embedding_dim=256)
+    m = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256)            # dropout_rate 0.1, like train_hybrid.py:400-404
+    m.load_state_dict(S)
+    m = m.to("cuda").train()
+    m.set_dropout_stream(seed, exact_next=True)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    with torch.no_grad():
+        out = m(x.cuda())
+    torch.cuda.synchronize()
+    assert m.last_path(B) == 2 and m.last_drop_seed == seed
+    with torch.no_grad():
+        ref, new_stats = T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(seed, p, B))
+    tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}
+    for k, t in tol.items():
+        d = (out[k].cpu() - ref[k]).abs().max().item()
+        print("B=64 dropout", k, d)
+        assert d <= t, (k, d)
+    sd = m.state_dict()
+    for k in ("experts.3.2.conv2.2.running_mean", "experts.1.1.conv1.2.running_var", "feature_extractor.fusion.2.running_var"):
+        r = new_stats[k]
+        assert (sd[k].cpu() - r).abs().max().item() <= 2e-3 * max(1.0, r.abs().max().item()), k
+
+
 def test_config2_shape_batch32_latent256():
     """BASELINE config 2's exact shape (batch 32, latent 256, VAE-only): samples of the batch-32 forward equal the same samples
     run as a batch of 2 (which test_vae_gpu checks against the oracle and the reference fixture), the losses are the means of

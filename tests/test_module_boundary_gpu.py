@@ -1,0 +1,228 @@
+"""The nn.Module boundary as a foreign training loop sees it: a step that uses only `torch.optim`, `torch.nn.utils`
+and the two modules — nothing from `lunaris_orion_amd.trainer`, no `mark_weights_changed()` — must reproduce the trace the
+reference's own `TrainingManager._process_batch` produced (tests/golden/hybrid_loop_L256_B2.npz); `model.encoder(x)` /
+`model.decoder(z, skips)` are callable like the reference's sub-modules (lunar_generate.py:127-153, 194-229, 273-275, 290) and
+carry gradients; in-place parameter updates are noticed without help.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import teacher_ref as T
+from oracle import vae_ref as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _models(L):
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    vae = LunarisCoreVAE(L); vae.load_state_dict(R.closed_form_params(L)); vae = vae.to("cuda")
+    t = LunarMoETeacher(); t.load_state_dict(T.closed_form_teacher_state()); t = t.to("cuda").train()      # dropout_rate 0.1
+    return vae, t
+
+
+class _Loop:
+    """The state a TrainingManager keeps around `_process_batch` (train_hybrid.py:283-286, 502-527) and one method with the
+    statement order of train_hybrid.py:841-926 (its fp32 branch: no autocast, no GradScaler)."""
+
+    def __init__(self, vae, teacher, accum=1):
+        self.vae, self.teacher, self.accum = vae, teacher, accum
+        self.vae_opt = torch.optim.AdamW(vae.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
+        self.t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
+        sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts
+        self.vae_sched = sched(self.vae_opt, T_0=10, T_mult=2, eta_min=1e-6)
+        self.t_sched = sched(self.t_opt, T_0=10, T_mult=2, eta_min=1e-6)
+        self.baseline = None
+        self.recon_weight, self.kl_weight, self.quality_weight = 1.0, 0.1, 0.5
+        self.reward_scale, self.semantic_weight, self.momentum, self.max_grad_norm = 0.1, 0.5, 0.9, 1.0
+
+    def process_batch(self, images, batch_idx):
+        self.vae_opt.zero_grad(set_to_none=True)
+        self.t_opt.zero_grad(set_to_none=True)
+        images = images.detach().requires_grad_(True)
+        recon, mu, logvar = self.vae(images)
+        with torch.no_grad():
+            prompt = self.teacher(images)["prompt_embedding"]
+        recon_loss = F.mse_loss(recon, images, reduction="mean")
+        kl_loss = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+        ev = self.teacher(recon.detach(), prompt)
+        q, sem = ev["quality_scores"], ev["semantic_score"]
+        quality_reward = q.mean(dim=1, keepdim=True)
+        total_reward = quality_reward + self.semantic_weight * sem
+        tr = total_reward.mean().item()
+        self.baseline = tr if self.baseline is None else self.momentum * self.baseline + (1 - self.momentum) * tr
+        advantage = (total_reward - self.baseline).detach() * self.reward_scale
+        pg_loss = -(advantage * recon_loss).mean()
+        vae_loss = (self.recon_weight * recon_loss + self.kl_weight * kl_loss + pg_loss) / self.accum
+        quality_loss = -torch.mean(q)
+        teacher_loss = self.quality_weight * quality_loss / self.accum
+        vae_loss.backward()
+        teacher_loss.backward()
+        if (batch_idx + 1) % self.accum == 0:
+            torch.nn.utils.clip_grad_norm_(self.vae.parameters(), self.max_grad_norm)
+            torch.nn.utils.clip_grad_norm_(self.teacher.parameters(), self.max_grad_norm)
+            self.vae_opt.step()
+            self.t_opt.step()
+            self.vae_sched.step()
+            self.t_sched.step()
+        return {"recon_loss": recon_loss.item(), "kl_loss": kl_loss.item(), "quality_loss": quality_loss.item(), "pg_loss": pg_loss.item(),
+                "semantic_reward": sem.mean().item(), "quality_reward": quality_reward.mean().item(), "baseline": self.baseline,
+                "advantage": advantage.mean().item(), "vae_loss": vae_loss.item(), "teacher_loss": teacher_loss.item(),
+                "total_loss": vae_loss.item() + teacher_loss.item(), "quality_scores": q.mean().item()}
+
+
+def test_a_reference_shaped_step_with_torch_optimizers_matches_the_references_trace():
+    g = np.load(os.path.join(GOLD, "hybrid_loop_L256_B2.npz"))
+    cols, trace, seeds = [str(c) for c in g["cols"]], g["trace"], [int(v) for v in g["call_seeds"]]
+    L, B, steps = (int(v) for v in g["meta"])
+    vae, t = _models(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    t.set_dropout_stream(seeds[0], exact_next=True)
+    loop = _Loop(vae, t)
+    tol = {"recon_loss": ("rel", 2e-4), "kl_loss": ("rel", 2e-4), "vae_loss": ("rel", 1e-3), "pg_loss": ("abs", 5e-4), "advantage": ("abs", 5e-4)}
+    for s in range(steps):
+        vae.next_eps = R.closed_form_eps(B, L, salt=s).cuda()       # what the fixture injected through randn_like
+        m = loop.process_batch(x.clone(), s)
+        assert t.last_drop_seed == seeds[2 * s + 1] and t.last_path(B) == 2
+        for j, c in enumerate(cols):
+            kind, lim = tol.get(c, ("abs", 3e-3))
+            err = abs(m[c] - trace[s, j]) / (abs(trace[s, j]) if kind == "rel" else 1.0)
+            assert err <= lim, (s, c, m[c], trace[s, j])
+    with_grad = sum(1 for p in t.parameters() if p.grad is not None)
+    assert with_grad == int(g["teacher_params_with_grad"]) == 28
+    np.testing.assert_allclose(t.gate[2].weight.detach().cpu().numpy()[:4, :8], g["gate_w_after"], atol=2e-4)
+    np.testing.assert_allclose(vae.encoder.fc_mu.bias.detach().cpu().numpy()[:16], g["vae_fc_mu_b_after"], atol=2e-4)
+    assert abs(loop.vae_opt.param_groups[0]["lr"] - float(g["lr_after"])) <= 1e-12
+
+
+def test_teacher_outputs_carry_a_graph_over_gate_and_quality_heads():
+    """`quality_scores` / `expert_weights` as differentiable outputs: arbitrary upstream gradients vs autograd of the oracle on the
+    same dropout masks, also after a LATER forward call has overwritten the workspace (the node keeps its own head inputs)."""
+    from oracle import dropout_ref as D
+    B, seed, p = 2, 0x1234ABCD5678EF01, 0.1
+    _, t = _models(256)
+    S = T.closed_form_teacher_state()
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    t.set_dropout_stream(seed, exact_next=True)
+    out = t(x.cuda())
+    assert out["quality_scores"].requires_grad and out["expert_weights"].requires_grad and not out["semantic_score"].requires_grad
+    gq = torch.linspace(-1.0, 1.0, B * 4).view(B, 4)
+    gw = torch.linspace(0.5, -0.25, B * 4).view(B, 4)
+    with torch.no_grad():
+        t(torch.flip(x, dims=[0]).cuda())                 # another forward in between: different pooled features, another seed
+    ((out["quality_scores"] * gq.cuda()).sum() + (out["expert_weights"] * gw.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    S2 = {k: (v.clone().requires_grad_(True) if (k.startswith("gate.") or k.startswith("quality_heads.")) else v) for k, v in S.items()}
+    o, _ = T.teacher_forward(x, S2, training=True, masks=D.TeacherMasks(seed, p, B))
+    ((o["quality_scores"] * gq).sum() + (o["expert_weights"] * gw).sum()).backward()
+    n = 0
+    for k, prm in t.named_parameters():
+        if k.startswith("gate.") or k.startswith("quality_heads."):
+            ref = S2[k].grad
+            assert prm.grad is not None, k
+            assert (prm.grad.cpu() - ref).norm().item() / (ref.norm().item() + 1e-12) <= 2e-2, k
+            n += 1
+        else:
+            assert prm.grad is None, k
+    assert n == 28
+    with torch.no_grad():
+        assert not t(x.cuda())["quality_scores"].requires_grad
+
+
+def test_encoder_and_decoder_are_callable_like_the_references_submodules():
+    """mu, logvar, skips = model.encoder(x); recon = model.decoder(z, skips) (lunar_generate.py:273-275) equals model(x) on the same
+    noise bit for bit; the skip list has the reference's shapes and matches the oracle; `decoder(z, [])` is the sampling call."""
+    L, B = 256, 2
+    vae, _ = _models(L)
+    P = R.closed_form_params(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    eps = R.closed_form_eps(B, L, salt=0)
+    with torch.no_grad():
+        recon_ref, mu_ref, lv_ref = vae(x.cuda(), eps.cuda())
+        mu, logvar, skips = vae.encoder(x.cuda())
+        assert torch.equal(mu, mu_ref) and torch.equal(logvar, lv_ref)
+        assert [tuple(s.shape) for s in skips] == [(B, 64, 64, 64), (B, 128, 32, 32), (B, 256, 16, 16)]
+        z = mu + eps.cuda() * torch.exp(0.5 * logvar)
+        recon = vae.decoder(z, skips)
+        # the fused forward forms z in fp32 and rounds it to fp16 exactly like lo_vae_decode_skips does with this z
+        assert (recon - recon_ref).abs().max().item() <= 2e-3
+        _, _, skips_o = R.encoder_forward(x, P)
+        for k in range(3):
+            assert (skips[k].cpu() - skips_o[k]).abs().max().item() <= 2e-2 * max(1.0, skips_o[k].abs().max().item())
+        r1_o = R.decoder_forward(z.cpu(), skips_o[:1], P)
+        r0 = vae.decoder(z, [])
+        assert torch.equal(r0, vae.decode(z))
+        r1 = vae.decoder(z, skips[:1])                    # only skips[0] is added (after up3)
+        assert not torch.equal(r1, r0) and not torch.equal(r1, recon)
+        assert (r1.cpu() - r1_o).abs().max().item() <= 5e-3
+    r_ref, mu_o, lv_o = R.vae_forward(x, eps, P)
+    assert (mu.cpu() - mu_o).abs().max().item() <= 5e-3 and (recon.cpu() - r_ref).abs().max().item() <= 5e-3
+
+
+def test_gradients_through_separately_called_encoder_and_decoder_match_the_fused_module():
+    """loss(model.decoder(reparam(model.encoder(x)))) back-propagated through the two autograd nodes gives the gradients of
+    loss(model(x)) (one node) for all 72 parameters, and both match the oracle's gradients of the golden fixture."""
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+
+    def loss_of(recon, mu, logvar):
+        return F.mse_loss(recon, x) + 0.1 * (-0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp()))
+
+    vae_a, _ = _models(L)
+    loss_of(*vae_a(x, eps)).backward()
+    vae_b, _ = _models(L)
+    mu, logvar, skips = vae_b.encoder(x)
+    z = mu + eps * torch.exp(0.5 * logvar)
+    loss_of(vae_b.decoder(z, skips), mu, logvar).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (k, pa), (_, pb) in zip(vae_a.named_parameters(), vae_b.named_parameters()):
+        assert pa.grad is not None and pb.grad is not None, k
+        err = (pa.grad - pb.grad).norm().item() / (pa.grad.norm().item() + 1e-20)
+        worst = max(worst, err)
+        assert err <= 2e-2, (k, err)          # z / skip gradients cross the module boundary in fp32 <-> fp16: not bitwise
+    print("worst relative difference split vs fused:", worst)
+    # ... and the oracle's autograd of the same loss
+    P = {k: v.clone().requires_grad_(True) for k, v in R.closed_form_params(L).items()}
+    r_o, mu_o, lv_o = R.vae_forward(x.cpu(), eps.cpu(), P)
+    (F.mse_loss(r_o, x.cpu()) + 0.1 * (-0.5 * torch.mean(1 + lv_o - mu_o.pow(2) - lv_o.exp()))).backward()
+    for k, pb in vae_b.named_parameters():
+        ref = P[k].grad
+        assert (pb.grad.cpu() - ref).norm().item() / (ref.norm().item() + 1e-20) <= 3e-2, k
+
+
+def test_foreign_in_place_updates_are_noticed_without_mark_weights_changed():
+    """`torch.optim.AdamW(model.parameters()).step()` (train_hybrid.py:916-923) and manual in-place edits move the parameters'
+    version counters; the next forward re-packs the fp16 operand copies by itself: outputs equal those of a fresh module holding
+    the same parameters."""
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    L, B = 256, 2
+    vae, _ = _models(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    opt = torch.optim.AdamW(vae.parameters(), lr=1e-4)
+    recon, mu, logvar = vae(x, eps)
+    (F.mse_loss(recon, x) + 0.1 * mu.pow(2).mean()).backward()
+    v0 = vae._params_version()
+    opt.step()
+    assert vae._params_version() > v0
+    with torch.no_grad():
+        r_after_step, mu_after_step, _ = vae(x, eps)        # the optimizer's update alone is seen ...
+        assert (mu_after_step - mu).abs().max().item() > 1e-5
+        vae.decoder.final_conv.bias.add_(0.05)              # ... and so are manual in-place edits
+        vae.encoder.down2[0].weight.mul_(1.01)
+        r_stale_check, mu1, _ = vae(x, eps)
+        assert (r_stale_check - r_after_step).abs().max().item() > 1e-3
+    fresh = LunarisCoreVAE(L)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in vae.state_dict().items()})
+    fresh = fresh.to("cuda")
+    with torch.no_grad():
+        r2, mu2, _ = fresh(x, eps)
+    assert torch.isfinite(r2).all() and torch.isfinite(mu2).all()
+    assert torch.equal(mu1, mu2) and torch.equal(r_stale_check, r2)

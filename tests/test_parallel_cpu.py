@@ -44,9 +44,20 @@ def _worker(rank, world, port, q):
     direct.begin(flat_direct)
     direct.finish()
     assert direct.bytes_per_phase() == [4 * flat_direct.numel()]
+    # the product's hand-over pattern: three ranges handed over one after the other (tail of the buffer first, like the phased
+    # backward does), fp16 wire, then one finish(); every range complete and equal to the all-reduce average to fp16 rounding
+    o2 = R.OracleTrainer(P).step(xs, es, 0.0, do_update=False)
+    flat16 = torch.cat([g.flatten() for g in o2["grads"].values()])
+    n = flat16.numel()
+    b1, b2 = (n // 10) * 3 + 1, (n // 10) * 1 + 3                # odd boundaries: remainder paths in every range
+    d16 = FlatGradSync(mode="direct", compress_fp16=True)
+    d16.begin(flat16[b1:]); d16.begin(flat16[b2:b1]); d16.begin(flat16[:b2])
+    d16.finish()
+    assert d16.bytes_per_phase() == [2 * (n - b1), 2 * (b1 - b2), 2 * b2]
     # plain Python objects only (tensors through a spawn-context Queue need the producer to stay alive)
     res = {"sum": flat.double().sum().item(), "l2": flat.double().norm().item(),
            "direct_vs_allreduce": (flat_direct - flat[:-1]).abs().max().item(),
+           "direct16_rel": ((flat16 - flat).norm() / flat.norm()).item(), "direct16_sum": flat16.double().sum().item(),
            "lr": [cosine_warm_restarts_lr(1e-4, 1e-6, 10, 2, k) for k in range(40)]}
     if rank == 0:
         full = R.OracleTrainer(P).step(x, eps, 0.0, do_update=False)
@@ -74,6 +85,10 @@ def test_flat_grad_sync_equals_global_batch_gradient():
     assert out[0]["lr"] == out[1]["lr"]
     # the all-to-all reduce-scatter + all-gather form gives the same average (sum order differs: fp32 rounding only)
     assert max(out[0]["direct_vs_allreduce"], out[1]["direct_vs_allreduce"]) <= 1e-7
+    # three hand-over ranges on the fp16 wire: identical on both ranks, equal to the fp32 average to fp16 rounding (2^-11 relative
+    # per element before the fp32 share sum)
+    assert out[0]["direct16_sum"] == out[1]["direct16_sum"]
+    assert max(out[0]["direct16_rel"], out[1]["direct16_rel"]) <= 1e-3, (out[0]["direct16_rel"], out[1]["direct16_rel"])
 
 
 def test_shard_batch_partitions_without_overlap():

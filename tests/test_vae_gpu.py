@@ -339,7 +339,8 @@ L, B = 256, 2
 P = R.closed_form_params(L)
 x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
 out = []
-for sync in (None, FlatGradSync(force=True), FlatGradSync(force=True, compress_fp16=True), FlatGradSync(force=True, mode="direct", time_exposed=True)):
+for sync in (None, FlatGradSync(force=True), FlatGradSync(force=True, compress_fp16=True), FlatGradSync(force=True, mode="direct", time_exposed=True),
+             FlatGradSync(force=True, mode="direct", compress_fp16=True, time_exposed=True)):
     m = LunarisCoreVAE(L); m.load_state_dict(P); m = m.to("cuda")
     st = VAEStepper(m, grad_sync=sync)
     for s in range(2):
@@ -352,7 +353,10 @@ assert abs(out[0]["recon_loss"] - out[1]["recon_loss"]) <= 1e-5 and abs(out[0]["
 assert abs(out[0]["recon_loss"] - out[2]["recon_loss"]) < 1e-4, out
 # the all-to-all reduce-scatter + all-gather form (RCCL all_to_all_single / all_gather_into_tensor on the three hand-over ranges)
 assert abs(out[0]["recon_loss"] - out[3]["recon_loss"]) <= 1e-5 and abs(out[0]["grad_norm"] - out[3]["grad_norm"]) <= 1e-5 * out[0]["grad_norm"], out
-assert sync.exposed_ms_per_step() is not None and len(sync.bytes_per_phase()) == 3 and sum(sync.bytes_per_phase()) == 4 * m.flat_parameters().numel()
+# ... and the default of an N > 1 run: the same on the fp16 wire (pack / share sum / unpack by the library's kernels, every range chained
+# on the communication stream)
+assert abs(out[0]["recon_loss"] - out[4]["recon_loss"]) < 1e-4 and abs(out[0]["grad_norm"] - out[4]["grad_norm"]) <= 2e-3 * out[0]["grad_norm"], out
+assert sync.exposed_ms_per_step() is not None and len(sync.bytes_per_phase()) == 3 and sum(sync.bytes_per_phase()) == 2 * m.flat_parameters().numel()
 # the hybrid step under data parallelism: gradient ranges of both models + the 5-float reward-mean exchange
 from oracle import teacher_ref as T
 from lunaris_orion_amd.teacher import LunarMoETeacher

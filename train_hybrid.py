@@ -2,7 +2,8 @@
 """`train_hybrid.py` for the MI355X-native build: the reference CLI (same 35 flags, same defaults:
 /root/reference/train_hybrid.py:1076-1133) driving the native VAE step (lunaris_orion_amd.trainer.VAEStepper).
 
-What is the same: flags/defaults (the five dead flags are accepted and ignored like in the reference), seeds
+What is the same: flags/defaults (the dead flags are accepted; `--save_every` / `--keep_n_checkpoints`, which the reference parses
+and never reads, are honoured: periodic `checkpoints/step_<N>.pt`, the newest N kept), seeds
 (:1138-1141), the dataset contract (`sprites*.npy` uint8 (N,128,128,3) + `labels*.csv`, :100-201), 90/10 split with
 drop_last (:551-569), the step semantics of `_process_batch` (:838-954) including its accumulation rule, the 12 metric
 names (:929-942), the checkpoint dictionary keys (:596-606), SIGINT -> checkpoint (:587-592).
@@ -60,9 +61,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--kl_weight", type=float, default=0.1)
     p.add_argument("--quality_weight", type=float, default=0.5)
     p.add_argument("--log_every", type=int, default=100)
-    p.add_argument("--save_every", type=int, default=1000)               # dead in the reference
+    p.add_argument("--save_every", type=int, default=1000)               # dead in the reference; honoured here: checkpoints/step_<N>.pt every N steps
     p.add_argument("--sample_every", type=int, default=500)              # dead in the reference
-    p.add_argument("--keep_n_checkpoints", type=int, default=5)          # dead in the reference
+    p.add_argument("--keep_n_checkpoints", type=int, default=5)          # dead in the reference; honoured here: the newest N step_<N>.pt files are kept
     p.add_argument("--early_stopping_patience", type=int, default=7)
     p.add_argument("--eval_save_freq", type=int, default=500)
     p.add_argument("--reward_scale", type=float, default=0.1)
@@ -107,7 +108,10 @@ def main(argv=None):
         # nccl = RCCL over xGMI; LO_DIST_BACKEND=gloo rehearses the multi-rank control flow with several ranks on one GPU
         dist.init_process_group(os.environ.get("LO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
         from lunaris_orion_amd.parallel import FlatGradSync
-        grad_sync = FlatGradSync()
+        # the xGMI-shaped exchange (all-to-all reduce-scatter + all-gather, fp16 wire) behind the backward; LO_DP_EXCHANGE=allreduce:
+        # one RCCL all-reduce per hand-over range on the fp32 wire (DP == single process to fp32 rounding)
+        dp_mode = os.environ.get("LO_DP_EXCHANGE", "direct")
+        grad_sync = FlatGradSync(mode=dp_mode, compress_fp16=dp_mode == "direct")
 
     out_dir = Path(args.output_dir)
     (out_dir / "checkpoints").mkdir(parents=True, exist_ok=True)
@@ -196,6 +200,11 @@ def main(argv=None):
                         writer.add_scalar(k, v, global_step)
                 log.info(f"step {global_step} loss {metrics['total_loss']:.4f} recon {metrics['recon_loss']:.4f} "
                          f"kl {metrics['kl_loss']:.4f} lr {m['lr']:.2e} grad_norm {m['grad_norm']:.3f}")
+            if args.save_every > 0 and global_step % args.save_every == 0:                 # train_hybrid.py:1113,1115 (dead flags there)
+                save_checkpoint(f"step_{global_step}")
+                if rank == 0:
+                    for gone in hostside.prune_periodic_checkpoints(out_dir / "checkpoints", args.keep_n_checkpoints):
+                        log.debug(f"removed old periodic checkpoint {gone.name}")
             if rank == 0 and global_step % args.eval_save_freq == 0:                       # train_hybrid.py:951-952
                 recon = stepper.last[0]
                 tout = getattr(stepper, "last_teacher_out", None)
