@@ -200,6 +200,12 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
                     int fused, const float* drecon, const float* gmu, const float* glv, float loss_scale,
                     float* flat_grads, void* stream);
 
+/* GroupNorm + Mish run inside the producing convolution's epilogue wherever the kernel that owns the layer supports it (the
+ * workgroups holding one sample's tiles exchange their partial sums through the workspace and wait for each other; csrc/lo_common.h,
+ * LoGnFuse): fused_layers = how many of the 16 conv + GroupNorm layers of this plan do so.  The wait is bounded: byte_offset names a
+ * 32-bit word of the workspace that a workgroup sets to 1 if its wait ran out (results of that step are then invalid); the host
+ * reads it with the step's metrics.  No reference counterpart (aten::native_group_norm is a separate op there). */
+int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* fused_layers);
 /* where lo_vae_forward left an intermediate tensor inside the workspace (fp16 NHWC; dims4 = B, H, W, C), for parity tests
  * against the reference's hooked module outputs (lunar_generate.py:94-120, 168-190): which 0 = raw encoder conv output
  * (stage s, k = 0 strided conv, 1 / 2 ResBlock convs), 1 = raw decoder transposed-conv output, 2 = encoder stage (ResBlock)

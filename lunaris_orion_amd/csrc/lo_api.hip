@@ -194,6 +194,16 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   // fp8 operand mode (LO_VAE_FP8_FWD): e4m3 weights + per-row scales of the forward op, e4m3 copy of the activation o_a
   bool f8;                   // this layer's forward conv runs on e4m3 operands
   size_t o_wp8, o_wscale, o_a8;   // o_a8 = 0: no consumer needs the copy
+  // GroupNorm + Mish fused into the forward conv's epilogue (LoGnFuse, lo_common.h): exchange lines, arrival counters, and how many
+  // launches have used them (the counters are monotonic: launch k leaves them at k * tiles per sample)
+  bool gnf; int gnf_mts, gnf_nt;
+  size_t o_xbuf, o_xcnt;
+  unsigned gnf_epoch;
+  // GroupNorm-backward APPLY fused into the data-gradient epilogue of the layer that CONSUMES this layer's activation (LoGnBwdFuse):
+  // arrival counters [B][8], launches so far, and -- per backward -- whether o_dv / P2 were already produced that way
+  size_t o_bcnt;
+  unsigned gba_epoch;
+  bool dv_done; int np2;
 };
 
 struct Arena {
@@ -253,6 +263,10 @@ struct LoVae {
   bool overlap;
   float* norm_scratch;   // lo_vae_set_gradnorm_scratch: where a single-call backward leaves the early part of the gradient norm
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
+  bool fuse_gnf;      // fuse GroupNorm + Mish of a conv output into that conv's epilogue (sample rendezvous between its workgroups)
+  bool fuse_gna;      // fuse the GroupNorm-backward APPLY pass into the data-gradient epilogue that already carries its reduction
+  size_t o_sync_fail; // one word: set by a workgroup whose rendezvous poll ran out (never, unless a launch was lost)
+  const void* sync_for_ws;
   // fp8 operand mode of the forward convs (lo_vae_create_ex flag LO_VAE_FP8_FWD)
   bool fp8_fwd;
   size_t o_eout8[4], o_h08, o_packjobs8;
@@ -287,10 +301,15 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   int p1rows = nchunk > (c.Ho * c.Wo) / 64 ? nchunk : (c.Ho * c.Wo) / 64;   // >= tiles per sample of any data-gradient epilogue
   c.np1 = 0;
   c.o_P1 = ar.take((size_t)B * p1rows * Cout * 2 * 4);
-  c.o_P2 = ar.take((size_t)B * nchunk * Cout * 4);
+  c.o_P2 = ar.take((size_t)B * p1rows * Cout * 4);     // nchunk rows (lo_gn_bwd_apply) or one row per tile (fused apply)
   c.o_dv = ar.take(act);
   c.f8 = false;
   c.o_wp8 = c.o_wscale = c.o_a8 = 0;
+  c.gnf = false; c.gnf_mts = c.gnf_nt = 0; c.gnf_epoch = 0;
+  c.o_xbuf = ar.take((size_t)B * LO_GNF_MAX_TILES * 128);
+  c.o_xcnt = ar.take((size_t)B * 4);
+  c.o_bcnt = ar.take((size_t)B * 8 * 4);
+  c.gba_epoch = 0; c.dv_done = false; c.np2 = 0;
   return LO_OK;
 }
 
@@ -422,6 +441,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->o_slab_dz = ar.take((size_t)h->dfcd_split * B * L * 4);
   h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
+  h->o_sync_fail = ar.take(256);
   // ---- fp8 operand mode: every forward conv whose geometry the e4m3 igemm covers (Cin % 128 == 0: the 128 / 256 / 512
   // channel ResBlock and stride-2 convs, the 512 / 256 / 128 channel transposed convs) reads an e4m3 copy of its input,
   // written by the kernel that produces the fp16 activation (which the backward still uses)
@@ -459,6 +479,20 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   // was not bitwise reproducible while a weight-gradient kernel ran beside it (tools/gnb_det.py: 1365 mismatching tensors
   // in 24 runs; 0 with this form) -- the determinism tests of tests/test_fullsize_gpu.py and test_vae_gpu.py guard it
   h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
+  // GroupNorm + Mish in the conv epilogue (LO_GN_FUSE=0: the separate lo_gn_fwd pass after every conv).  Which layers qualify is a
+  // property of the kernel lo_conv_run picks for the geometry (lo_conv_gn_fuse_tiles); the fp8 operand mode keeps the separate
+  // pass (it also writes the e4m3 copy of the activation).
+  h->fuse_gnf = !(getenv("LO_GN_FUSE") && atoi(getenv("LO_GN_FUSE")) == 0) && !h->fp8_fwd;
+  // ... and the backward's apply pass in the data-gradient epilogue of the consuming layer (LO_GNB_APPLY_FUSE=0: separate
+  // lo_gn_bwd_apply launches); needs the fused reduction
+  h->fuse_gna = h->fuse_gnb && !(getenv("LO_GNB_APPLY_FUSE") && atoi(getenv("LO_GNB_APPLY_FUSE")) == 0);
+  h->sync_for_ws = nullptr;
+  {
+    auto plan = [&](ConvLayer& c, bool first) {
+      c.gnf = h->fuse_gnf && !first && lo_conv_gn_fuse_tiles(c.gf, &c.gnf_mts, &c.gnf_nt);
+    };
+    for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) plan(h->enc[s][k], s == 0 && k == 0); plan(h->dec[s], false); }
+  }
   if (h->overlap) {
     // The side stream carries work that has slack (weight gradients, the tail of the optimizer step, operand refresh); the
     // caller's stream carries the dependent chain that decides the step time.  Lowest queue priority for the side stream: when both
@@ -521,6 +555,18 @@ extern "C" int lo_vae_debug_tensor(const LoVae* h, int which, int s, int k, size
   LO_REQUIRE(c, "lo_vae_debug_tensor: unknown tensor kind %d", which);
   *byte_offset = which == 2 ? h->o_eout[s] : (which == 3 ? c->o_a : c->o_v);
   dims4[0] = h->B; dims4[1] = c->Ho; dims4[2] = c->Wo; dims4[3] = c->Cout;
+  return LO_OK;
+}
+
+// byte offset (inside the workspace) of the word a fused-GroupNorm workgroup sets when its rendezvous poll ran out; 0 = never
+extern "C" int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* fused_layers) {
+  LO_REQUIRE(h && byte_offset, "lo_vae_sync_fail_word: null argument");
+  *byte_offset = h->o_sync_fail;
+  if (fused_layers) {
+    int n = 0;
+    for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) n += h->enc[s][k].gnf ? 1 : 0; n += h->dec[s].gnf ? 1 : 0; }
+    *fused_layers = n;
+  }
   return LO_OK;
 }
 
@@ -771,6 +817,22 @@ extern "C" int lo_vae_join(LoVae* h, void* stream) {
   return LO_OK;
 }
 
+// The arrival counters of the fused GroupNorm epilogues live in the caller's workspace: zero them (and the failure word) the first
+// time a workspace is seen; from then on they only ever count up (ConvLayer::gnf_epoch follows them on the host).
+static int vae_ensure_sync_init(LoVae* h, void* ws, hipStream_t st) {
+  if (h->sync_for_ws == ws) return LO_OK;
+  auto zero = [&](ConvLayer& c) -> int {
+    LO_HIP(hipMemsetAsync(WSP(void, c.o_xcnt), 0, (size_t)h->B * 4, st));
+    LO_HIP(hipMemsetAsync(WSP(void, c.o_bcnt), 0, (size_t)h->B * 8 * 4, st));
+    c.gnf_epoch = 0; c.gba_epoch = 0;
+    return LO_OK;
+  };
+  for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) LO_TRY(zero(h->enc[s][k])); LO_TRY(zero(h->dec[s])); }
+  LO_HIP(hipMemsetAsync(WSP(void, h->o_sync_fail), 0, 256, st));
+  h->sync_for_ws = ws;
+  return LO_OK;
+}
+
 // in8: e4m3 copy of `in` (fp8 mode, layers with c.f8); y8: where to leave the e4m3 copy of y (0 = nobody reads it)
 // xprod: the conv+GN+Mish layer (plain mode) whose GroupNorm + Mish this conv applies on load; `in` is then its raw output o_v and
 //        its activation o_a / statistics are written by this launch (lo_conv3x3_pp<XF = 2>)
@@ -792,6 +854,18 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
     g_lo_prof_tag = tg;
   }
   int r_;
+  // GroupNorm + Mish inside the conv's own epilogue (the workgroups of a sample exchange their sums: LoGnFuse) where the kernel that
+  // owns this geometry supports it; the separate lo_gn_fwd pass below is then not run.  Same statistics, same arithmetic, same bits.
+  const bool fuse = c.gnf && !c.f8 && !xprod && !defer_gn && !o_y8;
+  LoGnFuse gf;
+  if (fuse) {
+    memset(&gf, 0, sizeof(gf));
+    gf.xbuf = WSP(float, c.o_xbuf); gf.counter = WSP(unsigned int, c.o_xcnt);
+    gf.MTs = c.gnf_mts; gf.NT = c.gnf_nt;
+    gf.target = (++c.gnf_epoch) * (unsigned)(c.gnf_mts * c.gnf_nt);
+    gf.gamma = PRM(c.p_gw); gf.beta = PRM(c.p_gb); gf.other = other; gf.y = y; gf.stats = WSP(float, c.o_stats); gf.mode = mode;
+    gf.fail = WSP(unsigned int, h->o_sync_fail);
+  }
   if (c.f8) {
     LO_REQUIRE(o_in8, "fp8 mode: no e4m3 copy of the input of a conv %d->%d", c.Cin, c.Cout);
     r_ = lo_conv_run_f8(c.gf, WSP(uint8_t, o_in8), WSP(uint8_t, c.o_wp8), WSP(float, c.o_wscale), PRM(c.p_b), nullptr, WSP(f16, c.o_v),
@@ -801,11 +875,12 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
     r_ = lo_conv_run(c.gf, WSP(f16, xprod->o_v), WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st,
                      nullptr, nullptr, &xg);
   } else {
-    r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st);
+    r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), fuse ? nullptr : WSP(float, c.o_part), nullptr, 1, st,
+                     nullptr, nullptr, nullptr, fuse ? &gf : nullptr);
   }
   g_lo_prof_tag = nullptr;
-  if (r_ != LO_OK) return r_;
-  if (defer_gn) return LO_OK;
+  if (r_ != LO_OK) { if (fuse) --c.gnf_epoch; return r_; }
+  if (defer_gn || fuse) return LO_OK;
   return lo_gn_fwd(WSP(f16, c.o_v), WSP(float, c.o_part), c.MT, PRM(c.p_gw), PRM(c.p_gb), other, y, WSP(float, c.o_stats), h->B,
                    c.Ho * c.Wo, c.Cout, mode, st, o_y8 ? WSP(uint8_t, o_y8) : nullptr);
 }
@@ -816,6 +891,7 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
 static int vae_decoder_forward(LoVae* h, const f16* const skips[3], const float* P, void* ws, float* recon, const float* target,
                                hipStream_t st) {
   const int B = h->B;
+  LO_TRY(vae_ensure_sync_init(h, ws, st));
   LO_TRY(vae_wait_level(h, st, 4));
   LO_TRY(lo_conv_run(h->g_dfc, WSP(f16, h->o_z), WSP(f16, h->o_wp_dfc), PRM(h->idx_dfc_b), nullptr, WSP(f16, h->o_yfc), nullptr,
                      nullptr, 1, st));
@@ -854,6 +930,7 @@ extern "C" int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64
 static int vae_encoder_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* P, void* ws, float* mu,
                                float* logvar, hipStream_t st) {
   const int B = h->B, L = h->L;
+  LO_TRY(vae_ensure_sync_init(h, ws, st));
   // ---- encoder (lunar_generate.py:127-153)
   const f16* cur = nullptr;
   size_t cur8 = 0;
@@ -964,8 +1041,11 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   const int k = h->bwd_layer++;
   f16* dv = WSP(f16, c.o_dv);
   const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
-  LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
-                           WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
+  // c.dv_done: the data gradient of the consuming layer has already turned this layer's activation gradient into dv (and P2) in
+  // its epilogue -- `dy` was never stored
+  if (!c.dv_done)
+    LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
+                             WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
   if (ov) {
     LO_HIP(hipEventRecord(h->ev_dv[k & 1], st));
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[k & 1], 0));
@@ -986,6 +1066,15 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       gb.v = WSP(f16, prod->o_v); gb.stats = WSP(float, prod->o_stats); gb.gamma = PRM(prod->p_gw); gb.beta = PRM(prod->p_gb);
       gb.P1 = WSP(float, prod->o_P1);
       prod->np1 = lo_conv_gnb_rows(c.gd);
+      int mts = 0, nt = 0;
+      if (h->fuse_gna && lo_conv_gnb_apply_tiles(c.gd, &mts, &nt) && mts == prod->np1) {
+        gb.dv = WSP(f16, prod->o_dv); gb.P2 = WSP(float, prod->o_P2);
+        gb.counter = WSP(unsigned int, prod->o_bcnt);
+        gb.target = (++prod->gba_epoch) * (unsigned)mts;
+        gb.fail = WSP(unsigned int, h->o_sync_fail);
+        prod->dv_done = true;
+        prod->np2 = mts;
+      }
       gbp = &gb;
     }
     static char dtag[32][64];
@@ -995,7 +1084,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
     }
     int r_ = lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st, gbp);
     g_lo_prof_tag = nullptr;
-    if (r_ != LO_OK) return r_;
+    if (r_ != LO_OK) { if (gbp && gbp->dv) { --prod->gba_epoch; prod->dv_done = false; } return r_; }
   }
   return LO_OK;
 }
@@ -1054,7 +1143,7 @@ static int vae_gn_finalize(LoVae* h, unsigned enc_mask, bool dec, float* G, void
     LoGnFinJob& j = jobs.j[jobs.n++];
     j.P1 = WSP(float, c.o_P1); j.P2 = WSP(float, c.o_P2);
     j.dgamma = GRD(c.p_gw); j.dbeta = GRD(c.p_gb); j.dbias = GRD(c.p_b);
-    j.nblk2 = B * lo_gn_nchunk(c.Ho * c.Wo, c.Cout);
+    j.nblk2 = B * (c.np2 > 0 ? c.np2 : lo_gn_nchunk(c.Ho * c.Wo, c.Cout));
     j.nblk1 = c.np1 > 0 ? B * c.np1 : j.nblk2;
     j.C = c.Cout; j.block0 = blocks;
     blocks += (c.Cout + 3) / 4;
@@ -1106,7 +1195,10 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   f16* Gd = WSP(f16, h->o_G[3]);
   if (phase == 0 || phase == 1 || phase == 5 || phase == 6) {
     h->bwd_layer = 0;
-    for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) h->enc[s][k].np1 = 0; h->dec[s].np1 = 0; }
+    for (int s = 0; s < 4; ++s) {
+      for (int k = 0; k < 3; ++k) { h->enc[s][k].np1 = 0; h->enc[s][k].dv_done = false; h->enc[s][k].np2 = 0; }
+      h->dec[s].np1 = 0; h->dec[s].dv_done = false; h->dec[s].np2 = 0;
+    }
   }
   if (phase == 0 || phase == 1 || phase == 5) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
   // padding elements of the flat gradient buffer are zero afterwards; every other element is overwritten (never accumulated
@@ -1212,9 +1304,12 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
       LO_TRY(conv_gn_bwd(h, c0, Gc, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
                          ws, inv, st));
     } else {
-      LO_TRY(lo_gn_bwd_nofinal(Gc, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gd,
-                               WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st, c0.np1));
-      LO_TRY(lo_first_conv_wgrad(x, Gd, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
+      const f16* dv0 = Gd;
+      if (c0.dv_done) dv0 = WSP(f16, c0.o_dv);      // conv1's data gradient has already applied this layer's GroupNorm backward
+      else
+        LO_TRY(lo_gn_bwd_nofinal(Gc, WSP(f16, c0.o_v), nullptr, WSP(float, c0.o_stats), PRM(c0.p_gw), PRM(c0.p_gb), nullptr, Gd,
+                                 WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st, c0.np1));
+      LO_TRY(lo_first_conv_wgrad(x, dv0, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
   }
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer

@@ -169,23 +169,31 @@ __device__ __forceinline__ float lo_wave_sum(float v) {
 // instruction).  With p = e^u + 1:  t = p^2 - 1,  t + 2 = p^2 + 1,  tau = t r,  r = 1 / (p^2 + 1),
 // mish = u tau,  mish' = tau + 4 u w p r^2.
 typedef float lo_f2 __attribute__((ext_vector_type(2)));
+// The two-wide helpers below are inlined into several kernels that must produce the SAME bits (the GroupNorm passes and the conv
+// epilogues that fuse them; tests/test_gn_fuse_gpu.py): floating-point contraction is off inside them and every fused
+// multiply-add is written out, so that no call site gets its own choice of which products to contract.
+__device__ __forceinline__ lo_f2 lo_fma2(lo_f2 a, lo_f2 b, lo_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ void lo_mish_parts2(lo_f2 u, lo_f2& w, lo_f2& p, lo_f2& r, lo_f2& tau) {
+#pragma clang fp contract(off)
   const lo_f2 c = __builtin_elementwise_min(u, (lo_f2){20.0f, 20.0f});
   w = (lo_f2){__expf(c[0]), __expf(c[1])};
   p = w + 1.0f;
-  const lo_f2 s = p * p + 1.0f;
+  const lo_f2 pp = p * p;
+  const lo_f2 s = pp + 1.0f;
   r = (lo_f2){__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};
-  tau = (p * p - 1.0f) * r;
+  tau = (pp - 1.0f) * r;
 }
 __device__ __forceinline__ lo_f2 lo_mish2(lo_f2 u) {
+#pragma clang fp contract(off)
   lo_f2 w, p, r, tau;
   lo_mish_parts2(u, w, p, r, tau);
   return u * tau;
 }
 __device__ __forceinline__ lo_f2 lo_mish_grad2(lo_f2 u) {
+#pragma clang fp contract(off)
   lo_f2 w, p, r, tau;
   lo_mish_parts2(u, w, p, r, tau);
-  return tau + (u * 4.0f) * (w * p) * (r * r);
+  return lo_fma2(u * 4.0f, (w * p) * (r * r), tau);
 }
 // mish(u) = u tanh(softplus(u)) = u t / (t + 2),  t = e^u (e^u + 2): one v_exp_f32 and one v_rcp_f32 (1 ulp; an IEEE
 // division costs ~10 more VALU instructions and the GroupNorm kernels are VALU-bound on exactly this arithmetic)
@@ -200,6 +208,143 @@ __device__ __forceinline__ float lo_mish_grad(float u) {
   float t = w * (w + 2.0f);
   float r = __builtin_amdgcn_rcpf(t + 2.0f);
   return t * r + u * (4.0f * w * (w + 1.0f)) * (r * r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm + Mish fused into the epilogue of the convolution that produces the tensor (forward).  GroupNorm(8, C) is per
+// sample, so nothing here is a grid-wide dependency: the workgroups that hold the tiles of ONE sample exchange their per-group
+// (sum, sum of squares) through memory and each normalises the tile it still has in LDS -- the separate lo_gn_fwd pass (one
+// more read of the raw output, one launch, one kernel boundary per layer) disappears.
+//
+// Hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", third row of the table of
+// hand-offs measured with sc1 loads in place of an acquire -- no cache maintenance instruction anywhere):
+//   producer: wave 0 writes its tile's exchange line, 32 floats = one whole 128-byte line, with ONE sc1 store instruction
+//             (agent-scope relaxed atomic stores), waits for vmcnt(0), then lane 0 adds 1 to the sample's arrival counter
+//             (agent-scope atomic);
+//   consumer: lane 0 polls that counter with sc1 loads until every tile of the sample has arrived (counters are monotonic: the
+//             host passes the value they reach at the end of THIS launch, so they are never reset), a workgroup barrier, then
+//             64 threads read the sample's lines with sc1 loads and form mean / rstd exactly like lo_gn_group_stats (double
+//             accumulation, same order: bitwise the statistics of the unfused path).
+// Progress: a waiting workgroup holds its CU slot, so the tiles of a sample must be dispatched close together -- the launchers
+// order tile ids sample-major and keep a sample's tiles on one XCD (lo_xcd_remap hands each XCD a contiguous range of tile
+// ids; workgroups of one XCD are dispatched in order), which bounds the wait by the skew of a few neighbouring workgroups.  The
+// poll is bounded anyway: after LO_GNF_SPIN_MAX polls the workgroup sets *fail and carries on (garbage out, no hang); the host
+// reads the word with the step's losses.
+// ---------------------------------------------------------------------------------------------
+#define LO_GNF_SPIN_MAX (1 << 21)
+#define LO_GNF_MAX_TILES 256        // exchange lines per sample and layer the workspace provides
+struct LoGnFuse {
+  float* xbuf;              // [B][MTs][NT][32] exchange lines
+  unsigned int* counter;    // [B] arrival counters (monotonic)
+  unsigned int target;      // counter value once every tile of this launch has arrived
+  int MTs, NT;              // partial rows per sample (m tiles x phases) and n tiles per row of the launch
+  const float* gamma;
+  const float* beta;
+  const f16* other;         // mode 1: skip tensor, mode 2: identity of the ResBlock; same layout as y
+  f16* y;                   // activation out; nullptr = fusion off
+  float* stats;             // [B][8][2] mean, rstd (saved for the backward)
+  int mode;                 // 0 y = mish(u), 1 y = mish(u) + other, 2 y = mish(mish(u) + other)   (lo_gn_fwd's modes)
+  unsigned int* fail;
+};
+
+// Every thread of the workgroup calls this (contains barriers).  s_x[32]: this tile's exchange line in LDS (slot grp*2 + which
+// for the groups the tile covers, zero elsewhere); on return s_stat[grp*2] = mean, s_stat[grp*2+1] = rstd of sample n.
+__device__ __forceinline__ void lo_gn_rendezvous(const LoGnFuse& f, int n, int row, int nt_i, int G, int BN, float inv_m,
+                                                 const float* s_x, float* s_stat, int tid) {
+  if (tid < 64) {
+    if (tid < 32) {
+      unsigned int* line = reinterpret_cast<unsigned int*>(f.xbuf) + (((size_t)n * f.MTs + row) * f.NT + nt_i) * 32;
+      __hip_atomic_store(line + tid, __float_as_uint(s_x[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the line (and this wave's earlier stores) have left before the count
+    if (tid == 0) {
+      __hip_atomic_fetch_add(f.counter + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while ((int)(__hip_atomic_load(f.counter + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - f.target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > LO_GNF_SPIN_MAX) { __hip_atomic_store(f.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {     // same arithmetic and order as lo_gn_group_stats: group = tid >> 3, part = tid & 7
+    const int grp = tid >> 3, part = tid & 7;
+    const int nt_of = (grp * G) / BN;             // the n tile whose line carries this group
+    double s = 0.0, q = 0.0;
+    for (int mt = part; mt < f.MTs; mt += 8) {
+      const unsigned int* line = reinterpret_cast<const unsigned int*>(f.xbuf) + (((size_t)n * f.MTs + mt) * f.NT + nt_of) * 32 + grp * 2;
+      s += (double)__uint_as_float(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      q += (double)__uint_as_float(__hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (part == 0) {
+      const double mean = s * inv_m;
+      double var = q * inv_m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stat[grp * 2 + 0] = (float)mean;
+      s_stat[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)1e-5f));
+    }
+  }
+  __syncthreads();
+}
+
+// GroupNorm affine folded with the statistics: u = v * sc + sh,  sc = gamma * rstd,  sh = beta - mean * sc
+__device__ __forceinline__ void lo_gn_scale_shift(float gamma, float beta, float mean, float rstd, float& sc, float& sh) {
+#pragma clang fp contract(off)
+  sc = gamma * rstd;
+  sh = __builtin_fmaf(-mean, sc, beta);
+}
+// y = GroupNorm-affine + Mish of eight consecutive channels (one 16-byte chunk): lo_gn_fwd's arithmetic, shared with the conv
+// epilogues that fuse it.  o: the second operand of modes 1 / 2.  yf (may be null): the eight results before the fp16 rounding.
+__device__ __forceinline__ f16x8 lo_gn_apply8(f16x8 h, const float* sc, const float* sh, int mode, f16x8 o, float* yf = nullptr) {
+#pragma clang fp contract(off)
+  f16x8 y;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const lo_f2 hv = {(float)h[j], (float)h[j + 1]};
+    lo_f2 m = lo_mish2(lo_fma2(hv, (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}));
+    if (mode != 0) {
+      const lo_f2 ov = {(float)o[j], (float)o[j + 1]};
+      m = mode == 1 ? m + ov : lo_mish2(m + ov);
+    }
+    y[j] = (f16)m[0];
+    y[j + 1] = (f16)m[1];
+    if (yf) { yf[j] = m[0]; yf[j + 1] = m[1]; }
+  }
+  return y;
+}
+
+// ---- GroupNorm backward, element arithmetic shared by lo_gn_bwd_reduce / lo_gn_bwd_apply (lo_norm.hip) and the data-gradient
+// epilogues that fuse the apply pass (same bits: contraction off, fused multiply-adds written out)
+//   xhat = v rstd + nmr (nmr = -mean rstd),  u = v sc + sh,  du = dy mish'(u)   (modes PLAIN / SKIP)
+__device__ __forceinline__ void lo_gn_du2_plain(lo_f2 hv, lo_f2 dyv, lo_f2 sc, lo_f2 sh, lo_f2 rstd, lo_f2 nmr, lo_f2& du, lo_f2& xhat) {
+#pragma clang fp contract(off)
+  xhat = lo_fma2(hv, rstd, nmr);
+  du = dyv * lo_mish_grad2(lo_fma2(hv, sc, sh));
+}
+//   dv = rstd (gamma du - k1 - xhat k2) = du sc - kb - xhat kc   (sc = gamma rstd, kb = rstd k1, kc = rstd k2)
+__device__ __forceinline__ lo_f2 lo_gn_dv2(lo_f2 du, lo_f2 xhat, lo_f2 sc, float kb, float kc) {
+#pragma clang fp contract(off)
+  return lo_fma2(-xhat, (lo_f2){kc, kc}, lo_fma2(du, sc, (lo_f2){-kb, -kb}));
+}
+
+// One lane announces this workgroup's arrival at a monotonic counter and waits (bounded) until it reaches `target`; every thread
+// of the workgroup calls this.  The caller has already made its payload visible: every storing wave waited for vmcnt(0) and the
+// workgroup passed a barrier (MI355X_MICROARCH.md, hand-off table: sc1 stores, one lane counts for the whole workgroup).
+__device__ __forceinline__ void lo_arrive_and_wait(unsigned int* counter, unsigned int target, unsigned int* fail, int tid) {
+  if (tid == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > LO_GNF_SPIN_MAX) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
 }
 
 // ---- counter RNG of the teacher's dropout layers (nn.Dropout / nn.Dropout2d, lunar_evaluator.py:97-99,139-140,212,225,246,

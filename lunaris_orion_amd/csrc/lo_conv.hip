@@ -190,8 +190,14 @@ struct IgemmArgs {
   const float* gb_gamma;
   const float* gb_beta;
   float* gb_P1;
+  f16* gb_dv;              // != null: the GroupNorm-backward apply runs here too (LoGnBwdFuse in lo_internal.h)
+  float* gb_P2;
+  unsigned int* gb_counter;
+  unsigned int gb_target;
+  unsigned int* gb_fail;
   const float* f8_scale;   // fp8 operand path: [n_phase][Cout] dequantisation factor (weight row scale / activation scale)
   int out_pitch, out_choff;   // out_pitch > 0: `out` has out_pitch channels per pixel, this op's channels start at out_choff
+  LoGnFuse gf;         // gf.y != null: GroupNorm + Mish of this output in the epilogue (sample rendezvous, lo_common.h)
   int M;               // rows per phase = B*GH*GW
   int nsplit;          // >= 1
   int ksteps_per_split;
@@ -258,7 +264,17 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
   // logical tile id -> (n tile fastest, then m tile, then phase / K split)
   const int NT = g.Cout / BN, MT = (a.M + BM - 1) / BM;
   const int tile_id = lo_xcd_remap(blockIdx.x, gridDim.x);
-  const int nt_i = tile_id % NT, mt_i = (tile_id / NT) % MT, z_i = tile_id / (NT * MT);
+  int nt_i = tile_id % NT, mt_i = (tile_id / NT) % MT, z_i = tile_id / (NT * MT);
+  if (!SPLITK && a.gf.y) {
+    // fused GroupNorm: the tiles of one sample wait for each other, so they get adjacent ids (sample, phase, m tile, n tile) --
+    // the default order puts the phase outermost, i.e. a sample's tiles a whole grid quarter apart
+    const int rows_ps = (g.GH * g.GW) / BM, tiles_ps = rows_ps * g.n_phase * NT;
+    const int n_s = tile_id / tiles_ps, r = tile_id - n_s * tiles_ps;
+    const int row = r / NT;
+    nt_i = r - row * NT;
+    z_i = row / rows_ps;
+    mt_i = n_s * rows_ps + (row - z_i * rows_ps);
+  }
   const int m0 = mt_i * BM, n0 = nt_i * BN;
   const int phase = SPLITK ? 0 : z_i;
   const int split = SPLITK ? z_i : 0;
@@ -494,6 +510,8 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     }
     if (a.out_pitch > 0)   // concatenated output tensor (teacher feature extractor); add_src / gb_v are not used with it
       *reinterpret_cast<f16x8*>(a.out + ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * a.out_pitch + a.out_choff + n0 + ochunk * 8) = h;
+    else if (a.gb_dv)      // fused GroupNorm-backward apply: the activation gradient only lives in this tile (LDS), nobody else reads it
+      *reinterpret_cast<f16x8*>(so + ml * OPITCH + ochunk * 16) = h;
     else
       *reinterpret_cast<f16x8*>(a.out + off) = h;
     if (a.bn_partial) {
@@ -510,7 +528,7 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
         ga2[j] += du * hv;          // sum du*xhat = rstd * (sum du*v - mean * sum du): finished after the loop
       }
     }
-    if (a.gn_partial) {
+    if (a.gn_partial || a.gf.y) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float x = (float)h[j]; s0 += x; q0 += x * x; }
 #pragma unroll
@@ -557,11 +575,86 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
       int ccx = cl >> 3, j = cl & 7;
       float tot = 0.f;
       for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
-      dst[o] = tot;
+      if (a.gb_dv) __hip_atomic_store(reinterpret_cast<unsigned int*>(dst) + o, __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else dst[o] = tot;
+    }
+    if (a.gb_dv) {
+      // ---- GroupNorm-backward APPLY of the producing layer, here: wait until every m tile of this sample (same n tile) has
+      //      published its P1 row, form the gamma-weighted group sums in lo_gn_bwd_apply's order, turn the tile's activation
+      //      gradient (still in LDS) into dv.  Single phase ops only (the launcher checks).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      lo_arrive_and_wait(a.gb_counter + n_img * NT + nt_i, a.gb_target, a.gb_fail, tid);
+      float* s_g = red;                   // [BN][2] gamma-weighted per-channel totals
+      float* s_c = red + 2 * BN;          // [BN / G][2] group means of (gamma du, gamma du xhat)
+      for (int c = tid; c < BN; c += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        const unsigned int* p = reinterpret_cast<const unsigned int*>(a.gb_P1) + ((size_t)n_img * MTs * g.Cout + n0 + c) * 2;
+        for (int k = 0; k < MTs; ++k) {
+          t1 += __uint_as_float(__hip_atomic_load(p + (size_t)k * g.Cout * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          t2 += __uint_as_float(__hip_atomic_load(p + (size_t)k * g.Cout * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const float gm = a.gb_gamma[n0 + c];
+        s_g[c * 2] = gm * t1;
+        s_g[c * 2 + 1] = gm * t2;
+      }
+      __syncthreads();
+      if (tid < (BN / G) * 2) {
+        const int gl = tid >> 1, w = tid & 1;
+        float tot = 0.f;
+        for (int c = gl * G; c < (gl + 1) * G; ++c) tot += s_g[c * 2 + w];
+        s_c[tid] = tot / ((float)per_sample * (float)G);
+      }
+      __syncthreads();
+      // this thread's 8 channels lie in ONE group (G >= 8: checked by the launcher)
+      const int gl = (ochunk * 8) / G, grp = n0 / G + gl;
+      const float mean = a.gb_stats[n_img * 16 + grp * 2], rstd = a.gb_stats[n_img * 16 + grp * 2 + 1];
+      const float nmr = -mean * rstd, kb = rstd * s_c[gl * 2], kc = rstd * s_c[gl * 2 + 1];
+      float sc[8], sh[8], acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gm = a.gb_gamma[n0 + ochunk * 8 + j];
+        sc[j] = gm * rstd;
+        sh[j] = __builtin_fmaf(nmr, gm, a.gb_beta[n0 + ochunk * 8 + j]);
+        acc[j] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < OP; ++i) {
+        const int ml = orow + i * ORPP;
+        const int m = m0 + ml;
+        if (m >= a.M) continue;
+        const f16x8 d = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
+        const int gy = (m >> g.lgw) & (g.GH - 1), gx = m & (g.GW - 1);
+        const size_t off = ((size_t)(n_img * g.Hout + gy) * g.Wout + gx) * g.Cout + n0 + ochunk * 8;
+        const f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
+        f16x8 outv;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          lo_f2 du, xh;
+          lo_gn_du2_plain((lo_f2){(float)vv[j], (float)vv[j + 1]}, (lo_f2){(float)d[j], (float)d[j + 1]}, (lo_f2){sc[j], sc[j + 1]},
+                          (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd, rstd}, (lo_f2){nmr, nmr}, du, xh);
+          const lo_f2 dv = lo_gn_dv2(du, xh, (lo_f2){sc[j], sc[j + 1]}, kb, kc);
+          const f16 d0 = (f16)dv[0], d1 = (f16)dv[1];
+          outv[j] = d0; outv[j + 1] = d1;
+          acc[j] += (float)d0; acc[j + 1] += (float)d1;
+        }
+        *reinterpret_cast<f16x8*>(a.gb_dv + off) = outv;
+      }
+      // per-channel sums of dv of this tile (conv bias gradient partials), fixed order over the row slots
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+      __syncthreads();
+      for (int c = tid; c < BN; c += 256) {
+        const int ccx = c >> 3, j = c & 7;
+        float tot = 0.f;
+        for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 8 + j];
+        a.gb_P2[((size_t)n_img * MTs + mt) * g.Cout + n0 + c] = tot;
+      }
     }
     if (a.gn_partial) __syncthreads();   // the section below reuses `red` (no caller sets both today; the barrier keeps that legal)
   }
-  if (a.gn_partial) {
+  if (a.gn_partial || a.gf.y) {
     // deterministic block reduction of the per-thread (sum, sumsq) of the two 4-channel halves of each chunk:
     //   level 1: 256 threads, each adds ORPP/P row slots of one (chunk, value)   level 2: P partials -> chunk sums
     //   level 3: half-chunks of a group (<= 16) -> group sums
@@ -573,6 +666,9 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     static_assert(P >= 1 && RPP2 * P == ORPP, "epilogue reduction shape");
     float* red2 = red + 1024;
     float* red3 = red2 + 256;
+    float* s_x = red3 + 64;               // fused GroupNorm: this tile's exchange line (32 floats), then the sample's statistics (16)
+    float* s_stat = s_x + 32;
+    if (tid < 32) s_x[tid] = 0.f;
     __syncthreads();
     {
       const int o = tid % NV, part = tid / NV;
@@ -590,17 +686,45 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     }
     __syncthreads();
     const int ngroups = BN / G;           // BN >= G is checked by the launcher
+    const int per_sample = g.GH * g.GW;
+    const int n_img = m0 / per_sample;
+    const int mt = (m0 - n_img * per_sample) / BM;
+    const int MTs = (per_sample / BM) * g.n_phase;
+    const int row = phase * (per_sample / BM) + mt;
     if (tid < ngroups * 2) {
       int gl = tid >> 1, which = tid & 1;
       int hc_begin = gl * G / 4, hc_end = (gl + 1) * G / 4;
       float tot = 0.f;
       for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[(hc >> 1) * 4 + (hc & 1) * 2 + which];
-      int per_sample = g.GH * g.GW;
-      int n_img = m0 / per_sample;
-      int mt = (m0 - n_img * per_sample) / BM;
-      int MTs = (per_sample / BM) * g.n_phase;
       int grp = (n0 / G) + gl;
-      a.gn_partial[(((size_t)n_img * MTs + phase * (per_sample / BM) + mt) * 8 + grp) * 2 + which] = tot;
+      if (a.gn_partial) a.gn_partial[(((size_t)n_img * MTs + row) * 8 + grp) * 2 + which] = tot;
+      s_x[grp * 2 + which] = tot;
+    }
+    if (a.gf.y) {
+      // ---- GroupNorm + Mish of this tile, once the whole sample's sums are known (lo_common.h: LoGnFuse)
+      __syncthreads();
+      lo_gn_rendezvous(a.gf, n_img, row, nt_i, G, BN, 1.0f / ((float)(per_sample * g.n_phase) * (float)G), s_x, s_stat, tid);
+      if (row == 0 && nt_i == 0 && tid < 16 && a.gf.stats) a.gf.stats[n_img * 16 + tid] = s_stat[tid];
+      float sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = n0 + ochunk * 8 + j, grp = c / G;
+        const float mean = s_stat[grp * 2], rstd = s_stat[grp * 2 + 1];
+        lo_gn_scale_shift(a.gf.gamma[c], a.gf.beta[c], mean, rstd, sc[j], sh[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < OP; ++i) {
+        const int ml = orow + i * ORPP;
+        const int m = m0 + ml;
+        if (m >= a.M) continue;
+        const f16x8 h = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
+        const int gy = (m >> g.lgw) & (g.GH - 1), gx = m & (g.GW - 1);
+        const int oy = gy * g.out_stride + g.out_oy[phase], ox = gx * g.out_stride + g.out_ox[phase];
+        const size_t off = ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * g.Cout + n0 + ochunk * 8;
+        f16x8 o = h;
+        if (a.gf.mode != 0) o = *reinterpret_cast<const f16x8*>(a.gf.other + off);
+        *reinterpret_cast<f16x8*>(a.gf.y + off) = lo_gn_apply8(h, sc, sh, a.gf.mode, o);
+      }
     }
   }
 }
@@ -974,7 +1098,7 @@ int lo_conv_run_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, const
                    f16* out, float* gn_partial, hipStream_t st) {
   LO_REQUIRE(lo_conv_f8_applies(g), "lo_conv_run_f8: geometry not supported (Cin %% 128, Cout %% 64)");
   IgemmArgs a;
-  memset(&a, 0, sizeof(a));
+  memset(&a, 0, sizeof(a));       // (a.gf.y = null: no fused GroupNorm on the fp8 path)
   a.in = reinterpret_cast<const f16*>(in8); a.w = reinterpret_cast<const f16*>(w8); a.f8_scale = wscale;
   a.bias = bias; a.add_src = add_src; a.out = out; a.gn_partial = gn_partial;
   a.g = g;
@@ -1071,13 +1195,60 @@ int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStrea
 }
 
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
+// Data-gradient op g with the fused GroupNorm-backward reduction: can its epilogue also run the APPLY pass (LoGnBwdFuse::dv)?
+// Single-phase ops on lo_igemm_nt / lo_conv3x3_pp whose tiles lie inside one sample and whose 8-channel chunks lie inside one
+// GroupNorm group.  mts / nt: P1 rows per sample and n tiles per row of the launch.
+bool lo_conv_gnb_apply_tiles(const LoGeom& g, int* mts, int* nt) {
+  if (g.n_phase != 1 || (g.Cout >> 3) < 8 || g.Cout % 64 != 0 || g.Cin % 64 != 0) return false;
+  if (lo_conv4s2_patch_applies(g)) return false;
+  if (lo_conv3_tiles_per_image(g, false) > 0) return lo_conv3_fuses_gnb(g) && lo_conv3_gn_fuse_tiles(g, mts, nt);
+  int bm, bn;
+  lo_conv_pick_tile(g, &bm, &bn);
+  const int per_sample = g.GH * g.GW;
+  if (per_sample % bm != 0 || (g.Cout >> 3) > bn) return false;
+  *mts = per_sample / bm;
+  *nt = g.Cout / bn;
+  return *nt <= 8 && *mts <= LO_GNF_MAX_TILES;
+}
+
+// Does the kernel lo_conv_run would launch for g (forward conv, no residual / gradient epilogue) take the fused GroupNorm epilogue,
+// and with which tile grid per sample?  mts: partial rows per sample (m tiles x phases), nt: n tiles per row.
+bool lo_conv_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt) {
+  if (lo_convt4_patch_applies(g)) return false;               // patch-resident transposed conv: own epilogue (not built)
+  if (lo_conv3_tiles_per_image(g, false) > 0) return lo_conv3_gn_fuse_tiles(g, mts, nt);
+  if (g.Cin % 64 != 0 || g.Cout % 64 != 0) return false;
+  int bm, bn;
+  lo_conv_pick_tile(g, &bm, &bn);
+  const int per_sample = g.GH * g.GW;
+  if (per_sample % bm != 0 || (g.Cout >> 3) > bn) return false;
+  *mts = (per_sample / bm) * g.n_phase;
+  *nt = g.Cout / bn;
+  return *mts * *nt <= LO_GNF_MAX_TILES;
+}
+
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb, const LoConvExtra* ex,
-                const LoGnApplyFuse* xg) {
+                const LoGnApplyFuse* xg, const LoGnFuse* gf) {
   IgemmArgs a;
+  memset(&a.gf, 0, sizeof(a.gf));
+  if (gf) {
+    int mts = 0, nt = 0;
+    LO_REQUIRE(nsplit <= 1 && !add_src && !gb && !ex && !xg && gf->y && gf->xbuf && gf->counter && gf->fail && gf->gamma && gf->beta &&
+               (gf->mode == 0 || gf->other), "lo_conv_run: bad fused-GroupNorm arguments");
+    LO_REQUIRE(lo_conv_gn_fuse_tiles(g, &mts, &nt) && mts == gf->MTs && nt == gf->NT,
+               "lo_conv_run: fused GroupNorm asked for a geometry / tile grid the kernel does not have (check lo_conv_gn_fuse_tiles)");
+    a.gf = *gf;
+  }
   a.in = in; a.w = wp; a.bias = bias; a.add_src = add_src; a.out = out; a.gn_partial = gn_partial; a.slab = slab;
   a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
   a.gb_beta = gb ? gb->beta : nullptr; a.gb_P1 = gb ? gb->P1 : nullptr;
+  a.gb_dv = gb ? gb->dv : nullptr; a.gb_P2 = gb ? gb->P2 : nullptr; a.gb_counter = gb ? gb->counter : nullptr;
+  a.gb_target = gb ? gb->target : 0u; a.gb_fail = gb ? gb->fail : nullptr;
+  if (gb && gb->dv) {
+    int mts = 0, nt = 0;
+    LO_REQUIRE(gb->P2 && gb->counter && gb->fail && lo_conv_gnb_apply_tiles(g, &mts, &nt),
+               "lo_conv_run: fused GroupNorm-backward apply asked for a geometry the kernel does not support (check lo_conv_gnb_apply_tiles)");
+  }
   a.act = ex ? ex->act : 0; a.bn_partial = ex ? ex->bn_partial : nullptr;
   a.out_pitch = ex ? ex->out_pitch : 0; a.out_choff = ex ? ex->out_choff : 0;
   LO_REQUIRE(a.out_pitch == 0 || (!add_src && !gb && a.out_pitch % 8 == 0 && a.out_choff % 8 == 0), "lo_conv_run: bad concatenated-output arguments");
@@ -1097,7 +1268,7 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   if (a.nsplit == 1 && !add_src && !gb && !ex && !xg && lo_convt4_patch_applies(g))
     return lo_convt4_patch_run(g, in, wp, bias, out, gn_partial, st);   // last transposed conv of the decoder, patch-resident
   if (a.nsplit == 1 && lo_conv3_tiles_per_image(g, ex != nullptr) > 0 && (!gb || lo_conv3_fuses_gnb(g)))
-    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb, xg);   // fused-tap kernel for 3x3 stride-1
+    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb, xg, gf);   // fused-tap kernel for 3x3 stride-1
   LO_REQUIRE(!xg, "lo_conv_run: GroupNorm on load is only available in the fused-tap kernel (check lo_conv3_fuses_gnb first)");
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");
@@ -1107,7 +1278,7 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   // tile choice
   int bm, bn;
   lo_conv_pick_tile(g, &bm, &bn);
-  if (gn_partial || gb) {
+  if (gn_partial || gb || gf) {
     LO_REQUIRE(per_sample % bm == 0 && a.M % bm == 0, "lo_conv_run: GN partials need whole tiles per sample");
     LO_REQUIRE((g.Cout >> 3) <= bn, "lo_conv_run: GroupNorm group wider than the N tile");
   }

@@ -61,6 +61,12 @@ struct Conv3Args {
   const float* gb_gamma = nullptr;
   const float* gb_beta = nullptr;
   float* gb_P1 = nullptr;
+  f16* gb_dv = nullptr;    // != null: the GroupNorm-backward apply runs in this epilogue too (LoGnBwdFuse in lo_internal.h)
+  float* gb_P2 = nullptr;
+  unsigned int* gb_counter = nullptr;
+  unsigned int gb_target = 0;
+  unsigned int* gb_fail = nullptr;
+  LoGnFuse gf = {};        // gf.y != null: GroupNorm + Mish of this output in the epilogue (lo_conv3x3_pp only; lo_common.h)
 };
 #ifdef LO_STAMPS
 unsigned long long* g_lo_conv3_stamps = nullptr;
@@ -717,7 +723,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; h[j] = (f16)(x > 0.f ? x : 0.2f * x); }
     }
-    *reinterpret_cast<f16x8*>(a.out + off) = h;
+    if (!PAIR && a.gb_dv) *reinterpret_cast<f16x8*>(so + ml * OPITCH + ochunk * 16) = h;   // fused apply: the activation gradient stays in LDS
+    else *reinterpret_cast<f16x8*>(a.out + off) = h;
     if (a.bn_partial) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; ga1[j] += x; ga2[j] += x * x; }
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
         ga2[j] += du * hv;          // sum du*xhat = rstd * (sum du*v - mean * sum du): finished after the loop
       }
     }
-    if (a.gn_partial) {
+    if (a.gn_partial || a.gf.y) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float x = (float)h[j]; s0 += x; q0 += x * x; }
 #pragma unroll
@@ -781,17 +788,91 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       } else {
         float tot = 0.f;
         for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
-        dst[o] = tot;
+        if (a.gb_dv) __hip_atomic_store(reinterpret_cast<unsigned int*>(dst) + o, __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dst[o] = tot;
+      }
+    }
+    if constexpr (!PAIR) {
+      if (a.gb_dv) {
+        // ---- GroupNorm-backward APPLY of the producing layer (same sequence as lo_igemm_nt's epilogue; lo_internal.h LoGnBwdFuse)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        lo_arrive_and_wait(a.gb_counter + n_img * NT + nt_i, a.gb_target, a.gb_fail, tid);
+        float* s_g = red;
+        float* s_c = red + 2 * BN;
+        for (int c = tid; c < BN; c += NTHR) {
+          float t1 = 0.f, t2 = 0.f;
+          const unsigned int* p = reinterpret_cast<const unsigned int*>(a.gb_P1) + ((size_t)n_img * tiles_img * g.Cout + n0 + c) * 2;
+          for (int k = 0; k < tiles_img; ++k) {
+            t1 += __uint_as_float(__hip_atomic_load(p + (size_t)k * g.Cout * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            t2 += __uint_as_float(__hip_atomic_load(p + (size_t)k * g.Cout * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          }
+          const float gm = a.gb_gamma[n0 + c];
+          s_g[c * 2] = gm * t1;
+          s_g[c * 2 + 1] = gm * t2;
+        }
+        __syncthreads();
+        if (tid < (BN / G) * 2) {
+          const int gl = tid >> 1, w = tid & 1;
+          float tot = 0.f;
+          for (int c = gl * G; c < (gl + 1) * G; ++c) tot += s_g[c * 2 + w];
+          s_c[tid] = tot / ((float)(H * W) * (float)G);
+        }
+        __syncthreads();
+        const int gl = (ochunk * 8) / G, gr = n0 / G + gl;
+        const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
+        const float nmr = -mean * rstd, kb = rstd * s_c[gl * 2], kc = rstd * s_c[gl * 2 + 1];
+        float sc[8], sh[8], acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gm = a.gb_gamma[n0 + ochunk * 8 + j];
+          sc[j] = gm * rstd;
+          sh[j] = __builtin_fmaf(nmr, gm, a.gb_beta[n0 + ochunk * 8 + j]);
+          acc[j] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < OP; ++i) {
+          const int ml = orow + i * ORPP;
+          const int ty = ml / TW, tx = ml % TW;
+          const f16x8 d = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
+          const size_t off = ((size_t)(n_img * H + y0 + ty) * W + x0 + tx) * g.Cout + n0 + ochunk * 8;
+          const f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
+          f16x8 outv;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            lo_f2 du, xh;
+            lo_gn_du2_plain((lo_f2){(float)vv[j], (float)vv[j + 1]}, (lo_f2){(float)d[j], (float)d[j + 1]}, (lo_f2){sc[j], sc[j + 1]},
+                            (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd, rstd}, (lo_f2){nmr, nmr}, du, xh);
+            const lo_f2 dv = lo_gn_dv2(du, xh, (lo_f2){sc[j], sc[j + 1]}, kb, kc);
+            const f16 d0 = (f16)dv[0], d1 = (f16)dv[1];
+            outv[j] = d0; outv[j + 1] = d1;
+            acc[j] += (float)d0; acc[j + 1] += (float)d1;
+          }
+          *reinterpret_cast<f16x8*>(a.gb_dv + off) = outv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+        __syncthreads();
+        for (int c = tid; c < BN; c += NTHR) {
+          const int ccx = c >> 3, j = c & 7;
+          float tot = 0.f;
+          for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 8 + j];
+          a.gb_P2[((size_t)n_img * tiles_img + t_img) * g.Cout + n0 + c] = tot;
+        }
       }
     }
     if (a.gn_partial) __syncthreads();
   }
-  if (a.gn_partial) {
+  if (a.gn_partial || a.gf.y) {
     float* red = reinterpret_cast<float*>(smem + BM * OPITCH);
     red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
     constexpr int NV = OCPR * 4, P = NTHR / NV, RPP2 = ORPP / P;
     float* red2 = red + NTHR * 4;
     float* red3 = red2 + NTHR;
+    float* s_x = red3 + 2 * NV;           // fused GroupNorm: this tile's exchange line (32 floats), then the sample's statistics (16)
+    float* s_stat = s_x + 32;
+    if (tid < 32) s_x[tid] = 0.f;
     __syncthreads();
     {
       const int o = tid % NV, part = tid / NV;
@@ -821,7 +902,33 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       float tot = 0.f;
       for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[half * NV + (hc >> 1) * 4 + (hc & 1) * 2 + which];
       int grp2 = (n0 / G) + gl;
-      a.gn_partial[(((size_t)(n_img + half) * tiles_img + t_img) * 8 + grp2) * 2 + which] = tot;
+      if (a.gn_partial) a.gn_partial[(((size_t)(n_img + half) * tiles_img + t_img) * 8 + grp2) * 2 + which] = tot;
+      if (!PAIR) s_x[grp2 * 2 + which] = tot;
+    }
+    if constexpr (!PAIR && !F8 && XF == 0) {
+      if (a.gf.y) {
+        // ---- GroupNorm + Mish of this tile once the whole sample's sums are known (lo_common.h: LoGnFuse); the tile is still in LDS
+        __syncthreads();
+        lo_gn_rendezvous(a.gf, n_img, t_img, nt_i, G, BN, 1.0f / ((float)(H * W) * (float)G), s_x, s_stat, tid);
+        if (t_img == 0 && nt_i == 0 && tid < 16 && a.gf.stats) a.gf.stats[n_img * 16 + tid] = s_stat[tid];
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = n0 + ochunk * 8 + j, gr = c / G;
+          const float mean = s_stat[gr * 2], rstd = s_stat[gr * 2 + 1];
+          lo_gn_scale_shift(a.gf.gamma[c], a.gf.beta[c], mean, rstd, sc[j], sh[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < OP; ++i) {
+          const int ml = orow + i * ORPP;
+          const int ty = ml / TW, tx = ml % TW;
+          const f16x8 h = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
+          const size_t off = ((size_t)(n_img * H + y0 + ty) * W + x0 + tx) * g.Cout + n0 + ochunk * 8;
+          f16x8 o = h;
+          if (a.gf.mode != 0) o = *reinterpret_cast<const f16x8*>(a.gf.other + off);
+          *reinterpret_cast<f16x8*>(a.gf.y + off) = lo_gn_apply8(h, sc, sh, a.gf.mode, o);
+        }
+      }
     }
   }
 #ifdef LO_STAMPS
@@ -900,18 +1007,41 @@ bool lo_conv3_fuses_gnb(const LoGeom& g) {
   return lo_conv3_tiles_per_image(g, false) > 0 && conv3_tile(g, &th, &tw, &bn, &nw) && nw == 8;
 }
 
+// fused GroupNorm epilogue: only the 8-wave ping-pong kernel, one image per tile
+bool lo_conv3_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt) {
+  int th, tw, bn, nw;
+  if (lo_conv3_tiles_per_image(g, false) <= 0 || !conv3_tile(g, &th, &tw, &bn, &nw) || nw != 8) return false;
+  if (conv3_mode() >= 2 && conv3_pair(g)) return false;
+  static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;
+  if (!pp && th == 16 && bn == 128) return false;       // the lock-step 8-wave kernel has no fused epilogue
+  *mts = (g.Hin / th) * (g.Win / tw);
+  *nt = g.Cout / bn;
+  return *mts * *nt <= LO_GNF_MAX_TILES;
+}
+
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb, const LoGnApplyFuse* xg) {
+                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb, const LoGnApplyFuse* xg, const LoGnFuse* gf) {
   int th, tw, bn, nw;
   LO_REQUIRE(conv3_tile(g, &th, &tw, &bn, &nw), "lo_conv3_run: geometry not supported by the fused-tap kernel");
+  if (gf) {
+    int mts = 0, nt = 0;
+    LO_REQUIRE(!add_src && !gb && !ex && !xg && lo_conv3_gn_fuse_tiles(g, &mts, &nt) && mts == gf->MTs && nt == gf->NT,
+               "lo_conv3_run: fused GroupNorm asked for a geometry / tile grid the kernel does not have");
+  }
   LO_REQUIRE(!gb || nw == 8, "lo_conv3_run: the fused GroupNorm-backward epilogue needs the 8-wave kernel");
   LO_REQUIRE(!xg || (nw == 8 && g.Cin <= 256 && g.Cin % 64 == 0), "lo_conv3_run: GroupNorm on load needs the 8-wave kernel and Cin <= 256");
   Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, nullptr, g};
-  if (gb) { a.gb_v = gb->v; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_P1 = gb->P1; }
+  if (gb) {
+    a.gb_v = gb->v; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_P1 = gb->P1;
+    a.gb_dv = gb->dv; a.gb_P2 = gb->P2; a.gb_counter = gb->counter; a.gb_target = gb->target; a.gb_fail = gb->fail;
+    LO_REQUIRE(!gb->dv || (nw == 8 && !(conv3_mode() >= 2 && conv3_pair(g)) && (g.Cout >> 3) >= 8),
+               "lo_conv3_run: fused GroupNorm-backward apply needs the one-image-per-tile 8-wave kernel");
+  }
   if (xg) {
     LO_REQUIRE(xg->partial && xg->MT > 0 && xg->gamma && xg->beta && xg->y, "lo_conv3_run: incomplete GroupNorm-on-load arguments");
     a.xg_partial = xg->partial; a.xg_MT = xg->MT; a.xg_gamma = xg->gamma; a.xg_beta = xg->beta; a.xg_stats = xg->stats; a.xg_y = xg->y;
   }
+  if (gf) a.gf = *gf;
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif

@@ -8,7 +8,16 @@ const char* lo_get_error();
 int lo_pack_weight(const float* w, f16* wp, const LoGeom& g, hipStream_t st);
 int lo_pack_all(const LoPackJob* jobs_dev, int njobs, int nblocks, hipStream_t st, int block_base = 0);   // block_base: a sub-range of the table
 int lo_pack_blocks(const LoGeom& g);   // blocks of one job in the fused pack launch
-struct LoGnBwdFuse { const f16* v; const float* stats; const float* gamma; const float* beta; float* P1; };
+// Data-gradient epilogue that also runs the GroupNorm backward of the layer whose activation gradient it produces.  P1: the
+// reduction (per-tile, per-channel sum du / sum du*xhat).  dv != null: the APPLY pass too -- the workgroups of a sample exchange
+// their P1 rows (sc1 stores, arrival counter per (sample, n tile): lo_common.h lo_arrive_and_wait), form the group sums in the
+// order lo_gn_bwd_apply uses and write dv (+ P2 = per-tile sums of dv for the conv bias gradient) instead of the activation
+// gradient, which is then never stored.  lo_conv_gnb_apply_tiles: whether the kernel lo_conv_run picks supports it.
+struct LoGnBwdFuse {
+  const f16* v; const float* stats; const float* gamma; const float* beta; float* P1;
+  f16* dv = nullptr; float* P2 = nullptr; unsigned int* counter = nullptr; unsigned int target = 0; unsigned int* fail = nullptr;
+};
+bool lo_conv_gnb_apply_tiles(const LoGeom& gd, int* mts, int* nt);
 // GroupNorm + Mish of the producing layer applied on the consumer's operand load (fused-tap kernel only, see Conv3Args::xg_*):
 // `in` of the conv is the producer's raw output; partial / MT = its epilogue sums; y / stats = what lo_gn_fwd would have written
 struct LoGnApplyFuse { const float* partial; int MT; const float* gamma; const float* beta; float* stats; f16* y; };
@@ -17,7 +26,11 @@ struct LoGnApplyFuse { const float* partial; int MT; const float* gamma; const f
 struct LoConvExtra { int act; float* bn_partial; int out_pitch = 0; int out_choff = 0; };
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr,
-                const LoConvExtra* ex = nullptr, const LoGnApplyFuse* xg = nullptr);
+                const LoConvExtra* ex = nullptr, const LoGnApplyFuse* xg = nullptr, const LoGnFuse* gf = nullptr);
+// gf: GroupNorm + Mish of the output inside the epilogue (LoGnFuse, lo_common.h).  lo_conv_gn_fuse_tiles: whether the kernel
+// lo_conv_run picks for g supports it, and the tile grid per sample the caller must put into gf->MTs / gf->NT
+bool lo_conv_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt);
+bool lo_conv3_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt);
 // fp8 (e4m3) operand path of the forward convs
 struct LoPackF8Job { const f16* src; uint8_t* dst; float* scale; int K[LO_MAX_PHASE]; int wofs[LO_MAX_PHASE]; int Cout, n_phase, block0; };
 bool lo_conv_f8_applies(const LoGeom& g);
@@ -40,7 +53,7 @@ int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, c
                        hipStream_t st, const LoConvExtra* ex);
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                  float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr, const LoGnBwdFuse* gb = nullptr,
-                 const LoGnApplyFuse* xg = nullptr);
+                 const LoGnApplyFuse* xg = nullptr, const LoGnFuse* gf = nullptr);
 bool lo_conv3_fuses_gnb(const LoGeom& g);
 bool lo_convt4_patch_applies(const LoGeom& g);   // patch-resident forward of the 64 -> 32 transposed convolution
 int lo_convt4_patch_tiles_per_image(const LoGeom& g);

@@ -62,8 +62,7 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
     float mean = s_stat[grp * 2], rstd = s_stat[grp * 2 + 1];
     float gm = j < 4 ? gm0[j & 3] : gm1[j & 3];
     float bt = j < 4 ? bt0[j & 3] : bt1[j & 3];
-    sc[j] = gm * rstd;
-    sh[j] = bt - mean * sc[j];
+    lo_gn_scale_shift(gm, bt, mean, rstd, sc[j], sh[j]);
   }
   const int rows = a.HW / a.nchunk;
   const size_t base = ((size_t)n * a.HW + (size_t)chunk * rows) * C + c0;
@@ -83,21 +82,8 @@ __global__ __launch_bounds__(256) void lo_gn_fwd_kernel(GnFwdArgs a) {
     for (int u = 0; u < U; ++u) {
       int rr = r + u * nslot;
       if (rr < rows) {
-        f16x8 y;
         float yf[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const lo_f2 hv = {(float)h[u][j], (float)h[u][j + 1]};
-          lo_f2 m = lo_mish2(hv * (lo_f2){sc[j], sc[j + 1]} + (lo_f2){sh[j], sh[j + 1]});
-          if constexpr (MODE != GN_MODE_PLAIN) {
-            const lo_f2 ov = {(float)o[u][j], (float)o[u][j + 1]};
-            m = MODE == GN_MODE_SKIP ? m + ov : lo_mish2(m + ov);
-          }
-          y[j] = (f16)m[0];
-          y[j + 1] = (f16)m[1];
-          yf[j] = m[0];
-          yf[j + 1] = m[1];
-        }
+        const f16x8 y = lo_gn_apply8(h[u], sc, sh, MODE, MODE != GN_MODE_PLAIN ? o[u] : h[u], a.y8 ? yf : nullptr);   // the arithmetic the fused conv epilogues share
         *reinterpret_cast<f16x8*>(a.y + base + (size_t)rr * C) = y;
         if (a.y8) {
           constexpr float S8 = LO_F8_ACT_SCALE;
@@ -132,20 +118,22 @@ struct GnBwdArgs {
   int np1;              // rows of P1 per sample (nchunk, or the tile count of the fused data-gradient epilogue)
 };
 
-// two elements at a time: xhat = hv*rstd + nmr (nmr = -mean*rstd), u = hv*sc + sh
+// two elements at a time: xhat = hv*rstd + nmr (nmr = -mean*rstd), u = hv*sc + sh.  PLAIN / SKIP: lo_gn_du2_plain (lo_common.h,
+// shared with the data-gradient epilogues that fuse the apply pass); contraction off, fused multiply-adds written out
 __device__ __forceinline__ void gn_du2(int mode, lo_f2 hv, lo_f2 dyv, lo_f2 ov, lo_f2 sc, lo_f2 sh, lo_f2 rstd, lo_f2 nmr,
                                        lo_f2& du, lo_f2& xhat, lo_f2& dsv) {
-  xhat = hv * rstd + nmr;
-  const lo_f2 u = hv * sc + sh;
+#pragma clang fp contract(off)
   if (mode == GN_MODE_RES) {
+    xhat = lo_fma2(hv, rstd, nmr);
+    const lo_f2 u = lo_fma2(hv, sc, sh);
     lo_f2 w, p, r, tau;
     lo_mish_parts2(u, w, p, r, tau);
-    const lo_f2 gu = tau + (u * 4.0f) * (w * p) * (r * r);
-    dsv = dyv * lo_mish_grad2(u * tau + ov);
+    const lo_f2 gu = lo_fma2(u * 4.0f, (w * p) * (r * r), tau);
+    dsv = dyv * lo_mish_grad2(lo_fma2(u, tau, ov));
     du = dsv * gu;
   } else {
     dsv = dyv;
-    du = dyv * lo_mish_grad2(u);
+    lo_gn_du2_plain(hv, dyv, sc, sh, rstd, nmr, du, xhat);
   }
 }
 
@@ -174,7 +162,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_reduce_kernel(GnBwdArgs a) {
   for (int j = 0; j < 8; ++j) {
     const int q = G4 ? (j >> 2) : 0;
     sc[j] = a.gamma[c0 + j] * rstd[q];
-    sh[j] = a.beta[c0 + j] + nmr[q] * a.gamma[c0 + j];     // beta - mean * gamma * rstd
+    sh[j] = __builtin_fmaf(nmr[q], a.gamma[c0 + j], a.beta[c0 + j]);     // beta - mean * gamma * rstd
   }
   lo_f2 a1[4], a2[4];
 #pragma unroll
@@ -284,7 +272,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
     const int q = G4 ? (j >> 2) : 0;
     const float gm = j < 4 ? gm0[j & 3] : gm1[j & 3];
     sc[j] = gm * rstd[q];
-    sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) + nmr[q] * gm;
+    sh[j] = __builtin_fmaf(nmr[q], gm, j < 4 ? bt0[j & 3] : bt1[j & 3]);      // beta - mean * gamma * rstd
   }
   float acc[8];
 #pragma unroll
@@ -318,7 +306,7 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
                  (lo_f2){sc[j], sc[j + 1]}, (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd[G4 ? (j >> 2) : 0], rstd[G4 ? (j >> 2) : 0]},
                  (lo_f2){nmr[G4 ? (j >> 2) : 0], nmr[G4 ? (j >> 2) : 0]}, du, xh, dsv);
           const int q = G4 ? (j >> 2) : 0;
-          const lo_f2 dv = du * (lo_f2){sc[j], sc[j + 1]} - (lo_f2){kb[q], kb[q]} - xh * (lo_f2){kc[q], kc[q]};
+          const lo_f2 dv = lo_gn_dv2(du, xh, (lo_f2){sc[j], sc[j + 1]}, kb[q], kc[q]);
           const f16 d0 = (f16)dv[0], d1 = (f16)dv[1];
           out[j] = d0;
           out[j + 1] = d1;

@@ -240,10 +240,24 @@ class VAEStepper:
 
     def metrics(self) -> Dict[str, float]:
         """Host copy of the last step's scalars (this synchronises the stream)."""
-        v = torch.cat([self.losses, self.scratch[1024:1028]]).cpu().tolist()
+        v = torch.cat([self.losses, self.scratch[1024:1028], self._sync_fail_word()]).cpu().tolist()
+        self._check_sync(v[8])
         self._update_loss_scale(v[7])
         return {"recon_loss": v[0], "kl_loss": v[1], "vae_loss": v[2], "pg_loss": v[3], "grad_norm": v[4],
                 "clip_coef": v[5], "grads_finite": v[6], "lr": self.lr, "skipped_steps": v[7], "loss_scale": self.vae.loss_scale}
+
+    def _sync_fail_word(self) -> torch.Tensor:
+        """The engines' "a fused-GroupNorm rendezvous ran out" words (lo_vae_sync_fail_word), summed, as one float."""
+        words = [e.sync_fail for e in self.vae._engines.values()]
+        if not words:
+            return torch.zeros(1, dtype=torch.float32, device=self.losses.device)
+        return torch.stack([w.float().sum() for w in words]).sum().reshape(1)
+
+    @staticmethod
+    def _check_sync(word: float) -> None:
+        if word != 0:
+            raise _lib.LunarisHipError("a fused GroupNorm epilogue gave up waiting for the other workgroups of its sample (a launch of this "
+                                       "step did not complete): the step's results are invalid; LO_GN_FUSE=0 runs the separate passes")
 
     def parameter_grads(self):
         """Views of the flat gradient buffer, one per parameter (state_dict order)."""
@@ -360,7 +374,8 @@ class HybridStepper(VAEStepper):
 
     def metrics(self) -> Dict[str, float]:
         """The 12 scalars of train_hybrid.py:929-942 (+ grad norm / lr); one host copy."""
-        v = torch.cat([self.losses, self.scratch[1024:1027], self.reward_out[:7], self.scratch[1027:1028]]).cpu().tolist()
+        v = torch.cat([self.losses, self.scratch[1024:1027], self.reward_out[:7], self.scratch[1027:1028], self._sync_fail_word()]).cpu().tolist()
+        self._check_sync(v[15])
         recon, kl, vae_loss, pg = v[0:4]
         q_loss, sem_r, q_r, baseline, adv, t_loss, q_mean = v[7:14]
         self._update_loss_scale(v[14])

@@ -258,6 +258,10 @@ class _Engine:
         self.batch, self.latent_dim, self.device = batch, latent_dim, device
         self.ws = torch.empty(_lib.lib.lo_vae_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
         self.packed_version = None      # (explicit version, sum of the parameters' version counters) of the last pack
+        off, nf = C.c_size_t(), C.c_int()
+        _lib.check(_lib.lib.lo_vae_sync_fail_word(self.handle, C.byref(off), C.byref(nf)), "lo_vae_sync_fail_word")
+        self.fused_gn_layers = nf.value
+        self.sync_fail = self.ws[off.value:off.value + 4].view(torch.int32)     # set by a fused-GroupNorm workgroup whose wait ran out
 
     def __del__(self):
         try:

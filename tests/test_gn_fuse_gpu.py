@@ -1,0 +1,99 @@
+"""GroupNorm + Mish inside the producing convolution's epilogue (csrc/lo_common.h: LoGnFuse -- the workgroups that hold one sample's
+tiles exchange their partial sums and wait for each other) against the separate lo_gn_fwd pass it replaces (LO_GN_FUSE=0): same
+statistics, same arithmetic, so every output, every saved activation and every gradient of a training step must agree BIT FOR BIT, at
+the oracle's batch size and at BASELINE's batch 64 (where the grids are longer than the chip and workgroups of different samples
+interleave); the bounded wait never runs out; golden parity of the fused default is what every other GPU test runs."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from oracle import vae_ref as R
+from lunaris_orion_amd.vae import LunarisCoreVAE
+from lunaris_orion_amd.trainer import VAEStepper
+B, L = {B}, {L}
+m = LunarisCoreVAE(L); m.load_state_dict(R.closed_form_params(L)); m = m.to("cuda")
+x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+st = VAEStepper(m, gradient_accumulation_steps=1)
+out = {{}}
+for s in range(2):
+    recon, mu, logvar = st.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
+    met = st.metrics()                       # raises if a rendezvous ran out
+    out[f"recon{{s}}"], out[f"mu{{s}}"], out[f"logvar{{s}}"] = recon.cpu(), mu.cpu(), logvar.cpu()
+    for (name, _), g_ in zip(m.named_parameters(), st.parameter_grads()):
+        out[f"grad{{s}}/{{name}}"] = g_.detach().cpu().clone()
+    out[f"losses{{s}}"] = torch.tensor([met["recon_loss"], met["kl_loss"], met["grad_norm"]], dtype=torch.float64)
+eng = m._engine(B)
+# intermediate tensors of the last forward, read back from the workspace: a failure names the first layer that differs
+import ctypes as C
+from lunaris_orion_amd import _lib
+def dbg(which, s, k):
+    off, dims = C.c_size_t(), (C.c_int * 4)()
+    _lib.check(_lib.lib.lo_vae_debug_tensor(eng.handle, which, s, k, C.byref(off), dims))
+    n = dims[0] * dims[1] * dims[2] * dims[3]
+    return eng.ws[off.value:off.value + 2 * n].view(torch.float16).clone().cpu()
+for s_ in range(4):
+    for k_ in range(3):
+        out[f"a_enc{{s_}}_conv{{k_}}_raw"] = dbg(0, s_, k_)
+    out[f"b_enc{{s_}}_out"] = dbg(2, s_, 0)
+for s_ in range(4):
+    out[f"c_dec{{s_}}_raw"] = dbg(1, s_, 0)
+    out[f"d_dec{{s_}}_act"] = dbg(3, s_, 0)
+out["fused_layers"] = torch.tensor(eng.fused_gn_layers)
+out["sync_fail"] = eng.sync_fail.cpu().clone()
+out["params"] = m.flat_parameters().detach().cpu().clone()
+torch.save(out, sys.argv[1])
+"""
+
+
+def _run(tmp_path, tag, B, L, env_extra):
+    f = tmp_path / f"{tag}.pt"
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", _SNIPPET.format(root=ROOT, B=B, L=L), str(f)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(f)
+
+
+@pytest.mark.parametrize("B,L", [(2, 256), (5, 256), (64, 512)])
+def test_fused_groupnorm_epilogue_equals_the_separate_pass_bit_for_bit(tmp_path, B, L):
+    fused = _run(tmp_path, "fused", B, L, {"LO_GNB_APPLY_FUSE": "0"})
+    plain = _run(tmp_path, "plain", B, L, {"LO_GN_FUSE": "0", "LO_GNB_APPLY_FUSE": "0"})
+    assert int(plain["fused_layers"]) == 0 and int(fused["fused_layers"]) >= 8, (int(fused["fused_layers"]), int(plain["fused_layers"]))
+    assert int(fused["sync_fail"].item()) == 0
+    bad = [(k, (fused[k].double() - plain[k].double()).abs().max().item()) for k in sorted(fused)
+           if k not in ("fused_layers", "sync_fail") and not torch.equal(fused[k], plain[k])]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("B,L", [(2, 256), (5, 256), (64, 512)])
+def test_fused_groupnorm_backward_apply_equals_the_separate_pass(tmp_path, B, L):
+    """The GroupNorm-backward APPLY inside the data-gradient epilogue of the consuming layer (lo_internal.h: LoGnBwdFuse::dv; 11 of
+    the 16 layers) against the separate lo_gn_bwd_apply launches (LO_GNB_APPLY_FUSE=0): the same group sums in the same order and the
+    same element arithmetic, so every dv -- hence every weight, GroupNorm and Linear gradient, every loss and every updated
+    parameter of a second step -- is bitwise the same, EXCEPT the conv bias gradients of the fused layers: those are sums of dv whose
+    partial rows are per tile instead of per chunk (another summation order: 1e-6 relative)."""
+    fused = _run(tmp_path, "fused", B, L, {})
+    plain = _run(tmp_path, "plain", B, L, {"LO_GNB_APPLY_FUSE": "0"})
+    assert int(fused["sync_fail"].item()) == 0
+    bad = []
+    for k in sorted(fused):
+        if k in ("fused_layers", "sync_fail"):
+            continue
+        a, b = fused[k].double(), plain[k].double()
+        conv_bias = k.startswith("grad") and k.endswith(".0.bias")
+        if conv_bias or k.startswith(("grad1", "params", "recon1", "mu1", "logvar1", "losses1")) or k[:2] in ("a_", "b_", "c_", "d_"):
+            # conv bias gradients, and everything downstream of the first update (which has used them)
+            tol = 2e-6 * max(b.abs().max().item(), 1e-30) if conv_bias else 1e-4 * max(b.abs().max().item(), 1e-30)
+            if (a - b).abs().max().item() > tol:
+                bad.append((k, (a - b).abs().max().item(), tol))
+        elif not torch.equal(fused[k], plain[k]):
+            bad.append((k, (a - b).abs().max().item(), 0.0))
+    assert not bad, bad
