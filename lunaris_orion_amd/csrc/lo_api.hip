@@ -204,6 +204,7 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_bcnt;
   unsigned gba_epoch;
   bool dv_done; int np2;
+  size_t o_wslab_l;          // this layer's own weight-gradient slab (merged slab reduction: lo_wgrad_reduce_all)
 };
 
 struct Arena {
@@ -264,6 +265,13 @@ struct LoVae {
   float* norm_scratch;   // lo_vae_set_gradnorm_scratch: where a single-call backward leaves the early part of the gradient norm
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
   bool fuse_gnf;      // fuse GroupNorm + Mish of a conv output into that conv's epilogue (sample rendezvous between its workgroups)
+  // the weight-gradient slab reductions of the layers of one backward range in ONE launch (job table in the workspace) instead of
+  // one launch per layer: range 0 = decoder (4 layers), 1 + k = encoder stage 4 - k (3 layers; 2 for the first stage), issued on
+  // the side stream behind the range's last weight-gradient GEMM
+  bool merge_reduce;
+  size_t o_redjobs;
+  std::vector<LoWgradRedJob> redjobs_host;
+  int red_first[5], red_n[5], red_block0[5], red_blocks[5];
   bool fuse_gna;      // fuse the GroupNorm-backward APPLY pass into the data-gradient epilogue that already carries its reduction
   size_t o_sync_fail; // one word: set by a workgroup whose rendezvous poll ran out (never, unless a launch was lost)
   const void* sync_for_ws;
@@ -387,9 +395,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   LO_TRY(lo_make_geom(&h->g_head_d, LO_LINEAR, B, 1, 1, 2 * L, 32768));   // dxflat = dml Wt^T  (Wt = W^T packed)
   LO_TRY(lo_make_geom(&h->g_dfc, LO_LINEAR, B, 1, 1, L, 32768));          // y = z Wd^T
   LO_TRY(lo_make_geom(&h->g_dfc_d, LO_LINEAR, B, 1, 1, 32768, L));        // dz = dy Wdt^T
-  h->head_split = getenv("LO_HEAD_SPLIT") ? atoi(getenv("LO_HEAD_SPLIT")) : 32;     // K splits of the two K = 32768 Linear GEMMs (tuning knobs)
-  h->dfcd_split = getenv("LO_DFCD_SPLIT") ? atoi(getenv("LO_DFCD_SPLIT")) : 32;
-  LO_REQUIRE(h->head_split >= 1 && h->head_split <= 128 && h->dfcd_split >= 1 && h->dfcd_split <= 128, "LO_HEAD_SPLIT / LO_DFCD_SPLIT out of range");
+  h->head_split = h->dfcd_split = 32;      // K splits of the two K = 32768 Linear GEMMs (8 / 16 / 32 / 64 measured in round 2: 32)
   h->o_wp_head = ar.take((size_t)2 * L * 32768 * 2);
   h->o_wp_head_t = ar.take((size_t)2 * L * 32768 * 2);
   h->o_wp_dfc = ar.take((size_t)L * 32768 * 2);
@@ -426,6 +432,13 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     wslab = b > wslab ? b : wslab;
   }
   h->o_wslab = ar.take(wslab);
+  // one slab per layer as well: with the merged reduction a layer's partial sums stay until the end of its backward range
+  h->merge_reduce = !(getenv("LO_WGRAD_MERGE") && atoi(getenv("LO_WGRAD_MERGE")) == 0);
+  for (int s = 0; s < 4; ++s) {
+    for (int k = 0; k < 3; ++k) h->enc[s][k].o_wslab_l = (h->merge_reduce && !(s == 0 && k == 0)) ? ar.take(lo_wgrad_slab_bytes(h->enc[s][k].gf)) : 0;
+    h->dec[s].o_wslab_l = h->merge_reduce ? ar.take(lo_wgrad_slab_bytes(h->dec[s].gf)) : 0;
+  }
+  h->o_redjobs = ar.take(sizeof(LoWgradRedJob) * 16);
   // The two Linear weight gradients run on the MAIN stream while the decoder's conv weight gradients may still be running on
   // the side stream: they get their own slab.  (Found by the buffer audit of round 2: at latent 512 / 256 both Linear
   // gradients are written directly and never touch a slab, but at latent 64 / 128 lo_wgrad_nsplit() gives decoder.fc two
@@ -442,6 +455,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
   h->o_sync_fail = ar.take(256);
+
   // ---- fp8 operand mode: every forward conv whose geometry the e4m3 igemm covers (Cin % 128 == 0: the 128 / 256 / 512
   // channel ResBlock and stride-2 convs, the 512 / 256 / 128 channel transposed convs) reads an e4m3 copy of its input,
   // written by the kernel that produces the fp16 activation (which the backward still uses)
@@ -499,10 +513,9 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     // have workgroups ready, the dispatcher serves the chain first and the side work fills what it leaves (LO_SIDE_PRIO=0: default
     // priority, the round-1 behaviour).  Timeline before (tools/timeline.py): the first GroupNorm pass of a step took 302 us instead of
     // 17 beside the side stream's AdamW, data-gradient launches 55-65 us instead of 36-44 beside the weight gradients.
-    static const int side_prio = getenv("LO_SIDE_PRIO") ? atoi(getenv("LO_SIDE_PRIO")) : 1;
     int prio_least = 0, prio_greatest = 0;
     bool ok;
-    if (side_prio && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest)
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest)
       ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least) == hipSuccess;
     else
       ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
@@ -627,10 +640,48 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
       h->n_packjobs8 = (int)j8.size();
       h->pack_blocks8 = blocks8;
     }
+    if (h->merge_reduce) {
+      std::vector<LoWgradRedJob>& rj = h->redjobs_host;
+      rj.clear();
+      int rblocks = 0;
+      auto addr = [&](ConvLayer& c) {
+        const int ns = lo_wgrad_slab_splits(c.gf);
+        if (ns <= 0) return;                      // written directly: nothing to reduce
+        LoWgradRedJob j;
+        memset(&j, 0, sizeof(j));
+        j.slab = WSP(float, c.o_wslab_l); j.grad_off = h->p_off[c.p_w]; j.total = (int)lo_packed_weight_elems(c.gf); j.nsplit = ns;
+        j.block0 = rblocks; j.g = c.gf;
+        rblocks += lo_wgrad_reduce_blocks(c.gf);
+        rj.push_back(j);
+      };
+      auto range = [&](int r, auto&& fill) {
+        h->red_first[r] = (int)rj.size(); h->red_block0[r] = rblocks;
+        fill();
+        h->red_n[r] = (int)rj.size() - h->red_first[r]; h->red_blocks[r] = rblocks - h->red_block0[r];
+      };
+      range(0, [&] { for (int s = 3; s >= 0; --s) addr(h->dec[s]); });
+      for (int s = 3; s >= 0; --s)
+        range(4 - s, [&] { for (int k = 2; k >= (s == 0 ? 1 : 0); --k) addr(h->enc[s][k]); });
+      LO_REQUIRE(rj.size() <= 16, "too many slab-reduction jobs");
+      if (!rj.empty())
+        LO_HIP(hipMemcpyAsync(WSP(void, h->o_redjobs), rj.data(), rj.size() * sizeof(LoWgradRedJob), hipMemcpyHostToDevice, st));
+    }
     h->packjobs_for_ws = ws;
     h->packjobs_for_params = (const void*)P;
   }
   return LO_OK;
+}
+
+// the merged slab reduction of backward ranges r0..r1 (adjacent in the job table) on `st`
+static int vae_reduce_slabs(LoVae* h, int r0, int r1, float* G, void* ws, float inv, hipStream_t st, const char* tag) {
+  if (!h->merge_reduce) return LO_OK;
+  int n = 0, blocks = 0;
+  for (int r = r0; r <= r1; ++r) { n += h->red_n[r]; blocks += h->red_blocks[r]; }
+  if (n == 0) return LO_OK;
+  if (g_lo_prof_on) g_lo_prof_tag = tag;
+  int r_ = lo_wgrad_reduce_all(WSP(LoWgradRedJob, h->o_redjobs) + h->red_first[r0], n, blocks, h->red_block0[r0], G, inv, st);
+  g_lo_prof_tag = nullptr;
+  return r_;
 }
 
 // side-stream bookkeeping: one event per operand-refresh level (see LoVae::ev_lvl)
@@ -644,7 +695,7 @@ static int vae_side_record(LoVae* h, int lvl, hipStream_t on) {
 // the same stream has just refreshed: 4 bytes of traffic per element instead of the 6 of a transposing cast from fp32, and the
 // same bits (LO_TRANSPOSE_F32=1: from the fp32 parameters).  2L and 32768 are multiples of 64 (L is 128, 256 or 512).
 static int vae_linear_transposes(LoVae* h, const float* P, void* ws, hipStream_t st) {
-  static const bool from_f32 = getenv("LO_TRANSPOSE_F32") && atoi(getenv("LO_TRANSPOSE_F32")) != 0;
+  constexpr bool from_f32 = false;
   const int L = h->L;
   if (from_f32 || (2 * L) % 64 != 0 || L % 64 != 0) {
     LO_TRY(lo_transpose_cast(PRM(h->idx_fc_mu_w), WSP(f16, h->o_wp_head_t), 2 * L, 32768, st));
@@ -677,7 +728,7 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
     return hi > lo ? lo_adamw(P + lo, G + lo, M + lo, V + lo, hi - lo, norm, lr, b1, b2, eps, wd, step, sd, cast) : LO_OK;
   };
   // the Linear layers' fp16 forward operands come out of the AdamW pass itself (LO_ADAM_CAST=0: separate cast launches)
-  static const int fuse_cast = getenv("LO_ADAM_CAST") ? atoi(getenv("LO_ADAM_CAST")) : 1;
+  constexpr int fuse_cast = 1;
   const size_t nh = (size_t)2 * L * 32768, nd = (size_t)32768 * L;
   // level 2: encoder stage 4 (10 % of the parameters): first consumer ~0.45 ms into the forward
   LO_TRY(adam(b4, bh));
@@ -740,8 +791,7 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
   }
   // the conv pack too (LO_SIDE_PACK, default on): the first conv of the encoder reads the fp32 weights directly, so the pack
   // hides behind it and its GroupNorm; every other consumer waits on its level
-  static const int side_pack = getenv("LO_SIDE_PACK") ? atoi(getenv("LO_SIDE_PACK")) : 1;
-  hipStream_t ps = side_pack ? cs : st;
+  hipStream_t ps = cs;
   LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs, h->pack_blocks, ps));
   if (h->fp8_fwd) LO_TRY(lo_pack_f8_all(WSP(LoPackF8Job, h->o_packjobs8), h->n_packjobs8, h->pack_blocks8, ps));
   if (ps != st) { LO_TRY(vae_side_record(h, 1, ps)); LO_TRY(vae_side_record(h, 2, ps)); }
@@ -763,10 +813,6 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
 //   side  :  pack encoder stages 1..3 (level 1) -> AdamW stage 4 + its packs (level 2) -> AdamW fc_mu|fc_logvar + fp16 copy (3)
 //            -> AdamW decoder.fc / decoder + copy + packs (4) -> transposed copies (5).  The forward waits for level 2 before
 //            encoder stage 4, 3 before the heads, 4 before the decoder; the backward for level 5.
-// LO_DEFER_OPT=1: levels 2..5 are not enqueued here but by the next lo_vae_forward behind its first stage (vae_flush_deferred;
-// everything else that touches the parameters flushes first: lo_vae_join, lo_vae_pack, the level waits, lo_vae_destroy).  The
-// timeline (tools/timeline.py) shows the 0.33 ms AdamW kernel beside the HBM-bound first stage of the next forward, whose first
-// GroupNorm pass then takes 302 us instead of 17 -- but moving that traffic behind the first stage does not shorten the step.
 // Until level 4 has completed, parameters [b4, n) and their Adam moments are in flight on the side stream: lo_vae_join orders
 // another stream (e.g. before the caller reads the parameters itself).  Without the side stream everything runs in order on
 // `stream`.  presummed != 0: scratch[512..1024) already holds the sum of squares of [b, n) (lo_vae_set_gradnorm_scratch).
@@ -798,12 +844,9 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
   h->defer.pending = true;
   h->defer.P = P; h->defer.G = G; h->defer.M = M; h->defer.V = V; h->defer.ws = ws; h->defer.norm = norm;
   h->defer.lr = lr; h->defer.beta1 = beta1; h->defer.beta2 = beta2; h->defer.eps = eps; h->defer.wd = weight_decay; h->defer.step = step;
-  // Measured (round 2, interleaved pairs of 300-step runs): deferring the tail behind the next forward's first stage (LO_DEFER_OPT=1,
-  // LO_DEFER_STAGE=0/1/2) gives 20 096 / 20 117 / 19 962 / 20 158 / 20 097 / 20 194 sprites/s against 19 965 / 20 128 for
-  // enqueueing it at once: no difference -- where the AdamW traffic lands only changes WHICH kernels it slows down, not the sum.
-  // Default: at once (fewer states to reason about); the deferred form stays behind the knob.
-  static const int defer_tail = getenv("LO_DEFER_OPT") ? atoi(getenv("LO_DEFER_OPT")) : 0;
-  if (!defer_tail) LO_TRY(vae_flush_deferred(h, nullptr));
+  // (deferring this tail behind the next forward's first stage was measured in round 2: no difference -- where the AdamW traffic
+  // lands only changes WHICH kernels it slows down, not the sum -- so it is enqueued at once)
+  LO_TRY(vae_flush_deferred(h, nullptr));
   return LO_OK;
 }
 // `stream` waits for whatever lo_vae_pack / lo_vae_optimizer_step left running (or still to be enqueued) on the side stream.
@@ -834,18 +877,8 @@ static int vae_ensure_sync_init(LoVae* h, void* ws, hipStream_t st) {
 }
 
 // in8: e4m3 copy of `in` (fp8 mode, layers with c.f8); y8: where to leave the e4m3 copy of y (0 = nobody reads it)
-// xprod: the conv+GN+Mish layer (plain mode) whose GroupNorm + Mish this conv applies on load; `in` is then its raw output o_v and
-//        its activation o_a / statistics are written by this launch (lo_conv3x3_pp<XF = 2>)
-// defer_gn: this layer's own GroupNorm pass is left to its consumer (which will be called with xprod = &c)
-static bool vae_gn_on_load(const LoVae* h, const ConvLayer& prod, const ConvLayer& cons) {
-  // Measured at batch 64 (three interleaved pairs of 300-step runs): 21 425 sprites/s with it, 21 593 without.  The separate passes
-  // it removes take 16 / 11 / 9 us (64 / 128 / 256 channels) but the consuming convs get 14 / 9 / 10 us slower: the Mish of the
-  // halo-inflated patch runs with every wave of the workgroup stopped between two barriers, off the MFMA pipe.  Off by default.
-  static const int on = getenv("LO_GN_ON_LOAD") ? atoi(getenv("LO_GN_ON_LOAD")) : 0;
-  return on && !h->fp8_fwd && !cons.f8 && cons.Cin <= 256 && lo_conv3_fuses_gnb(cons.gf);
-}
 static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16* y, int mode, const float* P, void* ws,
-                   hipStream_t st, size_t o_in8 = 0, size_t o_y8 = 0, ConvLayer* xprod = nullptr, bool defer_gn = false) {
+                   hipStream_t st, size_t o_in8 = 0, size_t o_y8 = 0) {
   static char ftag[64][64];
   static int fcount = 0;
   if (g_lo_prof_on && g_lo_prof_layers) {
@@ -856,7 +889,7 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
   int r_;
   // GroupNorm + Mish inside the conv's own epilogue (the workgroups of a sample exchange their sums: LoGnFuse) where the kernel that
   // owns this geometry supports it; the separate lo_gn_fwd pass below is then not run.  Same statistics, same arithmetic, same bits.
-  const bool fuse = c.gnf && !c.f8 && !xprod && !defer_gn && !o_y8;
+  const bool fuse = c.gnf && !c.f8 && !o_y8;
   LoGnFuse gf;
   if (fuse) {
     memset(&gf, 0, sizeof(gf));
@@ -870,17 +903,13 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
     LO_REQUIRE(o_in8, "fp8 mode: no e4m3 copy of the input of a conv %d->%d", c.Cin, c.Cout);
     r_ = lo_conv_run_f8(c.gf, WSP(uint8_t, o_in8), WSP(uint8_t, c.o_wp8), WSP(float, c.o_wscale), PRM(c.p_b), nullptr, WSP(f16, c.o_v),
                         WSP(float, c.o_part), st);
-  } else if (xprod) {
-    LoGnApplyFuse xg{WSP(float, xprod->o_part), xprod->MT, PRM(xprod->p_gw), PRM(xprod->p_gb), WSP(float, xprod->o_stats), WSP(f16, xprod->o_a)};
-    r_ = lo_conv_run(c.gf, WSP(f16, xprod->o_v), WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), WSP(float, c.o_part), nullptr, 1, st,
-                     nullptr, nullptr, &xg);
   } else {
     r_ = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), PRM(c.p_b), nullptr, WSP(f16, c.o_v), fuse ? nullptr : WSP(float, c.o_part), nullptr, 1, st,
-                     nullptr, nullptr, nullptr, fuse ? &gf : nullptr);
+                     nullptr, nullptr, fuse ? &gf : nullptr);
   }
   g_lo_prof_tag = nullptr;
   if (r_ != LO_OK) { if (fuse) --c.gnf_epoch; return r_; }
-  if (defer_gn || fuse) return LO_OK;
+  if (fuse) return LO_OK;
   return lo_gn_fwd(WSP(f16, c.o_v), WSP(float, c.o_part), c.MT, PRM(c.p_gw), PRM(c.p_gb), other, y, WSP(float, c.o_stats), h->B,
                    c.Ho * c.Wo, c.Cout, mode, st, o_y8 ? WSP(uint8_t, o_y8) : nullptr);
 }
@@ -938,29 +967,22 @@ static int vae_encoder_forward(LoVae* h, const float* x, const float* eps, uint6
     ConvLayer& c0 = h->enc[s][0];
     ConvLayer& c1 = h->enc[s][1];
     ConvLayer& c2 = h->enc[s][2];
-    // GroupNorm + Mish of c0 / c1 on the operand load of the ResBlock conv that consumes them, where that conv runs on the
-    // fused-tap kernel (stages 1..3 at batch 64): the activation is still written (by that conv), the separate pass is not run
-    const bool f01 = vae_gn_on_load(h, c0, c1), f12 = vae_gn_on_load(h, c1, c2);
     if (s == 0) {
       LO_TRY(lo_first_conv_fwd(x, PRM(c0.p_w), PRM(c0.p_b), WSP(f16, c0.o_v), WSP(float, c0.o_part), B, st));
-      if (!f01)
-        LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
-                         WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
+      LO_TRY(lo_gn_fwd(WSP(f16, c0.o_v), WSP(float, c0.o_part), c0.MT, PRM(c0.p_gw), PRM(c0.p_gb), nullptr, WSP(f16, c0.o_a),
+                       WSP(float, c0.o_stats), B, c0.Ho * c0.Wo, c0.Cout, 0, st, c0.o_a8 ? WSP(uint8_t, c0.o_a8) : nullptr));
       LO_TRY(vae_wait_level(h, st, 1));
     } else {
       // the last stage's packed weights are refreshed at the END of the side-stream chain of a pipelined optimizer step
       // (after the AdamW of everything from this stage on): same event as the Linear casts
       if (s == 3) LO_TRY(vae_wait_level(h, st, 2));
-      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8, nullptr, f01));
+      LO_TRY(conv_gn(h, c0, cur, nullptr, WSP(f16, c0.o_a), 0, P, ws, st, cur8, c0.o_a8));
     }
-    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8, f01 ? &c0 : nullptr, f12));
+    LO_TRY(conv_gn(h, c1, WSP(f16, c0.o_a), nullptr, WSP(f16, c1.o_a), 0, P, ws, st, c0.o_a8, c1.o_a8));
     // ResBlock tail: out = mish(mish(GN(conv2)) + identity); c2.o_a is unused, the result is the stage output
-    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st, c1.o_a8, h->o_eout8[s], f12 ? &c1 : nullptr));
+    LO_TRY(conv_gn(h, c2, WSP(f16, c1.o_a), WSP(f16, c0.o_a), WSP(f16, h->o_eout[s]), 2, P, ws, st, c1.o_a8, h->o_eout8[s]));
     cur = WSP(f16, h->o_eout[s]);
     cur8 = h->o_eout8[s];
-    // the deferred tail of a pipelined optimizer step goes to the side stream behind this stage (see lo_vae_optimizer_step)
-    static const int flush_after = getenv("LO_DEFER_STAGE") ? atoi(getenv("LO_DEFER_STAGE")) : 0;
-    if (s == flush_after) LO_TRY(vae_flush_deferred(h, st));
   }
   // ---- heads + reparameterisation (lunar_generate.py:150-152, 259-261)
   LO_TRY(lo_nhwc_to_nchw_f16(cur, WSP(f16, h->o_xflat), B, 64, 512, st));
@@ -1035,7 +1057,7 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
 // its GroupNorm-backward reduction is then fused into the data-gradient epilogue (prod->np1 records the row count).
 static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, int mode, const f16* layer_in, f16* ds,
                        f16* din, const f16* add_src, const float* P, float* G, void* ws, float inv_scale, hipStream_t st,
-                       ConvLayer* prod = nullptr) {
+                       ConvLayer* prod = nullptr, bool din_has_other_readers = false) {
   // every layer has its own dv buffer: the side-stream weight gradient of layer k may still be reading it while the main
   // stream produces the dv of the following layers (no event back from the side stream: two host calls per layer less)
   const int k = h->bwd_layer++;
@@ -1049,14 +1071,16 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   if (ov) {
     LO_HIP(hipEventRecord(h->ev_dv[k & 1], st));
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[k & 1], 0));
-    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
+    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, h->merge_reduce ? WSP(float, c.o_wslab_l) : WSP(float, h->o_wslab), GRD(c.p_w), inv_scale,
+                        h->side, h->merge_reduce));
   } else {
     static char wtag[32][64];
     if (g_lo_prof_on && g_lo_prof_layers) {
       snprintf(wtag[k & 31], 64, "wgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
       g_lo_prof_tag = wtag[k & 31];
     }
-    int r_ = lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st);
+    int r_ = lo_wgrad_run(c.gf, layer_in, dv, h->merge_reduce ? WSP(float, c.o_wslab_l) : WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st,
+                          h->merge_reduce);
     g_lo_prof_tag = nullptr;
     if (r_ != LO_OK) return r_;
   }
@@ -1072,6 +1096,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
         gb.counter = WSP(unsigned int, prod->o_bcnt);
         gb.target = (++prod->gba_epoch) * (unsigned)mts;
         gb.fail = WSP(unsigned int, h->o_sync_fail);
+        gb.keep_out = din_has_other_readers;      // the decoder's data gradients are also the encoder's skip gradients
         prod->dv_done = true;
         prod->np2 = mts;
       }
@@ -1222,10 +1247,11 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     const f16* layer_in = s > 0 ? WSP(f16, h->dec[s - 1].o_a) : WSP(f16, h->o_h0);
     f16* din = s > 0 ? WSP(f16, h->o_skipg[3 - s]) : Ga;   // up4->skipg[0] (wrt up3 out), up3->skipg[1], up2->skipg[2], up1->Ga
     // mode 1 (skip add) has the same du as mode 0; the skip branch receives gout unchanged (kept in skipg)
-    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, din, nullptr, P, G, ws, inv, st, s > 0 ? &h->dec[s - 1] : nullptr));
+    LO_TRY(conv_gn_bwd(h, c, gout, nullptr, 0, layer_in, nullptr, din, nullptr, P, G, ws, inv, st, s > 0 ? &h->dec[s - 1] : nullptr, true));
     gout = din;
   }
   // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
+  LO_TRY(vae_reduce_slabs(h, 0, 0, G, ws, inv, (h->overlap && !g_lo_prof_on) ? h->side : st, "wgrad reduce (decoder layers, merged)"));
   // ---- decoder.fc
   LO_TRY(lo_nhwc_to_nchw_f16(Ga, Gb, B, 64, 512, st));                       // Gb = dy of decoder.fc, [B][32768] c-major
   LO_TRY(lo_colsum_f16(Gb, GRD(h->idx_dfc_b), B, 32768, inv, st));
@@ -1311,6 +1337,8 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
                                  WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st, c0.np1));
       LO_TRY(lo_first_conv_wgrad(x, dv0, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
+    // this stage's weight-gradient GEMMs are all on the side stream now: their slabs in one launch behind them
+    LO_TRY(vae_reduce_slabs(h, 4 - s, 4 - s, G, ws, inv, (h->overlap && !g_lo_prof_on) ? h->side : st, "wgrad reduce (encoder layers, merged)"));
   }
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer
   if (h->overlap && !g_lo_prof_on) {

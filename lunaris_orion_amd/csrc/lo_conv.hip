@@ -195,6 +195,7 @@ struct IgemmArgs {
   unsigned int* gb_counter;
   unsigned int gb_target;
   unsigned int* gb_fail;
+  int gb_keep_out;
   const float* f8_scale;   // fp8 operand path: [n_phase][Cout] dequantisation factor (weight row scale / activation scale)
   int out_pitch, out_choff;   // out_pitch > 0: `out` has out_pitch channels per pixel, this op's channels start at out_choff
   LoGnFuse gf;         // gf.y != null: GroupNorm + Mish of this output in the epilogue (sample rendezvous, lo_common.h)
@@ -510,9 +511,10 @@ __global__ __launch_bounds__(256) void lo_igemm_nt(IgemmArgs a) {
     }
     if (a.out_pitch > 0)   // concatenated output tensor (teacher feature extractor); add_src / gb_v are not used with it
       *reinterpret_cast<f16x8*>(a.out + ((size_t)(n_img * g.Hout + oy) * g.Wout + ox) * a.out_pitch + a.out_choff + n0 + ochunk * 8) = h;
-    else if (a.gb_dv)      // fused GroupNorm-backward apply: the activation gradient only lives in this tile (LDS), nobody else reads it
+    else if (a.gb_dv) {    // fused GroupNorm-backward apply: the activation gradient lives on in this tile (LDS); stored only if somebody else reads it
       *reinterpret_cast<f16x8*>(so + ml * OPITCH + ochunk * 16) = h;
-    else
+      if (a.gb_keep_out) *reinterpret_cast<f16x8*>(a.out + off) = h;
+    } else
       *reinterpret_cast<f16x8*>(a.out + off) = h;
     if (a.bn_partial) {
 #pragma unroll
@@ -944,11 +946,11 @@ __global__ __launch_bounds__(256) void lo_wgrad_tn(WgradArgs a) {
 // 16-byte slab loads); group sg sums splits sg, sg+4, ... (4 loads in flight), the four partial sums are added in a fixed
 // order through LDS (bitwise reproducible).  Small weight tensors (36 k elements, up to 256 splits) get 4x the
 // workgroups and 4x the loads in flight of a one-thread-per-column loop.
-__global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
-                                                              int total, int nsplit, float scale) {
+__device__ __forceinline__ void lo_wgrad_reduce_block(const float* __restrict__ slab, float* __restrict__ grad, const LoGeom& g,
+                                                      int total, int nsplit, float scale, int bid) {
   __shared__ f32x4 part[4][64];
   const int col = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int i = (blockIdx.x * 64 + col) * 4;
+  const int i = (bid * 64 + col) * 4;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (i < total) {
     const float* src = slab + i;
@@ -976,6 +978,28 @@ __global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __res
   float* dst = grad + (size_t)n * g.sn + (size_t)c * g.sc + g.rs[p][t];
 #pragma unroll
   for (int e = 0; e < 4; ++e) dst[(size_t)e * g.sc] = v[e] * scale;
+}
+__global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
+                                                              int total, int nsplit, float scale) {
+  lo_wgrad_reduce_block(slab, grad, g, total, nsplit, scale, (int)blockIdx.x);
+}
+// the slab reductions of SEVERAL layers in one launch: job table in device memory (uploaded once per workspace by the executor);
+// job j owns the blocks [block0, block0 + ceil(total / 256)); grad = flat gradient buffer + the job's element offset
+__global__ __launch_bounds__(256) void lo_wgrad_reduce_all_kernel(const LoWgradRedJob* __restrict__ jobs, int njobs, int block_base,
+                                                                  float* __restrict__ G, float scale) {
+  const int bid = (int)blockIdx.x + block_base;
+  int j = 0;
+  while (j + 1 < njobs && bid >= jobs[j + 1].block0) ++j;
+  const LoWgradRedJob& J = jobs[j];
+  lo_wgrad_reduce_block(J.slab, G + J.grad_off, J.g, J.total, J.nsplit, scale, bid - J.block0);
+}
+int lo_wgrad_reduce_blocks(const LoGeom& g) { return (geom_packed_elems(g) / 4 + 63) / 64; }
+int lo_wgrad_reduce_all(const LoWgradRedJob* jobs_dev, int njobs, int nblocks, int block_base, float* G, float scale, hipStream_t st) {
+  if (njobs <= 0 || nblocks <= 0) return LO_OK;
+  LoProfScope _p("lo_wgrad_reduce", 0, 0, st);
+  hipLaunchKernelGGL(lo_wgrad_reduce_all_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, block_base, G, scale);
+  LO_LAUNCH_CHECK("wgrad_reduce_all");
+  return LO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1036,36 +1060,15 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int NSTAGE = STAGE_BYTES >= 32768 ? 2 : (STAGE_BYTES >= 16384 ? 3 : 4);
   // short K loops (<= 9 steps: the 64-channel 3x3 layers) are prologue / epilogue bound: one LDS stage less puts a third
-  // workgroup on the CU (measured 46.9 -> 39.8 us at 64 channels, 64x64; no gain on the longer loops).  LO_SHALLOW_PIPE=0/1 forces.
-  static const int shallow_env = getenv("LO_SHALLOW_PIPE") ? atoi(getenv("LO_SHALLOW_PIPE")) : -1;
+  // workgroup on the CU (measured 46.9 -> 39.8 us at 64 channels, 64x64; no gain on the longer loops; more stages where the grid
+  // leaves LDS unused did not make any launch faster either: these launches sit at the L2 -> LDS rate)
   int ksteps_max = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps_max = g.T[p] * (g.Cin / BK) > ksteps_max ? g.T[p] * (g.Cin / BK) : ksteps_max;
-  const bool shallow = shallow_env >= 0 ? shallow_env != 0 : ksteps_max <= 9;
-  // deep pipeline (LO_DEEP_PIPE=k: k more stages): a launch whose grid leaves LDS unused (<= 2 workgroups per CU on the VAE's short
-  // grids) spends it on more K steps in flight, as long as that costs no resident workgroup the grid could have used
-  static const int deep_env = getenv("LO_DEEP_PIPE") ? atoi(getenv("LO_DEEP_PIPE")) : 0;
-  const int wgs_cu = ((int)grid.x + 255) / 256;
-  auto fits = [&](int lds_new, int lds_old) {
-    const int res_old = (160 * 1024) / lds_old, res_new = (160 * 1024) / lds_new;
-    return res_new >= 1 && res_new >= (wgs_cu < res_old ? wgs_cu : res_old);
-  };
-  constexpr int L0 = igemm_lds_bytes<BM, BN, BK, NSTAGE, false>();
-  int deep = 0;
-  if (a.nsplit <= 1 && !shallow && deep_env > 0 && ksteps_max >= 4 * NSTAGE) {
-    if (deep_env >= 3 && fits(igemm_lds_bytes<BM, BN, BK, NSTAGE + 3, false>(), L0)) deep = 3;
-    else if (deep_env >= 2 && fits(igemm_lds_bytes<BM, BN, BK, NSTAGE + 2, false>(), L0)) deep = 2;
-    else if (fits(igemm_lds_bytes<BM, BN, BK, NSTAGE + 1, false>(), L0)) deep = 1;
-  }
+  const bool shallow = ksteps_max <= 9;
   if (a.nsplit > 1)
     LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE, true>(grid, a, st));
   else if (shallow && NSTAGE > 2)
     LO_CHECK(igemm_launch<BM, BN, BK, (NSTAGE > 2 ? NSTAGE - 1 : 2), false>(grid, a, st));
-  else if (deep == 3)
-    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE + 3, false>(grid, a, st));
-  else if (deep == 2)
-    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE + 2, false>(grid, a, st));
-  else if (deep == 1)
-    LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE + 1, false>(grid, a, st));
   else
     LO_CHECK(igemm_launch<BM, BN, BK, NSTAGE, false>(grid, a, st));
   LO_LAUNCH_CHECK("igemm");
@@ -1200,8 +1203,7 @@ int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStrea
 // GroupNorm group.  mts / nt: P1 rows per sample and n tiles per row of the launch.
 bool lo_conv_gnb_apply_tiles(const LoGeom& g, int* mts, int* nt) {
   if (g.n_phase != 1 || (g.Cout >> 3) < 8 || g.Cout % 64 != 0 || g.Cin % 64 != 0) return false;
-  if (lo_conv4s2_patch_applies(g)) return false;
-  if (lo_conv3_tiles_per_image(g, false) > 0) return lo_conv3_fuses_gnb(g) && lo_conv3_gn_fuse_tiles(g, mts, nt);
+  if (lo_conv3_tiles_per_image(g, false) > 0) return lo_conv3_gn_fuse_tiles(g, mts, nt);
   int bm, bn;
   lo_conv_pick_tile(g, &bm, &bn);
   const int per_sample = g.GH * g.GW;
@@ -1228,12 +1230,12 @@ bool lo_conv_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt) {
 
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb, const LoConvExtra* ex,
-                const LoGnApplyFuse* xg, const LoGnFuse* gf) {
+                const LoGnFuse* gf) {
   IgemmArgs a;
   memset(&a.gf, 0, sizeof(a.gf));
   if (gf) {
     int mts = 0, nt = 0;
-    LO_REQUIRE(nsplit <= 1 && !add_src && !gb && !ex && !xg && gf->y && gf->xbuf && gf->counter && gf->fail && gf->gamma && gf->beta &&
+    LO_REQUIRE(nsplit <= 1 && !add_src && !gb && !ex && gf->y && gf->xbuf && gf->counter && gf->fail && gf->gamma && gf->beta &&
                (gf->mode == 0 || gf->other), "lo_conv_run: bad fused-GroupNorm arguments");
     LO_REQUIRE(lo_conv_gn_fuse_tiles(g, &mts, &nt) && mts == gf->MTs && nt == gf->NT,
                "lo_conv_run: fused GroupNorm asked for a geometry / tile grid the kernel does not have (check lo_conv_gn_fuse_tiles)");
@@ -1243,7 +1245,7 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   a.gb_v = gb ? gb->v : nullptr; a.gb_stats = gb ? gb->stats : nullptr; a.gb_gamma = gb ? gb->gamma : nullptr;
   a.gb_beta = gb ? gb->beta : nullptr; a.gb_P1 = gb ? gb->P1 : nullptr;
   a.gb_dv = gb ? gb->dv : nullptr; a.gb_P2 = gb ? gb->P2 : nullptr; a.gb_counter = gb ? gb->counter : nullptr;
-  a.gb_target = gb ? gb->target : 0u; a.gb_fail = gb ? gb->fail : nullptr;
+  a.gb_target = gb ? gb->target : 0u; a.gb_fail = gb ? gb->fail : nullptr; a.gb_keep_out = gb && gb->keep_out ? 1 : 0;
   if (gb && gb->dv) {
     int mts = 0, nt = 0;
     LO_REQUIRE(gb->P2 && gb->counter && gb->fail && lo_conv_gnb_apply_tiles(g, &mts, &nt),
@@ -1263,13 +1265,10 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   int ksteps = 0;
   for (int p = 0; p < g.n_phase; ++p) ksteps = g.T[p] * (g.Cin / BK) > ksteps ? g.T[p] * (g.Cin / BK) : ksteps;
   a.ksteps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
-  if (a.nsplit == 1 && !gn_partial && !ex && !xg && lo_conv4s2_patch_applies(g))
-    return lo_conv4s2_patch_run(g, in, wp, bias, add_src, out, st, gb);   // ... and its data gradient
-  if (a.nsplit == 1 && !add_src && !gb && !ex && !xg && lo_convt4_patch_applies(g))
+  if (a.nsplit == 1 && !add_src && !gb && !ex && !gf && lo_convt4_patch_applies(g))
     return lo_convt4_patch_run(g, in, wp, bias, out, gn_partial, st);   // last transposed conv of the decoder, patch-resident
   if (a.nsplit == 1 && lo_conv3_tiles_per_image(g, ex != nullptr) > 0 && (!gb || lo_conv3_fuses_gnb(g)))
-    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb, xg, gf);   // fused-tap kernel for 3x3 stride-1
-  LO_REQUIRE(!xg, "lo_conv_run: GroupNorm on load is only available in the fused-tap kernel (check lo_conv3_fuses_gnb first)");
+    return lo_conv3_run(g, in, wp, bias, add_src, out, gn_partial, st, ex, gb, gf);   // fused-tap kernel for 3x3 stride-1
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");
     LO_REQUIRE(BK == 64 && g.Cout % 64 == 0, "lo_conv_run: split-K path needs Cin%%64==0 and Cout%%64==0");
@@ -1303,7 +1302,7 @@ void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out) {
   const int per_sample = g.GH * g.GW;
   const size_t M = (size_t)g.B * per_sample;
   const int BK = (g.Cin % 64 == 0) ? 64 : 32;
-  static const int min_wgs = getenv("LO_MIN_WGS") ? atoi(getenv("LO_MIN_WGS")) : 512;
+  constexpr int min_wgs = 512;     // 256 / 384 / 512 / 768 / 1024 swept twice (rounds 1, 2): a plateau, 512 kept
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   int bm = 64, bn = (g.Cout % 64 == 0) ? 64 : 32;
   if (BK == 32) {
@@ -1319,8 +1318,6 @@ void lo_conv_pick_tile(const LoGeom& g, int* bm_out, int* bn_out) {
       if (((M + cm - 1) / cm) * (g.Cout / cn) * g.n_phase >= (size_t)min_wgs) break;
     }
   }
-  static const char* force = getenv("LO_FORCE_TILE");   // tuning knob "BMxBN"
-  if (force) { int fm = 0, fn = 0; if (sscanf(force, "%dx%d", &fm, &fn) == 2 && g.Cout % fn == 0 && per_sample % fm == 0 && BK == 64) { bm = fm; bn = fn; } }
   *bm_out = bm; *bn_out = bn;
 }
 int lo_conv_tile_m(const LoGeom& g) {
@@ -1334,7 +1331,6 @@ int lo_conv_bn_rows(const LoGeom& g) {
   return (int)(((size_t)g.B * g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase);
 }
 int lo_conv_gnb_rows(const LoGeom& g) {
-  if (lo_conv4s2_patch_applies(g)) return lo_conv4s2_patch_tiles_per_image(g);
   if (lo_conv3_fuses_gnb(g)) return lo_conv3_tiles_per_image(g, false);
   return (g.GH * g.GW / lo_conv_tile_m(g)) * g.n_phase;
 }
@@ -1371,7 +1367,7 @@ int lo_wgrad_nsplit(const LoGeom& g) {
   long tiles = (long)((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps;
   int M = g.B * g.GH * g.GW;
   int ms_total = (M + bkp - 1) / bkp;
-  static const int target = getenv("LO_WGRAD_WGS") ? atoi(getenv("LO_WGRAD_WGS")) : 768;
+  constexpr int target = 768;      // 512 / 768 / 1024 swept in round 2: inside +-0.5 %
   long want = (target + tiles - 1) / tiles;
   // every split writes (and the reduce pass re-reads) one fp32 slab: keep the slab traffic under ~24 MB per launch,
   // but never go below one workgroup per CU
@@ -1386,7 +1382,19 @@ int lo_wgrad_nsplit(const LoGeom& g) {
   return (int)want;
 }
 
-int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st) {
+// pixel splits the kernel lo_wgrad_run launches for g really writes (the multi-tap kernel drops empty splits); 0 = the gradient is
+// written directly (no slab, no reduce)
+int lo_wgrad_slab_splits(const LoGeom& g) {
+  if (lo_wgrad3_nsplit(g) > 0) {
+    const int nchunks = g.B * g.Hin * g.Win / 32, ns = lo_wgrad3_nsplit(g), cps = (nchunks + ns - 1) / ns;
+    return (nchunks + cps - 1) / cps;
+  }
+  const int ns = lo_wgrad_nsplit(g);
+  return (ns == 1 && g.sc == 1) ? 0 : ns;
+}
+
+// defer_reduce: leave the slab; the caller sums it later (lo_wgrad_reduce_all with a job built from lo_wgrad_slab_splits)
+int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st, bool defer_reduce) {
   if (lo_wgrad3_nsplit(g) > 0) {
     int nsplit = 0;
     const int total = geom_packed_elems(g);
@@ -1395,6 +1403,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
       int r = lo_wgrad3_run(g, x, dy, slab, st, &nsplit);
       if (r != LO_OK) return r;
     }
+    if (defer_reduce) return LO_OK;
     LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);
     hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
     LO_LAUNCH_CHECK("wgrad_reduce");
@@ -1417,7 +1426,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g);
   a.taps = taps;
   dim3 grid(((g.Cout + bmw - 1) / bmw) * (g.Cin / bnw) * taps * a.nsplit);
-  static const int wg_stages = getenv("LO_WGRAD_STAGES") ? atoi(getenv("LO_WGRAD_STAGES")) : 3;   // 64-pixel steps: LDS stages (3 where the tile fits: +0.9 % on the step)
+  constexpr int wg_stages = 3;     // 64-pixel steps: LDS stages (3 where the tile fits: +0.9 % on the step over 2)
   {
     LoProfScope _p(lo_prof_geom_name("lo_wgrad_tn", g), geom_flops(g), geom_bytes(g), st);
 #define LO_WG(BMW, BNW)                                                                            \
@@ -1433,7 +1442,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
 #undef LO_WG
   }
   LO_LAUNCH_CHECK("wgrad_tn");
-  if (a.direct) return LO_OK;
+  if (a.direct || defer_reduce) return LO_OK;
   int total = a.packed_elems;
   LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (a.nsplit + 1), st);
   hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);

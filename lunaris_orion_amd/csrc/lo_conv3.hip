@@ -45,17 +45,6 @@ struct Conv3Args {
 #endif
   // fused GroupNorm-backward reduction (lo_conv3x3_pp only; same contract as IgemmArgs::gb_* in lo_conv.hip): the output is the
   // gradient wrt the activation of a conv+GN+Mish layer whose raw conv output is gb_v; P1[n][tile][c] = (sum du, sum du*xhat)
-  // GroupNorm + Mish of the PRODUCING layer applied on load (lo_conv3x3_pp<..., XF = 2>): `in` is that layer's raw conv output v;
-  // mean / rstd come from its conv epilogue's partial sums xg_partial [B][xg_MT][8][2]; the patch is transformed in LDS,
-  // a = mish(v * gamma * rstd + beta - mean * gamma * rstd), and the workgroups of the first channel tile also write their
-  // interior pixels of a to xg_y and (first tile of a sample) the statistics to xg_stats [B][8][2]: the separate lo_gn_fwd pass
-  // (one read of v, one launch) disappears, the activation it would have written still exists for the backward.
-  const float* xg_partial = nullptr;
-  int xg_MT = 0;
-  const float* xg_gamma = nullptr;
-  const float* xg_beta = nullptr;
-  float* xg_stats = nullptr;
-  f16* xg_y = nullptr;
   const f16* gb_v = nullptr;
   const float* gb_stats = nullptr;
   const float* gb_gamma = nullptr;
@@ -66,6 +55,7 @@ struct Conv3Args {
   unsigned int* gb_counter = nullptr;
   unsigned int gb_target = 0;
   unsigned int* gb_fail = nullptr;
+  int gb_keep_out = 0;
   LoGnFuse gf = {};        // gf.y != null: GroupNorm + Mish of this output in the epilogue (lo_conv3x3_pp only; lo_common.h)
 };
 #ifdef LO_STAMPS
@@ -82,263 +72,6 @@ unsigned long long* g_lo_conv3_stamps = nullptr;
 // only for even K0, i.e. not for the dx = +-1 taps).
 __device__ __forceinline__ int lo_pix16(int fr) { return fr; }
 __device__ __forceinline__ int lo_swz3(int row) { return ((row >> 1) & 3) << 1; }
-
-template <int BN, int TH, int TW, int NW, int NSB>
-__global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
-  constexpr int NTHR = NW * 64;
-  constexpr int BM = TH * TW;                 // output pixels per workgroup
-  constexpr int PW = TW + 2, PH = TH + 2, NPIX = PH * PW;
-  constexpr int PI = (NPIX + 8 * NW - 1) / (8 * NW);   // patch LDS-DMA instructions per wave (8 rows each)
-  static_assert(PI <= 9, "patch pieces must fit in taps 0..8");
-  constexpr int PATCH_BYTES = PI * NW * 1024;
-  constexpr int IB = BN / 8 / NW;             // weight-tile LDS-DMA instructions per wave and step
-  static_assert(IB >= 1, "weight tile smaller than one DMA instruction per wave");
-  constexpr int B_BYTES = BN * 128;
-  constexpr int D = NSB - 1;                  // steps in flight
-  constexpr int LPT = IB + 1;                 // DMA instructions per wave and step (weights + one patch piece / dummy)
-  static_assert(LPT * D <= 63, "vmcnt range");
-  constexpr int WGM = NW / 2;                 // wave grid: WGM (pixels) x 2 (channels)
-  constexpr int WM = BM / WGM, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-  static_assert(MI >= 1 && NI >= 1, "wave tile");
-  constexpr int OPITCH = BN * 2 + 16;
-  constexpr int MAIN_BYTES = 2 * PATCH_BYTES + NSB * B_BYTES + 1024;   // + 1 KiB dummy slot
-  constexpr int EPI_BYTES = BM * OPITCH + NTHR * 64;
-  constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
-  unsigned char* const s_patch = smem;
-  unsigned char* const s_b = smem + 2 * PATCH_BYTES;
-  unsigned char* const s_dummy = s_b + NSB * B_BYTES;
-
-  const LoGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % WGM, wn = wave / WGM;
-  const int H = g.Hin, W = g.Win, Cin = g.Cin;
-  const int tiles_x = W / TW, tiles_y = H / TH, tiles_img = tiles_x * tiles_y;
-  const int NT = g.Cout / BN;
-  const int tile_id = lo_xcd_remap3(blockIdx.x, gridDim.x);
-  const int nt_i = tile_id % NT, pt_i = tile_id / NT;          // channel tile fastest: both n tiles share the patch in L2
-  const int n_img = pt_i / tiles_img, t_img = pt_i - n_img * tiles_img;
-  const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
-  const int n0 = nt_i * BN;
-  const int KCB = Cin / 64;
-  const int nsteps = 9 * KCB;
-  const int Ktot = 9 * Cin;
-  const f16* zpage = reinterpret_cast<const f16*>(lo_zero_page3);
-  const uint32_t dyc = g.dyc[0], dxc = g.dxc[0];
-
-  // ---- per-lane DMA sources
-  int p_src[PI];   // element offset of this lane's patch chunk at channel block 0, or -1
-#pragma unroll
-  for (int i = 0; i < PI; ++i) {
-    int pp = (wave * PI + i) * 8 + (lane >> 3), pos = lane & 7;
-    int py = pp / PW, px = pp - py * PW;
-    int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    bool ok = pp < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    p_src[i] = ok ? ((n_img * H + iy) * W + ix) * Cin + ((pos ^ lo_swz3(pp)) * 8) : -1;
-  }
-  int b_src[IB];
-#pragma unroll
-  for (int i = 0; i < IB; ++i) {
-    int row = (wave * IB + i) * 8 + (lane >> 3), pos = lane & 7;
-    b_src[i] = (n0 + row) * Ktot + ((pos ^ lo_swz3(row)) * 8);
-  }
-  auto issue_patch_piece = [&](int buf, int cb, int piece) __attribute__((always_inline)) {
-    // piece is wave-uniform; pieces >= PI (and channel blocks past the end) go to the dummy slot
-    int off = -1;
-#pragma unroll
-    for (int i = 0; i < PI; ++i) if (i == piece) off = p_src[i];
-    const bool real = piece < PI && cb < KCB;
-    const f16* src = (real && off >= 0) ? a.in + (off + cb * 64) : zpage;
-    unsigned char* dst = real ? s_patch + buf * PATCH_BYTES + (wave * PI + piece) * 1024 : s_dummy;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-  auto issue_b = [&](int stage, int step) __attribute__((always_inline)) {
-    const bool live = step < nsteps;
-    const int cb = step / 9, tap = step - cb * 9;
-    const int koff = tap * Cin + cb * 64;
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      const f16* src = live ? a.w + (b_src[i] + koff) : zpage;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s_b + stage * B_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment read coordinates
-  const int fr = lane & 15, fq = lane >> 4;
-  const int fpix = lo_pix16(fr);
-  int pp0[MI];     // patch pixel index of this lane's output pixel (tap offset 0) per fragment
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    int p = wm * WM + mi * 16 + fpix;           // pixel inside the tile
-    int ty = p / TW, tx = p % TW;
-    pp0[mi] = (ty + 1) * PW + tx + 1;
-  }
-  int woff[NI][2];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      int R = wn * WN + ni * 16 + fpix;
-      woff[ni][kk] = R * 128 + (((kk * 4 + fq) ^ lo_swz3(R)) * 16);
-    }
-
-  f32x4 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: whole patch of channel block 0, then D step groups (weights + dummy)
-#pragma unroll
-  for (int i = 0; i < PI; ++i) issue_patch_piece(0, 0, i);
-#pragma unroll
-  for (int s = 0; s < D; ++s) {
-    issue_b(s, s);
-    issue_patch_piece(0, KCB, PI);   // dummy keeps the group size uniform
-  }
-  int rs = 0, ws = D % NSB;
-  int cb = 0, tap = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    LO_VMCNT(LPT * (D - 1));
-    __builtin_amdgcn_s_barrier();
-    issue_b(ws, step + D);
-    issue_patch_piece((cb + 1) & 1, cb + 1, tap);   // pieces 0..PI-1 of the next block during taps 0..PI-1, dummies after
-    const unsigned char* pbase = s_patch + (cb & 1) * PATCH_BYTES;
-    const unsigned char* bbase = s_b + rs * B_BYTES;
-    const int dy = (int)((dyc >> (2 * tap)) & 3u) - 1, dx = (int)((dxc >> (2 * tap)) & 3u) - 1;
-    const int delta = dy * PW + dx;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      f16x8 wf[NI], xf[MI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const f16x8*>(bbase + woff[ni][kk]);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        int pp = pp0[mi] + delta;
-        xf[mi] = *reinterpret_cast<const f16x8*>(pbase + pp * 128 + (((kk * 4 + fq) ^ lo_swz3(pp)) * 16));
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-    }
-    rs = (rs + 1 == NSB) ? 0 : rs + 1;
-    ws = (ws + 1 == NSB) ? 0 : ws + 1;
-    if (++tap == 9) { tap = 0; ++cb; }
-  }
-  LO_VMCNT(0);
-  __syncthreads();
-
-  // ---- epilogue (same structure as lo_igemm_nt): bias -> fp16 tile in LDS -> coalesced stores (+ add / LeakyReLU,
-  //      GroupNorm or BatchNorm partial sums in a fixed order)
-  unsigned char* so = smem;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    // A operand row (lane & 15) -> channel wn*WN + ni*16 + lo_pix16(row); D row 4*fq + reg is that operand row
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    int nl[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      nl[r] = wn * WN + ni * 16 + lo_pix16(fq * 4 + r);
-      if (a.bias) bv[r] = a.bias[n0 + nl[r]];
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      int ml = wm * WM + mi * 16 + fpix;
-      f32x4 v = acc[ni][mi] + bv;
-      // lo_pix16 maps 4 consecutive operand rows to 4 consecutive channels
-      f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-      *reinterpret_cast<f16x4*>(so + ml * OPITCH + nl[0] * 2) = h;
-    }
-  }
-  __syncthreads();
-  constexpr int OCPR = BN / 8, ORPP = NTHR / OCPR, OP = BM / ORPP;
-  static_assert(OP >= 1 && BM % ORPP == 0, "epilogue row passes");
-  const int orow = tid / OCPR, ochunk = tid % OCPR;
-  const int G = g.Cout >> 3;
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-  float ga1[8], ga2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < OP; ++i) {
-    int ml = orow + i * ORPP;
-    int ty = ml / TW, tx = ml % TW;
-    f16x8 h = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
-    size_t off = ((size_t)(n_img * H + y0 + ty) * W + x0 + tx) * g.Cout + n0 + ochunk * 8;
-    if (a.add_src) {
-      f16x8 r = *reinterpret_cast<const f16x8*>(a.add_src + off);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (f16)((float)h[j] + (float)r[j]);
-    }
-    if (a.act == 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { float x = (float)h[j]; h[j] = (f16)(x > 0.f ? x : 0.2f * x); }
-    }
-    *reinterpret_cast<f16x8*>(a.out + off) = h;
-    if (a.bn_partial) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { float x = (float)h[j]; ga1[j] += x; ga2[j] += x * x; }
-    }
-    if (a.gn_partial) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { float x = (float)h[j]; s0 += x; q0 += x * x; }
-#pragma unroll
-      for (int j = 4; j < 8; ++j) { float x = (float)h[j]; s1 += x; q1 += x * x; }
-    }
-  }
-  if (a.bn_partial) {
-    // per-channel (sum, sumsq) of this tile, fixed summation order -> bn_partial[tile][channel][2]
-    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);   // [NTHR][16] floats
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { red[tid * 16 + j * 2] = ga1[j]; red[tid * 16 + j * 2 + 1] = ga2[j]; }
-    __syncthreads();
-    float* dst = a.bn_partial + ((size_t)pt_i * g.Cout + n0) * 2;
-    for (int o = tid; o < BN * 2; o += NTHR) {
-      int cl = o >> 1, w = o & 1;
-      int ccx = cl >> 3, j = cl & 7;
-      float tot = 0.f;
-      for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
-      dst[o] = tot;
-    }
-  }
-  if (a.gn_partial) {
-    float* red = reinterpret_cast<float*>(smem + BM * OPITCH);
-    red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
-    constexpr int NV = OCPR * 4, P = NTHR / NV, RPP2 = ORPP / P;
-    float* red2 = red + NTHR * 4;
-    float* red3 = red2 + NTHR;
-    __syncthreads();
-    {
-      const int o = tid % NV, part = tid / NV;
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < RPP2; ++r) t += red[((part * RPP2 + r) * OCPR) * 4 + o];
-      red2[part * NV + o] = t;
-    }
-    __syncthreads();
-    if (tid < NV) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < P; ++q) t += red2[q * NV + tid];
-      red3[tid] = t;
-    }
-    __syncthreads();
-    const int ngroups = BN / G;
-    if (tid < ngroups * 2) {
-      int gl = tid >> 1, which = tid & 1;
-      int hc_begin = gl * G / 4, hc_end = (gl + 1) * G / 4;
-      float tot = 0.f;
-      for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[(hc >> 1) * 4 + (hc & 1) * 2 + which];
-      int grp = (n0 / G) + gl;
-      a.gn_partial[(((size_t)n_img * tiles_img + t_img) * 8 + grp) * 2 + which] = tot;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Ping-pong variant for long grids: 8 waves, 16x16 output pixels x BN channels per workgroup, one workgroup per CU.
@@ -362,19 +95,15 @@ __global__ __launch_bounds__(NW * 64) void lo_conv3x3_halo(Conv3Args a) {
 // both images are read through the same chunk -> k map.  The epilogue multiplies by f8_scale[n] before the bias.  (Teacher 3x3 convolutions of the dropout path in fp8 mode, BASELINE config 5.)
 // ONECB: the launch has a single channel block (Cin == 64 for fp16): the second patch buffer is never filled, and without it two
 // workgroups fit on a CU, so that one's prologue / epilogue overlaps the other's tap loop.
-// XF: 0 = none, 1 = the teacher's folded block tail (levels of lrelu(x + k)), 2 = GroupNorm + Mish of the producing layer
-// PAIR: 8 x 8-pixel maps (the 512-channel stage).  One tile = two whole images side by side: patch columns 0..9 hold image 2p with
-// its halo, columns 10..19 image 2p+1 (the 20-column patch row is exactly two 10-column halos), a 16-pixel fragment is row y of
-// both images, and everything per sample in the epilogue (GroupNorm sums, the fused GroupNorm-backward reduction, addresses)
-// is split by the half of the fragment a row slot belongs to.
-template <int BN, int TH, int TW, int XF, bool F8 = false, bool ONECB = false, bool PAIR = false>
+// XF: the teacher's folded block tail (levels of lrelu(x + k)) applied to the patch on load
+enum { LO_PP_PLAIN = 0, LO_PP_XF = 1, LO_PP_F8 = 2 };     // operand mode: fp16, fp16 with the teacher's transform on load, e4m3
+template <int BN, int TH, int MODE, bool ONECB = false>
 __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
-  static_assert(!(XF && F8), "the transform on load works on fp16 patches");
-  static_assert(!PAIR || (TH == 8 && TW == 16 && XF == 0), "PAIR: two 8x8 images per tile, no transform on load");
+  constexpr int TW = 16;                      // one 16-pixel fragment per tile row
+  constexpr bool XF = MODE == LO_PP_XF, F8 = MODE == LO_PP_F8;
   constexpr int ES = F8 ? 1 : 2;              // bytes per operand element
   constexpr int CB = 128 / ES;                // channels per 128-byte row = channel block of one step
   constexpr int NW = 8, NTHR = 512, NSB = 4, D = 3;
-  static_assert(TW == 16, "one 16-pixel fragment per tile row");
   constexpr int BM = TH * TW;
   // patch rows are 20 pixels apart (18 used): the swizzle key of pixel pp + 20*mi is key(pp) ^ (mi & 1) * 4, so the eight
   // patch fragments of a step are two base registers (V, V ^ 64) plus immediates; same for the weight rows (16 apart)
@@ -389,8 +118,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   constexpr int WGM = 4, WM = BM / WGM, WN = BN / 2, MI = WM / 16, NI = WN / 16;
   constexpr int OPITCH = BN * 2 + 16;
   constexpr int XF_LEV = 2, XF_C = 128;       // transform constants staged in LDS: [2 levels][6 classes][128 channels] fp16
-  constexpr int XG_CMAX = 256;                // XF = 2: (scale, shift) per input channel as float2, then 16 floats of statistics
-  constexpr int K_BYTES = XF == 1 ? XF_LEV * 6 * XF_C * 2 : (XF == 2 ? XG_CMAX * 8 + 64 : 0);
+  constexpr int K_BYTES = XF ? XF_LEV * 6 * XF_C * 2 : 0;
   constexpr int NPB = ONECB ? 1 : 2;          // patch buffers
   constexpr int MAIN_BYTES = NPB * PATCH_BYTES + NSB * B_BYTES + K_BYTES;
   constexpr int EPI_BYTES = BM * OPITCH + NTHR * 64;
@@ -407,11 +135,11 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   const int grp = wave >> 2;                  // waves w and w+4 share a SIMD
   const int wm = wave & 3, wn = wave >> 2;
   const int H = g.Hin, W = g.Win, Cin = g.Cin;
-  const int tiles_x = PAIR ? 1 : W / TW, tiles_y = PAIR ? 1 : H / TH, tiles_img = tiles_x * tiles_y;
+  const int tiles_x = W / TW, tiles_y = H / TH, tiles_img = tiles_x * tiles_y;
   const int NT = g.Cout / BN;
   const int tile_id = lo_xcd_remap3(blockIdx.x, gridDim.x);
   const int nt_i = tile_id % NT, pt_i = tile_id / NT;
-  const int n_img = PAIR ? pt_i * 2 : pt_i / tiles_img, t_img = PAIR ? 0 : pt_i - n_img * tiles_img;   // PAIR: first image of the two
+  const int n_img = pt_i / tiles_img, t_img = pt_i - n_img * tiles_img;
   const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
   const int n0 = nt_i * BN;
   const int KCB = Cin / CB;
@@ -431,14 +159,8 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int py = pp / PW, px = pp - py * PW;
     int iy = y0 - 1 + py, ix = x0 - 1 + px;
     bool ok = pp < NPIX && px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    int img = n_img;
-    if (PAIR) {
-      img = n_img + (px >= 10 ? 1 : 0);
-      ix = (px >= 10 ? px - 10 : px) - 1;
-      ok = pp < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    }
-    p_src[i] = ok ? (((img * H + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16) : -1;
-    if (XF == 1 && ok && iy < 8) {
+    p_src[i] = ok ? (((n_img * H + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16) : -1;
+    if (XF && ok && iy < 8) {
       p_src[i] = (((n_img * 8 + iy) * W + ix) * Cin) * ES + ((pos ^ lo_swz3(pp)) * 16);
       p_xc |= 1u << i;
     }
@@ -457,7 +179,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       int off = -1;
 #pragma unroll
       for (int i = 0; i < PI; ++i) if (i == piece) off = p_src[i];
-      const unsigned char* base = (XF == 1 && ((p_xc >> piece) & 1u)) ? xcb : inb;
+      const unsigned char* base = (XF && ((p_xc >> piece) & 1u)) ? xcb : inb;
       const unsigned char* src = off >= 0 ? base + (off + cb * 128) : zpage;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_patch + buf * PATCH_BYTES + q * 1024), 16, 0, 0);
@@ -476,7 +198,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   };
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int pp00 = (wm * MI + 1) * PW + fr + 1 + (PAIR && fr >= 8 ? 2 : 0);   // patch pixel of fragment 0 at tap offset (0, 0)
+  const int pp00 = (wm * MI + 1) * PW + fr + 1;   // patch pixel of fragment 0 at tap offset (0, 0)
   const int R0 = wn * WN + fr;
   const int fch = fq;                                      // 16-byte chunk of this lane's fragment at kk = 0 (kk = 1: fq + 4)
   const int w00 = R0 * 128 + ((fch ^ lo_swz3(R0)) * 16);   // weight fragment (ni = 0, kk = 0) inside a ring stage
@@ -495,33 +217,6 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   // T_nlev(..T_1(x)); rows 0..7 came from xc already transformed, pixels outside the image stay zero (the padding)
   auto xform_patch = [&](int buf, int cb) __attribute__((always_inline)) {
     unsigned char* pb = s_patch + buf * PATCH_BYTES;
-    if constexpr (XF == 2) {
-      // GroupNorm + Mish of the producing layer on every in-image pixel of the patch (the zero padding stays zero); the same
-      // arithmetic as lo_gn_fwd's plain mode.  Interior pixels are the by-product store of the activation.
-      const float* tab = reinterpret_cast<const float*>(s_k);
-      for (int idx = tid; idx < NPIX * 8; idx += NTHR) {
-        const int pp = idx >> 3, pos = idx & 7;
-        const int py = pp / PW, px = pp - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        if (px < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-          const int c = cb * 64 + ((pos ^ lo_swz3(pp)) * 8);
-          const f16x8 v = *reinterpret_cast<const f16x8*>(pb + pp * 128 + pos * 16);
-          f16x8 y;
-#pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(tab + (c + j) * 2);   // sc[j], sh[j], sc[j+1], sh[j+1]
-            const lo_f2 hv = {(float)v[j], (float)v[j + 1]};
-            const lo_f2 m = lo_mish2(hv * (lo_f2){t[0], t[2]} + (lo_f2){t[1], t[3]});
-            y[j] = (f16)m[0];
-            y[j + 1] = (f16)m[1];
-          }
-          *reinterpret_cast<f16x8*>(pb + pp * 128 + pos * 16) = y;
-          if (nt_i == 0 && py >= 1 && py <= TH && px >= 1 && px <= TW)
-            *reinterpret_cast<f16x8*>(a.xg_y + ((size_t)(n_img * H + iy) * W + ix) * Cin + c) = y;
-        }
-      }
-      return;
-    }
     for (int idx = tid; idx < NPIX * 8; idx += NTHR) {
       const int pp = idx >> 3, pos = idx & 7;
       const int py = pp / PW, px = pp - py * PW;
@@ -539,7 +234,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       }
     }
   };
-  if (XF == 1) {
+  if (XF) {
     for (int i = tid; i < a.nlev * 6 * XF_C / 8; i += NTHR)
       *reinterpret_cast<f16x8*>(s_k + i * 16) = *reinterpret_cast<const f16x8*>(a.kx + i * 8);
   }
@@ -548,23 +243,6 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   for (int i = 0; i < PI; ++i) issue_patch_piece(0, 0, i);
 #pragma unroll
   for (int s = 0; s < D; ++s) issue_b(s, s);
-  if constexpr (XF == 2) {
-    // statistics of this sample from the producer's partial sums, then (scale, shift) per input channel -- under the latency of
-    // the LDS-DMA just issued.  Same expressions as lo_gn_fwd, which this launch replaces.
-    float* tab = reinterpret_cast<float*>(s_k);
-    float* s_stat = tab + XG_CMAX * 2;
-    const int Gi = Cin >> 3;
-    lo_gn_group_stats(a.xg_partial, a.xg_MT, n_img, 1.0f / ((float)(H * W) * (float)Gi), s_stat, tid);
-    __syncthreads();
-    if (tid < Cin) {
-      const int gr = tid / Gi;
-      const float mean = s_stat[gr * 2], rstd = s_stat[gr * 2 + 1];
-      const float sc = a.xg_gamma[tid] * rstd;
-      tab[tid * 2] = sc;
-      tab[tid * 2 + 1] = a.xg_beta[tid] - mean * sc;
-    }
-    if (nt_i == 0 && t_img == 0 && tid < 16 && a.xg_stats) a.xg_stats[n_img * 16 + tid] = s_stat[tid];
-  }
   LO_VMCNT(IB * (D - 1));            // patch + step 0 landed (this wave's share)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // XF: the staged constants
   __builtin_amdgcn_s_barrier();
@@ -669,7 +347,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
   LO_VMCNT(0);
   __syncthreads();
 
-  // ---- epilogue: identical to lo_conv3x3_halo
+  // ---- epilogue: same LDS-staged form as lo_igemm_nt's
   unsigned char* so = smem;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -696,8 +374,7 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
   float gsc[8], gsh[8];   // fused GN-backward reduction: u = v * gsc + gsh for this thread's 8 channels (the tile lies inside one sample)
-  static_assert(!PAIR || ORPP % 16 == 0, "PAIR: a thread's row slots must stay in one half of the fragment");
-  const int my_img = n_img + (PAIR ? (orow & 15) >> 3 : 0);   // the sample this thread's rows belong to
+  const int my_img = n_img;
   if (a.gb_v) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -713,7 +390,6 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     int ty = ml / TW, tx = ml % TW;
     f16x8 h = *reinterpret_cast<const f16x8*>(so + ml * OPITCH + ochunk * 16);
     size_t off = ((size_t)(n_img * H + y0 + ty) * W + x0 + tx) * g.Cout + n0 + ochunk * 8;
-    if (PAIR) off = ((size_t)(my_img * H + ty) * W + (tx & 7)) * g.Cout + n0 + ochunk * 8;
     if (a.add_src) {
       f16x8 r = *reinterpret_cast<const f16x8*>(a.add_src + off);
 #pragma unroll
@@ -723,8 +399,10 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; h[j] = (f16)(x > 0.f ? x : 0.2f * x); }
     }
-    if (!PAIR && a.gb_dv) *reinterpret_cast<f16x8*>(so + ml * OPITCH + ochunk * 16) = h;   // fused apply: the activation gradient stays in LDS
-    else *reinterpret_cast<f16x8*>(a.out + off) = h;
+    if (a.gb_dv) {                                 // fused apply: the activation gradient stays in LDS; stored only if somebody else reads it
+      *reinterpret_cast<f16x8*>(so + ml * OPITCH + ochunk * 16) = h;
+      if (a.gb_keep_out) *reinterpret_cast<f16x8*>(a.out + off) = h;
+    } else *reinterpret_cast<f16x8*>(a.out + off) = h;
     if (a.bn_partial) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float x = (float)h[j]; ga1[j] += x; ga2[j] += x * x; }
@@ -777,22 +455,12 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
     for (int o = tid; o < BN * 2; o += NTHR) {
       int cl = o >> 1, w = o & 1;
       int ccx = cl >> 3, j = cl & 7;
-      if (PAIR) {   // row slots with (r & 15) < 8 belong to image n_img, the others to n_img + 1 (one P1 row per sample)
-        float t0 = 0.f, t1 = 0.f;
-        for (int r = 0; r < ORPP; ++r) {
-          const float x = red[(r * OCPR + ccx) * 16 + j * 2 + w];
-          if ((r & 15) < 8) t0 += x; else t1 += x;
-        }
-        dst[o] = t0;
-        dst[(size_t)g.Cout * 2 + o] = t1;
-      } else {
-        float tot = 0.f;
-        for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
-        if (a.gb_dv) __hip_atomic_store(reinterpret_cast<unsigned int*>(dst) + o, __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else dst[o] = tot;
-      }
+      float tot = 0.f;
+      for (int r = 0; r < ORPP; ++r) tot += red[(r * OCPR + ccx) * 16 + j * 2 + w];
+      if (a.gb_dv) __hip_atomic_store(reinterpret_cast<unsigned int*>(dst) + o, __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else dst[o] = tot;
     }
-    if constexpr (!PAIR) {
+    {
       if (a.gb_dv) {
         // ---- GroupNorm-backward APPLY of the producing layer (same sequence as lo_igemm_nt's epilogue; lo_internal.h LoGnBwdFuse)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -882,30 +550,24 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
       red2[part * NV + o] = t;
     }
     __syncthreads();
-    static_assert(!PAIR || (RPP2 <= 8 && 8 % RPP2 == 0), "PAIR: the row slots of a part must stay in one half of the fragment");
     if (tid < NV) {
-      float t = 0.f, t1 = 0.f;
+      float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < P; ++q) {
-        if (PAIR && ((q * RPP2) & 15) >= 8) t1 += red2[q * NV + tid];
-        else t += red2[q * NV + tid];
-      }
+      for (int q = 0; q < P; ++q) t += red2[q * NV + tid];
       red3[tid] = t;
-      if (PAIR) red3[NV + tid] = t1;
     }
     __syncthreads();
     const int ngroups = BN / G;
-    if (tid < ngroups * 2 * (PAIR ? 2 : 1)) {
-      const int half = tid / (ngroups * 2), t2 = tid - half * (ngroups * 2);
-      int gl = t2 >> 1, which = t2 & 1;
+    if (tid < ngroups * 2) {
+      int gl = tid >> 1, which = tid & 1;
       int hc_begin = gl * G / 4, hc_end = (gl + 1) * G / 4;
       float tot = 0.f;
-      for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[half * NV + (hc >> 1) * 4 + (hc & 1) * 2 + which];
+      for (int hc = hc_begin; hc < hc_end; ++hc) tot += red3[(hc >> 1) * 4 + (hc & 1) * 2 + which];
       int grp2 = (n0 / G) + gl;
-      if (a.gn_partial) a.gn_partial[(((size_t)(n_img + half) * tiles_img + t_img) * 8 + grp2) * 2 + which] = tot;
-      if (!PAIR) s_x[grp2 * 2 + which] = tot;
+      if (a.gn_partial) a.gn_partial[(((size_t)n_img * tiles_img + t_img) * 8 + grp2) * 2 + which] = tot;
+      s_x[grp2 * 2 + which] = tot;
     }
-    if constexpr (!PAIR && !F8 && XF == 0) {
+    if constexpr (!F8 && !XF) {
       if (a.gf.y) {
         // ---- GroupNorm + Mish of this tile once the whole sample's sums are known (lo_common.h: LoGnFuse); the tile is still in LDS
         __syncthreads();
@@ -943,137 +605,89 @@ __global__ __launch_bounds__(512) void lo_conv3x3_pp(Conv3Args a) {
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-// mode: 0 = off, 1 = LO_HALO=1 (every applicable shape, older tile choice), 2 = default (shapes where it measured faster),
-// 3 = the ping-pong kernel on every shape it can tile
+// LO_HALO: 0 = never, 2 = default (the shapes where it measured faster than lo_igemm_nt), 3 = every shape it can tile (what the
+// forced parity test uses: small batches run on it too)
 static inline int conv3_mode() {
   static const int m = getenv("LO_HALO") ? atoi(getenv("LO_HALO")) : 2;
   return m;
 }
-// 8 x 8 maps, an even batch, GroupNorm groups of at most 64 channels: the two-images-per-tile form of the ping-pong kernel
-static inline bool conv3_pair(const LoGeom& g) {
-  // Measured at batch 64: 48 / 50 us per forward / data-gradient launch against 43 / 45 for lo_igemm_nt -- 128 pixels x 64 channels
-  // per workgroup leaves a wave 8 MFMAs per (tap, channel block) step, too few for the two barriers of a step.  Opt-in.
-  static const int on = getenv("LO_HALO_PAIR") ? atoi(getenv("LO_HALO_PAIR")) : 0;
-  return on && g.Win == 8 && g.Hin == 8 && g.B % 2 == 0 && g.Cout % 64 == 0 && (g.Cout >> 3) <= 64;
-}
-static inline bool conv3_tile(const LoGeom& g, int* th, int* tw, int* bn, int* nw) {
+// tile of the 8-wave ping-pong kernel that gives >= 256 workgroups at batch 64: 16x16 pixels x 128 channels, 8x16 x 128 when that
+// would leave CUs idle, 16x16 x 64 for 64 output channels
+static inline bool conv3_tile(const LoGeom& g, int* th, int* tw, int* bn) {
   if (g.n_phase != 1 || g.T[0] != 9 || g.in_stride != 1 || g.out_stride != 1) return false;
-  if (g.Cin % 64 || g.Cout % 64) return false;
-  if (g.Hin % 8) return false;
-  static const int want_bn = getenv("LO_HALO_BN") ? atoi(getenv("LO_HALO_BN")) : 128;
-  static const int want_big = getenv("LO_HALO_BIG") ? atoi(getenv("LO_HALO_BIG")) : 1;
-  *nw = 4;
-  // the 8-wave ping-pong kernel with the tile that gives >= 256 workgroups: 16x16 pixels x 64 channels for Cout = 64, 8x16 x 128
-  // when the 16x16 x 128 tile would leave CUs idle (LO_HALO=1 keeps the older choice below, which includes the 4-wave kernels)
-  if (conv3_mode() >= 2 && conv3_pair(g)) { *th = 8; *tw = 16; *bn = 64; *nw = 8; return true; }   // two 8x8 images per tile
-  if (conv3_mode() >= 2 && g.Win % 16 == 0 && g.Hin % 16 == 0) {
-    const long t16 = (long)g.B * (g.Hin / 16) * (g.Win / 16);
-    if (g.Cout % 128 == 0 && t16 * (g.Cout / 128) >= 256) { *th = 16; *tw = 16; *bn = 128; *nw = 8; return true; }
-    if (g.Cout % 128 == 0) { *th = 8; *tw = 16; *bn = 128; *nw = 8; return true; }
-    if (g.Cout == 64) { *th = 16; *tw = 16; *bn = 64; *nw = 8; return true; }
-  }
-  if (want_big && g.Win % 16 == 0 && g.Hin % 16 == 0 && g.Cout % 128 == 0) { *th = 16; *tw = 16; *bn = 128; *nw = 8; }
-  else if (g.Win % 16 == 0) { *th = 8; *tw = 16; *bn = (want_bn == 128 && g.Cout % 128 == 0) ? 128 : 64; }
-  else if (g.Win % 8 == 0) { *th = 8; *tw = 8; *bn = (want_bn == 128 && g.Cout % 128 == 0) ? 128 : 64; }
+  if (g.Cin % 64 || g.Cout % 64 || g.Win % 16 || g.Hin % 16) return false;
+  const long t16 = (long)g.B * (g.Hin / 16) * (g.Win / 16);
+  if (g.Cout % 128 == 0 && t16 * (g.Cout / 128) >= 256) { *th = 16; *tw = 16; *bn = 128; }
+  else if (g.Cout % 128 == 0) { *th = 8; *tw = 16; *bn = 128; }
+  else if (g.Cout == 64) { *th = 16; *tw = 16; *bn = 64; }
   else return false;
-  if ((g.Cout >> 3) > *bn) return false;   // a GroupNorm group must fit inside the N tile
-  return true;
+  return (g.Cout >> 3) <= *bn;   // a GroupNorm group must fit inside the N tile
 }
 
-// tiles per image of the halo kernel for this geometry, or 0 when the kernel does not apply / is not selected
+// tiles per image of the fused-tap kernel for this geometry, or 0 when the kernel does not apply / is not selected
 int lo_conv3_tiles_per_image(const LoGeom& g, bool need_bn) {
-  int th, tw, bn, nw;
+  int th, tw, bn;
   const int mode = conv3_mode();
-  if (mode == 0 || !conv3_tile(g, &th, &tw, &bn, &nw)) return 0;
-  if (need_bn && nw != 8) return 0;   // BatchNorm partial rows (teacher epilogue) only with the 16x16-pixel tile
-  if (mode >= 2 && nw != 8) return 0;
+  if (mode == 0 || !conv3_tile(g, &th, &tw, &bn)) return 0;
   if (mode == 2) {
     // default: where it measured faster than lo_igemm_nt -- the 16x16-pixel x 128-channel workgroup on
     // long grids (>= 4 tiles per CU: the teacher), and, for launches without the BatchNorm epilogue, any tile choice above that
     // puts a workgroup on every CU (the VAE's 64 / 128 / 256-channel ResBlock convolutions at batch 64: 44 -> 36, 34 -> 28,
     // 36 -> 33 us; +1.0 % on the step over three interleaved pairs)
-    const bool pair = conv3_pair(g);
-    const long tiles = pair ? (long)(g.B / 2) * (g.Cout / bn) : (long)g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
+    const long tiles = (long)g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
     const bool long_grid = th == 16 && bn == 128 && tiles >= 1024;
     if (!(long_grid || (!need_bn && tiles >= 256))) return 0;
   }
-  if (conv3_pair(g)) return need_bn ? 0 : 1;   // one row of per-sample sums per image
   return (g.Hin / th) * (g.Win / tw);
 }
 
-// does the kernel lo_conv3_run would launch for g carry the fused GroupNorm-backward epilogue?  (the 8-wave ping-pong kernel does)
-bool lo_conv3_fuses_gnb(const LoGeom& g) {
-  int th, tw, bn, nw;
-  return lo_conv3_tiles_per_image(g, false) > 0 && conv3_tile(g, &th, &tw, &bn, &nw) && nw == 8;
-}
+// does the kernel lo_conv3_run would launch for g carry the fused GroupNorm-backward epilogue?  (it always does)
+bool lo_conv3_fuses_gnb(const LoGeom& g) { return lo_conv3_tiles_per_image(g, false) > 0; }
 
-// fused GroupNorm epilogue: only the 8-wave ping-pong kernel, one image per tile
+// fused GroupNorm epilogue (LoGnFuse / LoGnBwdFuse::dv): tile rows per sample and n tiles per row of the launch
 bool lo_conv3_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt) {
-  int th, tw, bn, nw;
-  if (lo_conv3_tiles_per_image(g, false) <= 0 || !conv3_tile(g, &th, &tw, &bn, &nw) || nw != 8) return false;
-  if (conv3_mode() >= 2 && conv3_pair(g)) return false;
-  static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;
-  if (!pp && th == 16 && bn == 128) return false;       // the lock-step 8-wave kernel has no fused epilogue
+  int th, tw, bn;
+  if (lo_conv3_tiles_per_image(g, false) <= 0 || !conv3_tile(g, &th, &tw, &bn)) return false;
   *mts = (g.Hin / th) * (g.Win / tw);
   *nt = g.Cout / bn;
   return *mts * *nt <= LO_GNF_MAX_TILES;
 }
 
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
-                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb, const LoGnApplyFuse* xg, const LoGnFuse* gf) {
-  int th, tw, bn, nw;
-  LO_REQUIRE(conv3_tile(g, &th, &tw, &bn, &nw), "lo_conv3_run: geometry not supported by the fused-tap kernel");
+                 float* gn_partial, hipStream_t st, const LoConvExtra* ex, const LoGnBwdFuse* gb, const LoGnFuse* gf) {
+  int th, tw, bn;
+  LO_REQUIRE(conv3_tile(g, &th, &tw, &bn), "lo_conv3_run: geometry not supported by the fused-tap kernel");
   if (gf) {
     int mts = 0, nt = 0;
-    LO_REQUIRE(!add_src && !gb && !ex && !xg && lo_conv3_gn_fuse_tiles(g, &mts, &nt) && mts == gf->MTs && nt == gf->NT,
+    LO_REQUIRE(!add_src && !gb && !ex && lo_conv3_gn_fuse_tiles(g, &mts, &nt) && mts == gf->MTs && nt == gf->NT,
                "lo_conv3_run: fused GroupNorm asked for a geometry / tile grid the kernel does not have");
   }
-  LO_REQUIRE(!gb || nw == 8, "lo_conv3_run: the fused GroupNorm-backward epilogue needs the 8-wave kernel");
-  LO_REQUIRE(!xg || (nw == 8 && g.Cin <= 256 && g.Cin % 64 == 0), "lo_conv3_run: GroupNorm on load needs the 8-wave kernel and Cin <= 256");
   Conv3Args a{in, wp, bias, add_src, out, gn_partial, ex ? ex->bn_partial : nullptr, ex ? ex->act : 0, nullptr, nullptr, 0, nullptr, g};
   if (gb) {
     a.gb_v = gb->v; a.gb_stats = gb->stats; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta; a.gb_P1 = gb->P1;
     a.gb_dv = gb->dv; a.gb_P2 = gb->P2; a.gb_counter = gb->counter; a.gb_target = gb->target; a.gb_fail = gb->fail;
-    LO_REQUIRE(!gb->dv || (nw == 8 && !(conv3_mode() >= 2 && conv3_pair(g)) && (g.Cout >> 3) >= 8),
-               "lo_conv3_run: fused GroupNorm-backward apply needs the one-image-per-tile 8-wave kernel");
-  }
-  if (xg) {
-    LO_REQUIRE(xg->partial && xg->MT > 0 && xg->gamma && xg->beta && xg->y, "lo_conv3_run: incomplete GroupNorm-on-load arguments");
-    a.xg_partial = xg->partial; a.xg_MT = xg->MT; a.xg_gamma = xg->gamma; a.xg_beta = xg->beta; a.xg_stats = xg->stats; a.xg_y = xg->y;
+    a.gb_keep_out = gb->keep_out ? 1 : 0;
+    LO_REQUIRE(!gb->dv || (g.Cout >> 3) >= 8, "lo_conv3_run: fused GroupNorm-backward apply needs groups of at least 8 channels");
   }
   if (gf) a.gf = *gf;
 #ifdef LO_STAMPS
   a.stamps = g_lo_conv3_stamps;
 #endif
-  const bool pair = conv3_mode() >= 2 && conv3_pair(g);
-  LO_REQUIRE(!pair || (!xg && !(ex && ex->bn_partial)), "lo_conv3_run: the two-image tile has no transform on load / BatchNorm epilogue");
-  const int tiles = pair ? (g.B / 2) * (g.Cout / bn) : g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
+  const int tiles = g.B * (g.Hin / th) * (g.Win / tw) * (g.Cout / bn);
   double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
   double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * (g.Cin + g.Cout) + 9.0 * g.Cin * g.Cout);
   static char name[64];
-  snprintf(name, sizeof(name), nw == 8 ? "lo_conv3x3_pp<%d,%dx%d>" : "lo_conv3x3_halo<%d,%dx%d>", bn, th, tw);
-  if (xg) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cin;   // the by-product store of the normalised activation
+  snprintf(name, sizeof(name), "lo_conv3x3_pp<%d,%dx%d>", bn, th, tw);
   // algorithmic bytes of the FUSED op, as in launch_igemm: the residual gradient it adds and the producing layer's raw conv output
   // that the fused GroupNorm-backward reduction reads, each the size of the output
   if (add_src) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cout;
   if (gb) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cout;
-  LoProfScope _p(xg ? "lo_conv3x3_pp (GroupNorm + Mish on load)" : lo_prof_intern(name), flops, bytes, st);
-  static const int pp = getenv("LO_HALO_PP") ? atoi(getenv("LO_HALO_PP")) : 1;   // 0: lock-step 8-wave kernel (A/B knob)
-  if (pair) hipLaunchKernelGGL((lo_conv3x3_pp<64, 8, 16, 0, false, false, true>), dim3(tiles), dim3(512), 0, st, a);
-  else if (xg && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
-  else if (xg && bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, 2, false, true>), dim3(tiles), dim3(512), 0, st, a);
-  else if (xg && bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
-  else if (xg) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, 2>), dim3(tiles), dim3(512), 0, st, a);
-  else if (nw == 8 && th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, 16, false>), dim3(tiles), dim3(512), 0, st, a);
-  else if (nw == 8 && bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, false, false, true>), dim3(tiles), dim3(512), 0, st, a);
-  else if (nw == 8 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
-  else if (nw == 8 && pp) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
-  else if (nw == 8) hipLaunchKernelGGL((lo_conv3x3_halo<128, 16, 16, 8, 3>), dim3(tiles), dim3(512), 0, st, a);
-  else if (tw == 16 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_halo<64, 8, 16, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
-  else if (tw == 16 && bn == 128) hipLaunchKernelGGL((lo_conv3x3_halo<128, 8, 16, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
-  else if (tw == 8 && bn == 64) hipLaunchKernelGGL((lo_conv3x3_halo<64, 8, 8, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((lo_conv3x3_halo<128, 8, 8, 4, 3>), dim3(tiles), dim3(256), 0, st, a);
-  LO_LAUNCH_CHECK("conv3x3_halo");
+  LoProfScope _p(lo_prof_intern(name), flops, bytes, st);
+  if (th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
+  else if (bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, LO_PP_PLAIN, true>), dim3(tiles), dim3(512), 0, st, a);
+  else if (bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
+  LO_LAUNCH_CHECK("conv3x3_pp");
   return LO_OK;
 }
 
@@ -1095,8 +709,8 @@ int lo_conv3_run_pp_xf(const LoGeom& g, const f16* in, const f16* xc, const f16*
   double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
   double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * (g.Cin + g.Cout) + 9.0 * g.Cin * g.Cout);
   LoProfScope _p(nlev ? "lo_conv3x3_pp (transform on load)" : "lo_conv3x3_pp", flops, bytes, st);
-  if (nlev) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, true>), dim3(tiles), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false>), dim3(tiles), dim3(512), 0, st, a);
+  if (nlev) hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, LO_PP_XF>), dim3(tiles), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
   LO_LAUNCH_CHECK("conv3x3_pp_xf");
   return LO_OK;
 }
@@ -1119,7 +733,7 @@ int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, c
   double flops = 2.0 * g.B * g.Hin * g.Win * (double)g.Cout * 9 * g.Cin;
   double bytes = (double)g.B * g.Hin * g.Win * (g.Cin + 2.0 * g.Cout) + 9.0 * g.Cin * g.Cout;
   LoProfScope _p("lo_conv3x3_pp<f8>", flops, bytes, st);
-  hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, 16, false, true>), dim3(tiles), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, LO_PP_F8>), dim3(tiles), dim3(512), 0, st, a);
   LO_LAUNCH_CHECK("conv3x3_pp_f8");
   return LO_OK;
 }
@@ -1314,12 +928,10 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
   }
 }
 
-// ConvTranspose2d k4 s2 p1 forward geometry with 64 -> 32 or 128 -> 64 channels on a map of whole 16 x 16 tiles (LO_CONVT_PATCH=0: off)
+// ConvTranspose2d k4 s2 p1 forward geometry with 64 -> 32 or 128 -> 64 channels on a map of whole 16 x 16 tiles
 bool lo_convt4_patch_applies(const LoGeom& g) {
-  static const int on = getenv("LO_CONVT_PATCH") ? atoi(getenv("LO_CONVT_PATCH")) : 1;
-  static const int wide = getenv("LO_CONVT_PATCH_WIDE") ? atoi(getenv("LO_CONVT_PATCH_WIDE")) : 1;   // the 128 -> 64 layer as well
-  if (!on || g.n_phase != 4 || g.in_stride != 1 || g.out_stride != 2) return false;
-  if (!((g.Cin == 64 && g.Cout == 32) || (wide && g.Cin == 128 && g.Cout == 64))) return false;
+  if (g.n_phase != 4 || g.in_stride != 1 || g.out_stride != 2) return false;
+  if (!((g.Cin == 64 && g.Cout == 32) || (g.Cin == 128 && g.Cout == 64))) return false;
   for (int p = 0; p < 4; ++p) if (g.T[p] != 4) return false;
   return g.Hin % 16 == 0 && g.Win % 16 == 0 && g.Hout == 2 * g.Hin && g.Wout == 2 * g.Win;
 }
@@ -1336,178 +948,5 @@ int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const flo
   if (g.Cin == 64) hipLaunchKernelGGL((lo_convt4_patch_fwd_kernel<1, 32>), dim3(tiles), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((lo_convt4_patch_fwd_kernel<2, 64>), dim3(tiles), dim3(512), 0, st, a);
   LO_LAUNCH_CHECK("convt4_patch_fwd");
-  return LO_OK;
-}
-
-// =============================================================================================
-// Patch-resident data gradient of the same layer: din[n, y, x, :] = sum_{r,s} dv[n, 2y-1+r, 2x-1+s, :] W[:, :, r, s], a 4x4
-// stride-2 convolution of the 32-channel gradient at 128x128 down to 64 channels at 64x64 (LO_CONVT4_S2_DGRAD geometry).  On
-// lo_igemm_nt (128 x 64 x 32 tiles, 16 K steps) it takes 65 us for 17 GFLOP and 168 MB.  Here: 8 x 16 output pixels per
-// workgroup, the 18 x 34-pixel patch of dv staged once (39 KB, 64-byte pixel rows, chunks swizzled by (pixel >> 1) & 3: the
-// stride-2 fragment reads are 2-way conflicted at worst), the packed weights in two passes of 8 taps (32 KB each, rows
-// swizzled as in the forward kernel), weights as the A operand; wave w owns output row w of the tile.  Epilogue staged in LDS
-// for 16-byte stores, with the residual add and the fused GroupNorm-backward reduction of the producing layer (same form and
-// summation order rules as lo_igemm_nt's: sum du and sum du*v per channel, statistics re-read after the loop).
-// =============================================================================================
-struct Conv4S2PatchArgs {
-  const f16* in;        // dv [B][2Ho][2Wo][32]
-  const f16* w;         // packed [64][16 * 32]
-  const float* bias;
-  const f16* add_src;   // [B][Ho][Wo][64] or null
-  f16* out;             // [B][Ho][Wo][64]
-  const f16* gb_v; const float* gb_stats; const float* gb_gamma; const float* gb_beta; float* gb_P1;
-  LoGeom g;
-};
-
-__global__ __launch_bounds__(512) void lo_conv4s2_patch_dgrad_kernel(Conv4S2PatchArgs a) {
-  constexpr int TH = 8, TW = 16, PW = 2 * TW + 2, PH = 2 * TH + 2, NPIX = PH * PW;   // 18 x 34 = 612 patch pixels
-  constexpr int CIN = 32, COUT = 64, KT = 16 * CIN;
-  constexpr int PQ = (NPIX + 15) / 16;                                               // 16 pixels of 64 B per LDS-DMA instruction
-  constexpr int PATCH_BYTES = PQ * 1024;
-  constexpr int W_BYTES = COUT * 8 * CIN * 2;                                        // 8 taps per pass
-  static_assert(PATCH_BYTES >= 512 * 16 * 4, "the reduction scratch of the fused epilogue lives in the patch buffer");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[PATCH_BYTES + W_BYTES];
-  unsigned char* const s_patch = smem;
-  unsigned char* const s_w = smem + PATCH_BYTES;
-  const LoGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Ho = g.Hout, Wo = g.Wout, Hi = g.Hin, Wi = g.Win;
-  const int tiles_x = Wo / TW, tiles_img = tiles_x * (Ho / TH);
-  const int tile_id = lo_xcd_remap3(blockIdx.x, gridDim.x);
-  const int n_img = tile_id / tiles_img, t_img = tile_id - n_img * tiles_img;
-  const int y0 = (t_img / tiles_x) * TH, x0 = (t_img % tiles_x) * TW;
-  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page3);
-  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
-  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
-  auto pswz = [](int pix) { return (pix >> 1) & 3; };
-
-  for (int q = wave; q < PQ; q += 8) {
-    const int pp = q * 16 + (lane >> 2), pos = lane & 3;
-    const int py = pp / PW, px = pp - py * PW;
-    const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
-    const bool ok = pp < NPIX && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
-    const unsigned char* src = ok ? inb + ((size_t)((n_img * Hi + iy) * Wi + ix) * CIN + ((pos ^ pswz(pp)) * 8)) * 2 : zpage;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(s_patch + q * 1024), 16, 0, 0);
-  }
-  auto issue_w = [&](int pass) __attribute__((always_inline)) {   // rows n (64) x 512 B; instruction q covers rows 2q, 2q+1
-    for (int q = wave; q < COUT / 2; q += 8) {
-      const int r = 2 * q + (lane >> 5), pos = lane & 31;
-      const unsigned char* src = wb + ((size_t)r * KT + pass * 8 * CIN + ((pos ^ (r & 15)) * 8)) * 2;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s_w + q * 1024), 16, 0, 0);
-    }
-  };
-  issue_w(0);
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[4];
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int tl = 0; tl < 8; ++tl) {
-      const int t = pass * 8 + tl;
-      const int pix = (2 * wave + g.dy[0][t] + 1) * PW + 2 * fr + g.dx[0][t] + 1;
-      const f16x8 xf = *reinterpret_cast<const f16x8*>(s_patch + pix * 64 + ((fq ^ pswz(pix)) * 16));
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        const int r = nf * 16 + fr;
-        const f16x8 wf = *reinterpret_cast<const f16x8*>(s_w + r * 512 + (((tl * 4 + fq) ^ (r & 15)) * 16));
-        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[nf], 0, 0, 0);
-      }
-    }
-    __syncthreads();                           // every wave is done with this pass's weights
-    if (pass == 0) issue_w(1);
-  }
-  // ---- epilogue: D[n = nf*16 + 4 fq + j][px = fr] of tile row `wave`; staging [128 px][8 chunks of 8 channels], chunk ^ (px & 7)
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) {
-    f32x4 v = acc[nf];
-    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + nf * 16 + 4 * fq);
-    const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-    const int px = wave * 16 + fr, chunk = nf * 2 + (fq >> 1);
-    *reinterpret_cast<f16x4*>(s_w + px * 128 + ((chunk ^ (px & 7)) * 16) + (fq & 1) * 8) = h;
-  }
-  __syncthreads();
-  const int chunk = tid & 7, slot = tid >> 3;      // this thread's 8 channels and its pixel slot (pixels slot, slot + 64)
-  const int G = COUT >> 3;                         // 8 channels per GroupNorm group: a chunk lies in one group
-  float gsc[8], gsh[8], ga1[8], ga2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ga1[j] = 0.f; ga2[j] = 0.f; }
-  if (a.gb_v) {
-    const int gr = (chunk * 8) / G;
-    const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      gsc[j] = a.gb_gamma[chunk * 8 + j] * rstd;
-      gsh[j] = a.gb_beta[chunk * 8 + j] - mean * gsc[j];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int px = slot + 64 * i;
-    f16x8 h = *reinterpret_cast<const f16x8*>(s_w + px * 128 + ((chunk ^ (px & 7)) * 16));
-    const size_t off = ((size_t)(n_img * Ho + y0 + (px >> 4)) * Wo + x0 + (px & 15)) * COUT + chunk * 8;
-    if (a.add_src) {
-      const f16x8 r = *reinterpret_cast<const f16x8*>(a.add_src + off);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (f16)((float)h[j] + (float)r[j]);
-    }
-    *reinterpret_cast<f16x8*>(a.out + off) = h;
-    if (a.gb_v) {
-      const f16x8 vv = *reinterpret_cast<const f16x8*>(a.gb_v + off);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float hv = (float)vv[j];
-        const float du = (float)h[j] * lo_mish_grad(hv * gsc[j] + gsh[j]);
-        ga1[j] += du;
-        ga2[j] += du * hv;
-      }
-    }
-  }
-  if (a.gb_v) {
-    const int gr = (chunk * 8) / G;
-    const float mean = a.gb_stats[n_img * 16 + gr * 2], rstd = a.gb_stats[n_img * 16 + gr * 2 + 1];   // re-read after the loop
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ga2[j] = rstd * (ga2[j] - mean * ga1[j]);
-    float* red = reinterpret_cast<float*>(s_patch);   // [512][16] floats; the patch is no longer read
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { red[tid * 16 + j * 2] = ga1[j]; red[tid * 16 + j * 2 + 1] = ga2[j]; }
-    __syncthreads();
-    float* dst = a.gb_P1 + ((size_t)n_img * tiles_img + t_img) * COUT * 2;
-    if (tid < COUT * 2) {
-      const int c = tid >> 1, w = tid & 1, ccx = c >> 3, j = c & 7;
-      float tot = 0.f;
-      for (int r = 0; r < 64; ++r) tot += red[(r * 8 + ccx) * 16 + j * 2 + w];
-      dst[tid] = tot;
-    }
-  }
-}
-
-bool lo_conv4s2_patch_applies(const LoGeom& g) {
-  // measured: 64.6 -> 55.7 us for the launch alone, but the step gets 0.5 % SLOWER (four interleaved pairs): two 73 KB workgroups
-  // per CU leave no LDS for the side stream's weight-gradient kernels that run beside the data gradients.  Opt-in.
-  static const int on = getenv("LO_CONV4S2_PATCH") ? atoi(getenv("LO_CONV4S2_PATCH")) : 0;
-  return on && g.n_phase == 1 && g.T[0] == 16 && g.in_stride == 2 && g.out_stride == 1 && g.Cin == 32 && g.Cout == 64 &&
-         g.Hout % 8 == 0 && g.Wout % 16 == 0 && g.Hin == 2 * g.Hout && g.Win == 2 * g.Wout;
-}
-int lo_conv4s2_patch_tiles_per_image(const LoGeom& g) { return lo_conv4s2_patch_applies(g) ? (g.Hout / 8) * (g.Wout / 16) : 0; }
-
-int lo_conv4s2_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out, hipStream_t st,
-                         const LoGnBwdFuse* gb) {
-  LO_REQUIRE(lo_conv4s2_patch_applies(g), "lo_conv4s2_patch_run: geometry not supported");
-  Conv4S2PatchArgs a{in, wp, bias, add_src, out, gb ? gb->v : nullptr, gb ? gb->stats : nullptr, gb ? gb->gamma : nullptr,
-                     gb ? gb->beta : nullptr, gb ? gb->P1 : nullptr, g};
-  const int tiles = g.B * (g.Hout / 8) * (g.Wout / 16);
-  const double flops = 2.0 * g.B * g.Hout * g.Wout * (double)g.Cout * 16 * g.Cin;
-  const double out_bytes = 2.0 * g.B * g.Hout * g.Wout * g.Cout;
-  const double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + 16.0 * g.Cin * g.Cout) + out_bytes + (add_src ? out_bytes : 0.0) + (gb ? out_bytes : 0.0);
-  LoProfScope _p("lo_conv4s2_patch_dgrad", flops, bytes, st);
-  hipLaunchKernelGGL(lo_conv4s2_patch_dgrad_kernel, dim3(tiles), dim3(512), 0, st, a);
-  LO_LAUNCH_CHECK("conv4s2_patch_dgrad");
   return LO_OK;
 }

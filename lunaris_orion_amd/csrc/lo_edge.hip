@@ -28,57 +28,6 @@ __device__ __forceinline__ void fc_stage_rows(const float* __restrict__ x, float
   }
 }
 
-__global__ __launch_bounds__(256) void lo_first_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                const float* __restrict__ bias, f16* __restrict__ v,
-                                                                float* __restrict__ gn_partial) {
-  __shared__ float xs[3][3][FC_W + 2];
-  __shared__ float ws[27][FC_CO];
-  __shared__ float red[256 * 4];
-  const int tid = threadIdx.x, oy = blockIdx.x, n = blockIdx.y;
-  fc_stage_rows(x, xs, n, oy, tid);
-  for (int i = tid; i < 27 * FC_CO; i += 256) {
-    int co = i % FC_CO, k = i / FC_CO;
-    ws[k][co] = w[co * 27 + k];  // canonical [co][ci][r][s] -> k = ci*9 + r*3 + s
-  }
-  __syncthreads();
-  const int px = tid >> 2, cg = tid & 3;
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
-#pragma unroll
-  for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        float xv = xs[ci][r][2 * px + s];
-        const float* wr = &ws[ci * 9 + r * 3 + s][cg * 16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] += xv * wr[j];
-      }
-  f16x8 h0, h1;
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    h0[j] = (f16)acc[j];
-    h1[j] = (f16)acc[8 + j];
-    float a = (float)h0[j], b = (float)h1[j];
-    s0 += a; q0 += a * a; s1 += b; q1 += b * b;
-  }
-  f16* dst = v + (((size_t)n * 64 + oy) * 64 + px) * FC_CO + cg * 16;
-  *reinterpret_cast<f16x8*>(dst) = h0;
-  *reinterpret_cast<f16x8*>(dst + 8) = h1;
-  red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
-  __syncthreads();
-  if (tid < 16) {
-    int grp = tid >> 1, which = tid & 1;       // group = 8 channels: cg = grp>>1, half = grp&1
-    int cgx = grp >> 1, half = grp & 1;
-    float tot = 0.f;
-    for (int p = 0; p < 64; ++p) tot += red[(p * 4 + cgx) * 4 + half * 2 + which];
-    gn_partial[(((size_t)n * 64 + oy) * 8 + grp) * 2 + which] = tot;
-  }
-}
-
 // The same forward on MFMA, ROWS output rows per workgroup.  D[co][px] = sum_k W[co][k] X[k][px], k = (ci, r, s) < 27 padded to 32:
 //   A (weights) : fp32 split into fp16 hi + lo halves, the four 16-channel fragments of a lane built once per workgroup
 //   B (im2col)  : lane (px, k group g) gathers its eight k values from the staged fp32 input rows (eight ds_read_b32 at per-lane
@@ -183,44 +132,6 @@ __global__ __launch_bounds__(256) void lo_first_conv_fwd_mfma_kernel(const float
       gn_partial[(((size_t)n * 64 + oy) * 8 + grp) * 2 + which] = red[0][grp][which] + red[1][grp][which] + red[2][grp][which] + red[3][grp][which];
     }
     __syncthreads();                       // `so` and `red` are rewritten by the next row
-  }
-}
-
-// first conv weight gradient: partial[wg][co*27 + k] over 8 output rows per workgroup
-__global__ __launch_bounds__(256) void lo_first_conv_wgrad_kernel(const float* __restrict__ x, const f16* __restrict__ dv,
-                                                                  float* __restrict__ partial) {
-  __shared__ float xs[3][3][FC_W + 2];
-  __shared__ f16 ds[64][FC_CO];
-  __shared__ float red[4][FC_CO][27];
-  const int tid = threadIdx.x, n = blockIdx.y, rb = blockIdx.x;  // rb: block of 8 output rows
-  const int co = tid & 63, part = tid >> 6;
-  float acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (int oy = rb * 8; oy < rb * 8 + 8; ++oy) {
-    __syncthreads();
-    fc_stage_rows(x, xs, n, oy, tid);
-    const f16* src = dv + (((size_t)n * 64 + oy) * 64) * FC_CO;
-    for (int i = tid; i < 64 * FC_CO / 8; i += 256)
-      reinterpret_cast<f16x8*>(&ds[0][0])[i] = reinterpret_cast<const f16x8*>(src)[i];
-    __syncthreads();
-    for (int p = part * 16; p < part * 16 + 16; ++p) {
-      float d = (float)ds[p][co];
-#pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int s = 0; s < 3; ++s) acc[ci * 9 + r * 3 + s] += d * xs[ci][r][2 * p + s];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 27; ++k) red[part][co][k] = acc[k];
-  __syncthreads();
-  float* out = partial + ((size_t)n * gridDim.x + rb) * (FC_CO * 27);
-  for (int i = tid; i < FC_CO * 27; i += 256) {
-    int c = i / 27, k = i % 27;
-    out[i] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
   }
 }
 
@@ -353,53 +264,6 @@ __device__ __forceinline__ void lc_stage_a4_wide(const f16* __restrict__ a4, uns
   for (int k = 0; k < NIT; ++k) {
     const int i = tid + k * 256;
     if (i < NCH) *reinterpret_cast<u32x4*>(tile + (i >> 2) * LC_PITCH + (i & 3) * 16) = v[k];
-  }
-}
-
-__global__ __launch_bounds__(256) void lo_final_conv_fwd_kernel(const f16* __restrict__ a4, const float* __restrict__ w,
-                                                                const float* __restrict__ bias, const float* __restrict__ target,
-                                                                float* __restrict__ recon, float* __restrict__ mse_partial) {
-  __shared__ __attribute__((aligned(16))) unsigned char tile[LC_TP * LC_TP * LC_PITCH];
-  __shared__ __attribute__((aligned(16))) float wl[9][LC_CI][4];
-  __shared__ float red[4];
-  const int tid = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
-  lc_stage_a4(a4, tile, n, ty, tx, tid);
-  for (int i = tid; i < 9 * LC_CI; i += 256) {
-    int ci = i % LC_CI, t = i / LC_CI;
-    wl[t][ci][0] = w[(0 * LC_CI + ci) * 9 + t];
-    wl[t][ci][1] = w[(1 * LC_CI + ci) * 9 + t];
-    wl[t][ci][2] = w[(2 * LC_CI + ci) * 9 + t];
-    wl[t][ci][3] = 0.f;
-  }
-  __syncthreads();
-  const int px = tid & 15, py = tid >> 4;
-  float a0 = bias[0], a1 = bias[1], a2 = bias[2];
-#pragma unroll 1
-  for (int r = 0; r < 3; ++r)
-#pragma unroll 1
-    for (int s = 0; s < 3; ++s) {
-      const unsigned char* p = tile + ((py + r) * LC_TP + px + s) * LC_PITCH;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        f16x8 h = *reinterpret_cast<const f16x8*>(p + ch * 16);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[r * 3 + s][ch * 8 + j][0]);
-          float xv = (float)h[j];
-          a0 += xv * wv[0]; a1 += xv * wv[1]; a2 += xv * wv[2];
-        }
-      }
-    }
-  const int oy = ty * LC_T + py, ox = tx * LC_T + px;
-  float r0 = tanhf(a0), r1 = tanhf(a1), r2 = tanhf(a2);
-  size_t o = ((size_t)n * 3 * 128 + oy) * 128 + ox;
-  recon[o] = r0; recon[o + 128 * 128] = r1; recon[o + 2 * 128 * 128] = r2;
-  if (mse_partial) {
-    float d0 = r0 - target[o], d1 = r1 - target[o + 128 * 128], d2 = r2 - target[o + 2 * 128 * 128];
-    float e = lo_wave_sum(d0 * d0 + d1 * d1 + d2 * d2);
-    if ((tid & 63) == 0) red[tid >> 6] = e;
-    __syncthreads();
-    if (tid == 0) mse_partial[((size_t)n * gridDim.y + ty) * gridDim.x + tx] = red[0] + red[1] + red[2] + red[3];
   }
 }
 
@@ -634,20 +498,16 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
 // =============================================================================================
 int lo_first_conv_fwd(const float* x, const float* w, const float* bias, f16* v, float* gn_partial, int B, hipStream_t st) {
   LoProfScope _p("lo_first_conv_fwd", 2.0 * B * 4096 * 64 * 27, (double)B * (3 * 16384 * 4 + 4096 * 64 * 2), st);
-  static const bool direct = getenv("LO_FIRST_FWD_DIRECT") && atoi(getenv("LO_FIRST_FWD_DIRECT")) != 0;   // A/B knob: the fp32 VALU kernel
-  if (direct) hipLaunchKernelGGL(lo_first_conv_fwd_kernel, dim3(64, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
-  else hipLaunchKernelGGL((lo_first_conv_fwd_mfma_kernel<4>), dim3(16, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
+  hipLaunchKernelGGL((lo_first_conv_fwd_mfma_kernel<4>), dim3(16, B), dim3(256), 0, st, x, w, bias, v, gn_partial);
   LO_LAUNCH_CHECK("first_conv_fwd");
   return LO_OK;
 }
 // partial: B*16*1728 floats
 int lo_first_conv_wgrad(const float* x, const f16* dv, float* partial, float* dw, int B, float scale, hipStream_t st) {
   LoProfScope _p("lo_first_conv_wgrad(+sum)", 2.0 * B * 4096 * 64 * 27, (double)B * (3 * 16384 * 4 + 4096 * 64 * 2), st);
-  static const bool direct = getenv("LO_FIRST_WGRAD_DIRECT") && atoi(getenv("LO_FIRST_WGRAD_DIRECT")) != 0;   // A/B knob: the fp32 VALU kernel
-  if (direct) hipLaunchKernelGGL(lo_first_conv_wgrad_kernel, dim3(8, B), dim3(256), 0, st, x, dv, partial);
-  else hipLaunchKernelGGL((lo_first_conv_wgrad_mfma_kernel<4>), dim3(16, B), dim3(256), 0, st, x, dv, partial);
+  hipLaunchKernelGGL((lo_first_conv_wgrad_mfma_kernel<4>), dim3(16, B), dim3(256), 0, st, x, dv, partial);
   LO_LAUNCH_CHECK("first_conv_wgrad");
-  hipLaunchKernelGGL(lo_colsum_kernel, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, dw, B * (direct ? 8 : 16), 1728, 1728, scale);
+  hipLaunchKernelGGL(lo_colsum_kernel, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, dw, B * 16, 1728, 1728, scale);
   LO_LAUNCH_CHECK("first_conv_wgrad_sum");
   return LO_OK;
 }
@@ -659,9 +519,7 @@ int lo_colsum(const float* partial, float* out, int nrow, int ncol, int stride, 
 int lo_final_conv_fwd(const f16* a4, const float* w, const float* bias, const float* target, float* recon,
                       float* mse_partial, int B, hipStream_t st) {
   LoProfScope _p("lo_final_conv_fwd", 2.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 + 3 * 4 * 2), st);
-  static const bool direct = getenv("LO_FINAL_FWD_DIRECT") && atoi(getenv("LO_FINAL_FWD_DIRECT")) != 0;   // A/B knob: the fp32 VALU kernel
-  if (direct) hipLaunchKernelGGL(lo_final_conv_fwd_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
-  else hipLaunchKernelGGL(lo_final_conv_fwd_mfma_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
+  hipLaunchKernelGGL(lo_final_conv_fwd_mfma_kernel, dim3(8, 8, B), dim3(256), 0, st, a4, w, bias, target, recon, mse_partial);
   LO_LAUNCH_CHECK("final_conv_fwd");
   return LO_OK;
 }
@@ -671,11 +529,8 @@ int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const f
                       hipStream_t st) {
   LcBwdArgs a{a4, w, recon, target, drecon, coef, gscale, da4, partial};
   LoProfScope _p("lo_final_conv_bwd(+sums)", 4.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 * 2 + 3 * 4 * 2), st);
-  static const int tpw = getenv("LO_FINAL_BWD_TPW") ? atoi(getenv("LO_FINAL_BWD_TPW")) : 8;   // 8, 4 or 2 tiles per workgroup
-  const int rows = tpw == 2 ? 32 : (tpw == 4 ? 16 : 8);
-  if (rows == 32) hipLaunchKernelGGL(lo_final_conv_bwd_kernel<2>, dim3(rows, B), dim3(256), 0, st, a);
-  else if (rows == 16) hipLaunchKernelGGL(lo_final_conv_bwd_kernel<4>, dim3(rows, B), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(lo_final_conv_bwd_kernel<8>, dim3(rows, B), dim3(256), 0, st, a);
+  constexpr int rows = 8;    // 8 tiles (a whole row of tiles) per workgroup; 4 / 2 measured in round 2: 86 / 108 / 147 us
+  hipLaunchKernelGGL(lo_final_conv_bwd_kernel<8>, dim3(rows, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("final_conv_bwd");
   hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * rows, 864, 867, scale);
   LO_LAUNCH_CHECK("final_conv_dw");

@@ -16,17 +16,15 @@ int lo_pack_blocks(const LoGeom& g);   // blocks of one job in the fused pack la
 struct LoGnBwdFuse {
   const f16* v; const float* stats; const float* gamma; const float* beta; float* P1;
   f16* dv = nullptr; float* P2 = nullptr; unsigned int* counter = nullptr; unsigned int target = 0; unsigned int* fail = nullptr;
+  bool keep_out = false;    // with dv: store the activation gradient too (somebody else reads it: the decoder's skip gradients)
 };
 bool lo_conv_gnb_apply_tiles(const LoGeom& gd, int* mts, int* nt);
-// GroupNorm + Mish of the producing layer applied on the consumer's operand load (fused-tap kernel only, see Conv3Args::xg_*):
-// `in` of the conv is the producer's raw output; partial / MT = its epilogue sums; y / stats = what lo_gn_fwd would have written
-struct LoGnApplyFuse { const float* partial; int MT; const float* gamma; const float* beta; float* stats; f16* y; };
 // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums; out_pitch > 0: the output tensor has out_pitch channels per pixel
 // and this op writes its Cout channels starting at channel out_choff (writing straight into a concatenated tensor)
 struct LoConvExtra { int act; float* bn_partial; int out_pitch = 0; int out_choff = 0; };
 int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                 float* gn_partial, float* slab, int nsplit, hipStream_t st, const LoGnBwdFuse* gb = nullptr,
-                const LoConvExtra* ex = nullptr, const LoGnApplyFuse* xg = nullptr, const LoGnFuse* gf = nullptr);
+                const LoConvExtra* ex = nullptr, const LoGnFuse* gf = nullptr);
 // gf: GroupNorm + Mish of the output inside the epilogue (LoGnFuse, lo_common.h).  lo_conv_gn_fuse_tiles: whether the kernel
 // lo_conv_run picks for g supports it, and the tile grid per sample the caller must put into gf->MTs / gf->NT
 bool lo_conv_gn_fuse_tiles(const LoGeom& g, int* mts, int* nt);
@@ -53,21 +51,22 @@ int lo_conv3_run_pp_f8(const LoGeom& g, const uint8_t* in8, const uint8_t* w8, c
                        hipStream_t st, const LoConvExtra* ex);
 int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out,
                  float* gn_partial, hipStream_t st, const LoConvExtra* ex = nullptr, const LoGnBwdFuse* gb = nullptr,
-                 const LoGnApplyFuse* xg = nullptr, const LoGnFuse* gf = nullptr);
+                 const LoGnFuse* gf = nullptr);
 bool lo_conv3_fuses_gnb(const LoGeom& g);
 bool lo_convt4_patch_applies(const LoGeom& g);   // patch-resident forward of the 64 -> 32 transposed convolution
 int lo_convt4_patch_tiles_per_image(const LoGeom& g);
-bool lo_conv4s2_patch_applies(const LoGeom& g);   // ... and of its data gradient (4x4 stride-2 conv, 32 -> 64 channels)
-int lo_conv4s2_patch_tiles_per_image(const LoGeom& g);
-int lo_conv4s2_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, const f16* add_src, f16* out, hipStream_t st,
-                         const LoGnBwdFuse* gb);
 int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, f16* out, float* gn_partial, hipStream_t st);
 int lo_conv_gnb_rows(const LoGeom& g);   // P1 rows per sample written by lo_conv_run(g, ..., gb) (fused GroupNorm-backward epilogue)
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);
 int lo_wgrad_nsplit(const LoGeom& g);
 int lo_wgrad3_nsplit(const LoGeom& g);   // multi-tap 3x3 stride-1 weight-gradient kernel: pixel splits, 0 = does not apply
 int lo_wgrad3_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, hipStream_t st, int* nsplit_out);
-int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st);
+int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st, bool defer_reduce = false);
+// the slab reductions of several layers in one launch (job table in device memory)
+struct LoWgradRedJob { const float* slab; size_t grad_off; int total, nsplit, block0, pad_; LoGeom g; };
+int lo_wgrad_slab_splits(const LoGeom& g);      // splits lo_wgrad_run writes for g; 0 = direct (no slab)
+int lo_wgrad_reduce_blocks(const LoGeom& g);
+int lo_wgrad_reduce_all(const LoWgradRedJob* jobs_dev, int njobs, int nblocks, int block_base, float* G, float scale, hipStream_t st);
 size_t lo_wgrad_slab_bytes(const LoGeom& g);
 size_t lo_packed_weight_elems(const LoGeom& g);
 

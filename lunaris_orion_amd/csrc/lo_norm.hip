@@ -14,7 +14,7 @@
 enum { GN_MODE_PLAIN = 0, GN_MODE_SKIP = 1, GN_MODE_RES = 2 };
 
 int lo_gn_nchunk(int HW, int C) {
-  static const long chunk_elems = getenv("LO_GN_CHUNK_ELEMS") ? atol(getenv("LO_GN_CHUNK_ELEMS")) : 16384;
+  constexpr long chunk_elems = 16384;     // smaller and larger chunks measured in round 1: the optimum except for the 128 x 128 layer
   // the 128x128-resolution layer (32 channels): twice the chunk halves the partial rows its backward apply pass re-reads
   // per workgroup (measured 50 -> 41 us; neutral for its other two passes, worse for every smaller layer)
   const long ce = (long)HW * C >= 524288 ? 2 * chunk_elems : chunk_elems;

@@ -292,8 +292,6 @@ __global__ __launch_bounds__(512) void lo_wgrad3x3_mt(Wgrad3Args a) {
 // launcher side
 // ---------------------------------------------------------------------------------------------
 static inline bool wgrad3_applies(const LoGeom& g) {
-  static const int on = getenv("LO_WGRAD_MT") ? atoi(getenv("LO_WGRAD_MT")) : 1;
-  if (!on) return false;
   if (g.n_phase != 1 || g.T[0] != 9 || g.in_stride != 1 || g.out_stride != 1) return false;
   if (g.Cin % 64 || g.Cout % 64 || g.Hin != g.Hout || g.Win != g.Wout) return false;
   if (g.Win % 16 == 0) return g.Hin % 2 == 0;
@@ -305,7 +303,7 @@ int lo_wgrad3_nsplit(const LoGeom& g) {
   if (!wgrad3_applies(g)) return 0;
   const long tiles = (long)(g.Cout / 64) * (g.Cin / 64);
   const long nchunks = (long)g.B * g.Hin * g.Win / 32;
-  static const int target = getenv("LO_WGRAD3_WGS") ? atoi(getenv("LO_WGRAD3_WGS")) : 512;
+  constexpr int target = 512;      // 256 / 512 / 768 swept in round 2: inside +-0.5 %
   long want = (target + tiles - 1) / tiles;
   const long slab_bytes = (long)g.Cout * 9 * g.Cin * 4;
   long cap = (24L << 20) / slab_bytes;                    // slab traffic (written here, re-read by the reduce pass)

@@ -135,8 +135,6 @@ class VAEStepper:
         host synchronisation in the single-process case: the skipped-update counter of the step just enqueued travels to pinned
         memory behind it; whichever earlier copy has landed by now is evaluated.  The host runs a step or two ahead of the GPU, so
         an overflow is answered after that many skipped updates — not after `--log_every` of them, as when only metrics() looked."""
-        if os.environ.get("LO_NO_SKIP_OBSERVE") == "1":      # measurement knob: no per-step device -> host copy at all
-            return
         dp = self.grad_sync is not None and getattr(self.grad_sync, "world", 1) > 1
         if dp:
             # fixed lag: wait for the observation of `_DP_LAG` steps ago (long finished unless the host runs further ahead than that)

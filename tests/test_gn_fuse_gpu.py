@@ -96,4 +96,5 @@ def test_fused_groupnorm_backward_apply_equals_the_separate_pass(tmp_path, B, L)
                 bad.append((k, (a - b).abs().max().item(), tol))
         elif not torch.equal(fused[k], plain[k]):
             bad.append((k, (a - b).abs().max().item(), 0.0))
-    assert not bad, bad
+    first_step = [t for t in bad if t[0].startswith(("grad0", "recon0", "mu0", "logvar0", "losses0"))]
+    assert not bad, (first_step or bad)[:12]

@@ -560,17 +560,17 @@ def test_pipelined_optimizer_step_equals_the_plain_one(precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gn_on_load", ["0", "1"])
-def test_golden_parity_with_the_fused_tap_kernel_forced_on(gn_on_load):
-    """At batch 64 the ResBlock convolutions (forward and data gradient, with the fused GroupNorm-backward epilogue) run on the
-    8-wave fused-tap kernel; at the parity batch they would fall back to lo_igemm_nt.  LO_HALO=3 forces the fused-tap kernel on
-    every shape it can tile, LO_GN_ON_LOAD=1 adds the GroupNorm + Mish on its operand load (opt-in path): the forward / gradient
-    / 3-step trace comparisons against the reference's fixtures must hold unchanged.  Both knobs are read once per process,
-    hence the subprocess (one pytest run per variant, not one per case)."""
+@pytest.mark.parametrize("gn_fuse", ["1", "0"])
+def test_golden_parity_with_the_fused_tap_kernel_forced_on(gn_fuse):
+    """At batch 64 the ResBlock convolutions (forward and data gradient, with the fused GroupNorm epilogues) run on the 8-wave
+    fused-tap kernel; at the parity batch they would fall back to lo_igemm_nt.  LO_HALO=3 forces the fused-tap kernel on every
+    shape it can tile: the forward / gradient / 3-step trace comparisons against the reference's fixtures must hold unchanged,
+    with the GroupNorm passes inside the conv epilogues (the sample rendezvous: LO_GN_FUSE / LO_GNB_APPLY_FUSE, on or off) and as
+    separate launches.  The knobs are read once per process, hence the subprocess (one pytest run per variant)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LO_HALO="3", LO_GN_ON_LOAD=gn_on_load, LO_HALO_PAIR="1", LO_CONV4S2_PATCH="1")   # + the two-images-per-tile form on the 8x8 stage, the patch-resident 4x4 s2 data gradient
+    env = dict(os.environ, LO_HALO="3", LO_GN_FUSE=gn_fuse, LO_GNB_APPLY_FUSE=gn_fuse)
     sel = "test_forward_matches_oracle_and_golden or test_gradients_match_the_golden_samples or test_fused_steps_match_golden_trace or test_run_to_run_bitwise_determinism"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_vae_gpu.py"), "-x", "-q", "-m", "gpu", "-k", sel],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
