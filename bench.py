@@ -313,7 +313,7 @@ def main():
                     which = "forward" if k.startswith("fwd") else ("data_gradient" if k.startswith("dgrad") else "weight_gradient")
                 elif k.startswith("lo_first_conv_fwd"):
                     which = "forward"
-                elif k.startswith("lo_first_conv_wgrad") or k.startswith("wgrad reduce (encoder"):
+                elif k.startswith("lo_first_conv_wgrad"):
                     which = "weight_gradient"
                 if which:
                     parts[which] += r[0] / args.prof_steps

@@ -204,7 +204,9 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_bcnt;
   unsigned gba_epoch;
   bool dv_done; int np2;
-  size_t o_wslab_l;          // this layer's own weight-gradient slab (merged slab reduction: lo_wgrad_reduce_all)
+  // few-rows layers (the 8 x 8 stage): forward / data gradient as a K-split 128 x 128-tile GEMM into fp32 slabs + ONE fused
+  // (sample, group)-local pass (slab sum + bias + GroupNorm [+ Mish | backward]); 0 = the one-launch kernel
+  int sk_fwd, sk_dgrad;
 };
 
 struct Arena {
@@ -261,17 +263,17 @@ struct LoVae {
   struct { bool pending; float* P; const float* G; float* M; float* V; void* ws; const float* norm; float lr, beta1, beta2, eps, wd; int step; } defer;
   int n_packjobs_s4, pack_blocks_s4, n_packjobs8_s4, pack_blocks8_s4;   // job-table prefix up to and including encoder stage 4
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
+  // LO_WGRAD_PAIR=1: the weight gradients are handed to the side stream two layers at a time (one event per pair instead of one
+  // per layer: every event record costs the caller's stream a 6-7 us bubble, tools/timeline.py)
+  size_t o_skslab;    // slabs of the split-K convolutions (one launch at a time on the caller's stream)
+  bool gn_local;      // LO_GN_LOCAL=0: never use the one-pass (sample, group)-local GroupNorm backward
+  bool pair_wgrad;
+  struct { ConvLayer* c; const f16* layer_in; } pend[2];
+  int npend, nevent;
   bool overlap;
   float* norm_scratch;   // lo_vae_set_gradnorm_scratch: where a single-call backward leaves the early part of the gradient norm
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
   bool fuse_gnf;      // fuse GroupNorm + Mish of a conv output into that conv's epilogue (sample rendezvous between its workgroups)
-  // the weight-gradient slab reductions of the layers of one backward range in ONE launch (job table in the workspace) instead of
-  // one launch per layer: range 0 = decoder (4 layers), 1 + k = encoder stage 4 - k (3 layers; 2 for the first stage), issued on
-  // the side stream behind the range's last weight-gradient GEMM
-  bool merge_reduce;
-  size_t o_redjobs;
-  std::vector<LoWgradRedJob> redjobs_host;
-  int red_first[5], red_n[5], red_block0[5], red_blocks[5];
   bool fuse_gna;      // fuse the GroupNorm-backward APPLY pass into the data-gradient epilogue that already carries its reduction
   size_t o_sync_fail; // one word: set by a workgroup whose rendezvous poll ran out (never, unless a launch was lost)
   const void* sync_for_ws;
@@ -318,6 +320,7 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   c.o_xcnt = ar.take((size_t)B * 4);
   c.o_bcnt = ar.take((size_t)B * 8 * 4);
   c.gba_epoch = 0; c.dv_done = false; c.np2 = 0;
+  c.sk_fwd = c.sk_dgrad = 0;
   return LO_OK;
 }
 
@@ -432,13 +435,6 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     wslab = b > wslab ? b : wslab;
   }
   h->o_wslab = ar.take(wslab);
-  // one slab per layer as well: with the merged reduction a layer's partial sums stay until the end of its backward range
-  h->merge_reduce = !(getenv("LO_WGRAD_MERGE") && atoi(getenv("LO_WGRAD_MERGE")) == 0);
-  for (int s = 0; s < 4; ++s) {
-    for (int k = 0; k < 3; ++k) h->enc[s][k].o_wslab_l = (h->merge_reduce && !(s == 0 && k == 0)) ? ar.take(lo_wgrad_slab_bytes(h->enc[s][k].gf)) : 0;
-    h->dec[s].o_wslab_l = h->merge_reduce ? ar.take(lo_wgrad_slab_bytes(h->dec[s].gf)) : 0;
-  }
-  h->o_redjobs = ar.take(sizeof(LoWgradRedJob) * 16);
   // The two Linear weight gradients run on the MAIN stream while the decoder's conv weight gradients may still be running on
   // the side stream: they get their own slab.  (Found by the buffer audit of round 2: at latent 512 / 256 both Linear
   // gradients are written directly and never touch a slab, but at latent 64 / 128 lo_wgrad_nsplit() gives decoder.fc two
@@ -460,6 +456,21 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   // channel ResBlock and stride-2 convs, the 512 / 256 / 128 channel transposed convs) reads an e4m3 copy of its input,
   // written by the kernel that produces the fp16 activation (which the backward still uses)
   h->fp8_fwd = (flags & LO_VAE_FP8_FWD) != 0;
+  {
+    // few-rows convolutions as split-K GEMMs + a fused slab pass (LO_SPLITK_CONV=0: every convolution on its one-launch kernel)
+    const bool sk_on = !(getenv("LO_SPLITK_CONV") && atoi(getenv("LO_SPLITK_CONV")) == 0) && !h->fp8_fwd;
+    size_t slab = 0;
+    auto plan_sk = [&](ConvLayer& c, bool first) {
+      if (first || !sk_on) return;
+      c.sk_fwd = lo_conv_splitk_plan(c.gf);
+      c.sk_dgrad = lo_conv_splitk_plan(c.gd);
+      const size_t bf = (size_t)c.sk_fwd * B * c.gf.GH * c.gf.GW * c.gf.Cout * 4, bd = (size_t)c.sk_dgrad * B * c.gd.GH * c.gd.GW * c.gd.Cout * 4;
+      slab = bf > slab ? bf : slab;
+      slab = bd > slab ? bd : slab;
+    };
+    for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) plan_sk(h->enc[s][k], s == 0 && k == 0); plan_sk(h->dec[s], false); }
+    h->o_skslab = ar.take(slab > 0 ? slab : 256);
+  }
   for (int s = 0; s < 4; ++s) h->o_eout8[s] = 0;
   h->o_h08 = 0; h->o_packjobs8 = 0; h->n_packjobs8 = h->pack_blocks8 = 0;
   h->n_packjobs8_enc = h->pack_blocks8_enc = 0;
@@ -493,17 +504,28 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   // was not bitwise reproducible while a weight-gradient kernel ran beside it (tools/gnb_det.py: 1365 mismatching tensors
   // in 24 runs; 0 with this form) -- the determinism tests of tests/test_fullsize_gpu.py and test_vae_gpu.py guard it
   h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
-  // GroupNorm + Mish in the conv epilogue (LO_GN_FUSE=0: the separate lo_gn_fwd pass after every conv).  Which layers qualify is a
-  // property of the kernel lo_conv_run picks for the geometry (lo_conv_gn_fuse_tiles); the fp8 operand mode keeps the separate
-  // pass (it also writes the e4m3 copy of the activation).
-  h->fuse_gnf = !(getenv("LO_GN_FUSE") && atoi(getenv("LO_GN_FUSE")) == 0) && !h->fp8_fwd;
+  h->pair_wgrad = getenv("LO_WGRAD_PAIR") && atoi(getenv("LO_WGRAD_PAIR")) != 0;
+  h->gn_local = !(getenv("LO_GN_LOCAL") && atoi(getenv("LO_GN_LOCAL")) == 0);
+  h->npend = 0; h->nevent = 0;
+  // GroupNorm + Mish in the conv epilogue (LO_GN_FUSE=1; the default is the separate lo_gn_fwd pass after every conv).  Built,
+  // bitwise equal to the separate pass (tests/test_gn_fuse_gpu.py) and measured at batch 64 in two interleaved rounds: 20 403 /
+  // 20 414 sprites/s against 20 821 / 20 859 -- 2 % SLOWER.  Per layer the fused conv launches take 7-22 us longer than before while
+  // the passes they replace took 8-23 us: every workgroup of a sample waits for the slowest tile of that sample (on two-round grids
+  // the second round starts staggered, so the skew of a whole round is paid twice), the hand-off is a chain of dependent memory
+  // round trips (publish, count, poll, read the lines: ~5 us on an otherwise idle CU), and the Mish of the tile (25 VALU operations
+  // per element) runs on 2 waves per SIMD with nothing to overlap it, where the separate pass spreads the same arithmetic over
+  // every wave slot of the chip.  Which layers qualify is a property of the kernel lo_conv_run picks for the
+  // geometry (lo_conv_gn_fuse_tiles); the fp8 operand mode keeps the separate pass (it also writes the e4m3 copy of the activation).
+  h->fuse_gnf = getenv("LO_GN_FUSE") && atoi(getenv("LO_GN_FUSE")) != 0 && !h->fp8_fwd;
   // ... and the backward's apply pass in the data-gradient epilogue of the consuming layer (LO_GNB_APPLY_FUSE=0: separate
-  // lo_gn_bwd_apply launches); needs the fused reduction
+  // lo_gn_bwd_apply launches); needs the fused reduction.  Same mechanism, but here it WINS (+0.8 %: 21 002 / 21 021 against
+  // 20 821 / 20 859): the epilogue already holds the activation gradient and has read v for the reduction, so the apply pass it
+  // removes (a read of dy and v, a write of dv: 12-27 us per layer) costs more than the wait, and dy is never stored at all
   h->fuse_gna = h->fuse_gnb && !(getenv("LO_GNB_APPLY_FUSE") && atoi(getenv("LO_GNB_APPLY_FUSE")) == 0);
   h->sync_for_ws = nullptr;
   {
     auto plan = [&](ConvLayer& c, bool first) {
-      c.gnf = h->fuse_gnf && !first && lo_conv_gn_fuse_tiles(c.gf, &c.gnf_mts, &c.gnf_nt);
+      c.gnf = h->fuse_gnf && !first && !c.sk_fwd && lo_conv_gn_fuse_tiles(c.gf, &c.gnf_mts, &c.gnf_nt);
     };
     for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) plan(h->enc[s][k], s == 0 && k == 0); plan(h->dec[s], false); }
   }
@@ -640,48 +662,10 @@ static int vae_ensure_pack_jobs(LoVae* h, const float* P, void* ws, hipStream_t 
       h->n_packjobs8 = (int)j8.size();
       h->pack_blocks8 = blocks8;
     }
-    if (h->merge_reduce) {
-      std::vector<LoWgradRedJob>& rj = h->redjobs_host;
-      rj.clear();
-      int rblocks = 0;
-      auto addr = [&](ConvLayer& c) {
-        const int ns = lo_wgrad_slab_splits(c.gf);
-        if (ns <= 0) return;                      // written directly: nothing to reduce
-        LoWgradRedJob j;
-        memset(&j, 0, sizeof(j));
-        j.slab = WSP(float, c.o_wslab_l); j.grad_off = h->p_off[c.p_w]; j.total = (int)lo_packed_weight_elems(c.gf); j.nsplit = ns;
-        j.block0 = rblocks; j.g = c.gf;
-        rblocks += lo_wgrad_reduce_blocks(c.gf);
-        rj.push_back(j);
-      };
-      auto range = [&](int r, auto&& fill) {
-        h->red_first[r] = (int)rj.size(); h->red_block0[r] = rblocks;
-        fill();
-        h->red_n[r] = (int)rj.size() - h->red_first[r]; h->red_blocks[r] = rblocks - h->red_block0[r];
-      };
-      range(0, [&] { for (int s = 3; s >= 0; --s) addr(h->dec[s]); });
-      for (int s = 3; s >= 0; --s)
-        range(4 - s, [&] { for (int k = 2; k >= (s == 0 ? 1 : 0); --k) addr(h->enc[s][k]); });
-      LO_REQUIRE(rj.size() <= 16, "too many slab-reduction jobs");
-      if (!rj.empty())
-        LO_HIP(hipMemcpyAsync(WSP(void, h->o_redjobs), rj.data(), rj.size() * sizeof(LoWgradRedJob), hipMemcpyHostToDevice, st));
-    }
     h->packjobs_for_ws = ws;
     h->packjobs_for_params = (const void*)P;
   }
   return LO_OK;
-}
-
-// the merged slab reduction of backward ranges r0..r1 (adjacent in the job table) on `st`
-static int vae_reduce_slabs(LoVae* h, int r0, int r1, float* G, void* ws, float inv, hipStream_t st, const char* tag) {
-  if (!h->merge_reduce) return LO_OK;
-  int n = 0, blocks = 0;
-  for (int r = r0; r <= r1; ++r) { n += h->red_n[r]; blocks += h->red_blocks[r]; }
-  if (n == 0) return LO_OK;
-  if (g_lo_prof_on) g_lo_prof_tag = tag;
-  int r_ = lo_wgrad_reduce_all(WSP(LoWgradRedJob, h->o_redjobs) + h->red_first[r0], n, blocks, h->red_block0[r0], G, inv, st);
-  g_lo_prof_tag = nullptr;
-  return r_;
 }
 
 // side-stream bookkeeping: one event per operand-refresh level (see LoVae::ev_lvl)
@@ -889,6 +873,14 @@ static int conv_gn(LoVae* h, ConvLayer& c, const f16* in, const f16* other, f16*
   int r_;
   // GroupNorm + Mish inside the conv's own epilogue (the workgroups of a sample exchange their sums: LoGnFuse) where the kernel that
   // owns this geometry supports it; the separate lo_gn_fwd pass below is then not run.  Same statistics, same arithmetic, same bits.
+  if (c.sk_fwd && !c.f8 && !o_y8) {
+    // few output rows: K-split GEMM into fp32 slabs, then ONE (sample, group)-local pass: slab sum + bias -> v, statistics, GroupNorm + Mish
+    int r2 = lo_conv_run(c.gf, in, WSP(f16, c.o_wp_f), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_skslab), c.sk_fwd, st);
+    g_lo_prof_tag = nullptr;
+    if (r2 != LO_OK) return r2;
+    return lo_splitk_gn_fwd(WSP(float, h->o_skslab), c.sk_fwd, PRM(c.p_b), PRM(c.p_gw), PRM(c.p_gb), other, WSP(f16, c.o_v), y,
+                            WSP(float, c.o_stats), h->B, c.Ho * c.Wo, c.Cout, mode, st);
+  }
   const bool fuse = c.gnf && !c.f8 && !o_y8;
   LoGnFuse gf;
   if (fuse) {
@@ -1051,6 +1043,20 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
   return LO_OK;
 }
 
+// hand the weight gradients whose dv is ready over to the side stream: ONE event for all of them
+static int vae_flush_wgrads(LoVae* h, float* G, void* ws, float inv_scale, hipStream_t st) {
+  if (h->npend == 0) return LO_OK;
+  const int e = (h->nevent++) & 1;
+  LO_HIP(hipEventRecord(h->ev_dv[e], st));
+  LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[e], 0));
+  for (int i = 0; i < h->npend; ++i) {
+    ConvLayer& c = *h->pend[i].c;
+    LO_TRY(lo_wgrad_run(c.gf, h->pend[i].layer_in, WSP(f16, c.o_dv), WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
+  }
+  h->npend = 0;
+  return LO_OK;
+}
+
 // backward of one conv+GN+Mish layer.  dy: gradient wrt the layer's activation output (after mish, before any skip add).
 // Produces the parameter gradients and, when din != null, the gradient wrt the layer input (+ add_src).
 // prod: the conv+GN+Mish layer (mode plain / skip) whose activation gradient this layer's data gradient produces;
@@ -1065,24 +1071,47 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
   // c.dv_done: the data gradient of the consuming layer has already turned this layer's activation gradient into dv (and P2) in
   // its epilogue -- `dy` was never stored
-  if (!c.dv_done)
-    LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
-                             WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
+  if (!c.dv_done) {
+    if (c.np1 == 0 && h->gn_local && lo_gn_bwd_local_applies(c.Ho * c.Wo, c.Cout)) {
+      // nobody has reduced this layer yet and a (sample, group) fits a workgroup: reduce + apply in ONE pass (the ResBlock tails of
+      // the 16 x 16 and 8 x 8 stages), one P1 / P2 row per sample
+      LO_TRY(lo_gn_bwd_local(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv, WSP(float, c.o_P1),
+                             WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st));
+      c.np1 = 1; c.np2 = 1;
+    } else {
+      LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
+                               WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
+    }
+  }
   if (ov) {
-    LO_HIP(hipEventRecord(h->ev_dv[k & 1], st));
-    LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[k & 1], 0));
-    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, h->merge_reduce ? WSP(float, c.o_wslab_l) : WSP(float, h->o_wslab), GRD(c.p_w), inv_scale,
-                        h->side, h->merge_reduce));
+    h->pend[h->npend].c = &c; h->pend[h->npend].layer_in = layer_in; ++h->npend;
+    if (!h->pair_wgrad || h->npend == 2) LO_TRY(vae_flush_wgrads(h, G, ws, inv_scale, st));
   } else {
     static char wtag[32][64];
     if (g_lo_prof_on && g_lo_prof_layers) {
       snprintf(wtag[k & 31], 64, "wgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gf.Cin, c.gf.Cout);
       g_lo_prof_tag = wtag[k & 31];
     }
-    int r_ = lo_wgrad_run(c.gf, layer_in, dv, h->merge_reduce ? WSP(float, c.o_wslab_l) : WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st,
-                          h->merge_reduce);
+    int r_ = lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, st);
     g_lo_prof_tag = nullptr;
     if (r_ != LO_OK) return r_;
+  }
+  if (din && prod && c.sk_dgrad && lo_gn_bwd_local_applies(prod->Ho * prod->Wo, prod->Cout)) {
+    // few output rows: the data gradient as a K-split GEMM into fp32 slabs, then ONE (sample, group)-local pass that sums them
+    // (+ the residual gradient) and runs the whole GroupNorm backward of the producing layer: dv, one P1 / P2 row per sample
+    static char stag[32][64];
+    if (g_lo_prof_on && g_lo_prof_layers) {
+      snprintf(stag[k & 31], 64, "dgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gd.Cin, c.gd.Cout);
+      g_lo_prof_tag = stag[k & 31];
+    }
+    int r_ = lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_skslab), c.sk_dgrad, st);
+    g_lo_prof_tag = nullptr;
+    if (r_ != LO_OK) return r_;
+    LO_TRY(lo_splitk_gn_bwd(WSP(float, h->o_skslab), c.sk_dgrad, add_src, WSP(f16, prod->o_v), WSP(float, prod->o_stats), PRM(prod->p_gw),
+                            PRM(prod->p_gb), din_has_other_readers ? din : nullptr, WSP(f16, prod->o_dv), WSP(float, prod->o_P1),
+                            WSP(float, prod->o_P2), h->B, prod->Ho * prod->Wo, prod->Cout, st));
+    prod->dv_done = true; prod->np1 = 1; prod->np2 = 1;
+    return LO_OK;
   }
   if (din) {
     LoGnBwdFuse gb, *gbp = nullptr;
@@ -1251,7 +1280,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     gout = din;
   }
   // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
-  LO_TRY(vae_reduce_slabs(h, 0, 0, G, ws, inv, (h->overlap && !g_lo_prof_on) ? h->side : st, "wgrad reduce (decoder layers, merged)"));
+  LO_TRY(vae_flush_wgrads(h, G, ws, inv, st));
   // ---- decoder.fc
   LO_TRY(lo_nhwc_to_nchw_f16(Ga, Gb, B, 64, 512, st));                       // Gb = dy of decoder.fc, [B][32768] c-major
   LO_TRY(lo_colsum_f16(Gb, GRD(h->idx_dfc_b), B, 32768, inv, st));
@@ -1337,8 +1366,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
                                  WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st, c0.np1));
       LO_TRY(lo_first_conv_wgrad(x, dv0, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
-    // this stage's weight-gradient GEMMs are all on the side stream now: their slabs in one launch behind them
-    LO_TRY(vae_reduce_slabs(h, 4 - s, 4 - s, G, ws, inv, (h->overlap && !g_lo_prof_on) ? h->side : st, "wgrad reduce (encoder layers, merged)"));
+    if (s == s_lo) LO_TRY(vae_flush_wgrads(h, G, ws, inv, st));      // nothing may be left pending at the join below
   }
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer
   if (h->overlap && !g_lo_prof_on) {

@@ -983,25 +983,6 @@ __global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __res
                                                               int total, int nsplit, float scale) {
   lo_wgrad_reduce_block(slab, grad, g, total, nsplit, scale, (int)blockIdx.x);
 }
-// the slab reductions of SEVERAL layers in one launch: job table in device memory (uploaded once per workspace by the executor);
-// job j owns the blocks [block0, block0 + ceil(total / 256)); grad = flat gradient buffer + the job's element offset
-__global__ __launch_bounds__(256) void lo_wgrad_reduce_all_kernel(const LoWgradRedJob* __restrict__ jobs, int njobs, int block_base,
-                                                                  float* __restrict__ G, float scale) {
-  const int bid = (int)blockIdx.x + block_base;
-  int j = 0;
-  while (j + 1 < njobs && bid >= jobs[j + 1].block0) ++j;
-  const LoWgradRedJob& J = jobs[j];
-  lo_wgrad_reduce_block(J.slab, G + J.grad_off, J.g, J.total, J.nsplit, scale, bid - J.block0);
-}
-int lo_wgrad_reduce_blocks(const LoGeom& g) { return (geom_packed_elems(g) / 4 + 63) / 64; }
-int lo_wgrad_reduce_all(const LoWgradRedJob* jobs_dev, int njobs, int nblocks, int block_base, float* G, float scale, hipStream_t st) {
-  if (njobs <= 0 || nblocks <= 0) return LO_OK;
-  LoProfScope _p("lo_wgrad_reduce", 0, 0, st);
-  hipLaunchKernelGGL(lo_wgrad_reduce_all_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, block_base, G, scale);
-  LO_LAUNCH_CHECK("wgrad_reduce_all");
-  return LO_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
@@ -1198,6 +1179,21 @@ int lo_pack_f8_all(const LoPackF8Job* jobs_dev, int njobs, int nblocks, hipStrea
 }
 
 // Run one conv-like op.  `slab` + nsplit > 1 selects split-K (output = fp32 partials, caller reduces).
+// Split-K plan for a single-phase convolution whose GroupNorm groups are (sample, group)-local (lo_gn_bwd_local_applies on ITS
+// OUTPUT): 128 x 128 tiles, K split so that about two workgroups per CU run.  Returns the number of splits, or 0 when the op
+// should stay on its one-launch kernel (long grids, fused-tap geometry that already fills the chip, too few K steps).
+int lo_conv_splitk_plan(const LoGeom& g) {
+  if (g.n_phase != 1 || g.T[0] < 9 || g.Cin % 64 != 0 || g.Cout % 128 != 0) return 0;
+  const long M = (long)g.B * g.GH * g.GW;
+  if (M % 128 != 0 || !lo_gn_bwd_local_applies(g.GH * g.GW, g.Cout)) return 0;
+  const long tiles = (M / 128) * (g.Cout / 128);
+  if (tiles >= 256) return 0;                         // the one-launch kernels already put a workgroup on every CU
+  const int ksteps = g.T[0] * (g.Cin / 64);
+  int ns = (int)((512 + tiles - 1) / tiles);
+  while (ns > 1 && ksteps / ns < 8) --ns;             // at least 8 K steps per split
+  return ns >= 2 ? ns : 0;
+}
+
 // Data-gradient op g with the fused GroupNorm-backward reduction: can its epilogue also run the APPLY pass (LoGnBwdFuse::dv)?
 // Single-phase ops on lo_igemm_nt / lo_conv3x3_pp whose tiles lie inside one sample and whose 8-channel chunks lie inside one
 // GroupNorm group.  mts / nt: P1 rows per sample and n tiles per row of the launch.
@@ -1272,6 +1268,9 @@ int lo_conv_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias
   if (a.nsplit > 1) {
     LO_REQUIRE(g.n_phase == 1 && slab, "lo_conv_run: split-K needs a single phase and a slab");
     LO_REQUIRE(BK == 64 && g.Cout % 64 == 0, "lo_conv_run: split-K path needs Cin%%64==0 and Cout%%64==0");
+    // convolutions with few output rows (the 8 x 8 stage: M = 4 096): 128 x 128 tiles halve the L2 -> LDS operand traffic of the
+    // 64 x 64 tiles that the tile heuristic would need to fill the chip, and the K split fills it instead (lo_conv_splitk_plan)
+    if (g.T[0] > 1 && a.M % 128 == 0 && g.Cout % 128 == 0) return launch_igemm<128, 128, 64>(a, st);
     return launch_igemm<64, 64, 64>(a, st);
   }
   // tile choice
@@ -1382,19 +1381,10 @@ int lo_wgrad_nsplit(const LoGeom& g) {
   return (int)want;
 }
 
-// pixel splits the kernel lo_wgrad_run launches for g really writes (the multi-tap kernel drops empty splits); 0 = the gradient is
-// written directly (no slab, no reduce)
-int lo_wgrad_slab_splits(const LoGeom& g) {
-  if (lo_wgrad3_nsplit(g) > 0) {
-    const int nchunks = g.B * g.Hin * g.Win / 32, ns = lo_wgrad3_nsplit(g), cps = (nchunks + ns - 1) / ns;
-    return (nchunks + cps - 1) / cps;
-  }
-  const int ns = lo_wgrad_nsplit(g);
-  return (ns == 1 && g.sc == 1) ? 0 : ns;
-}
-
-// defer_reduce: leave the slab; the caller sums it later (lo_wgrad_reduce_all with a job built from lo_wgrad_slab_splits)
-int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st, bool defer_reduce) {
+// (one reduction launch for several layers -- a slab per layer, job table in the workspace -- was built in round 3 and measured 1 %
+// SLOWER on the step in both forms tried, all layers at the end of the backward and one launch per stage: the per-layer launch
+// right behind its GEMM finds the slab in the Infinity Cache, the merged one re-reads up to 0.2 GB from HBM in front of the join)
+int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st) {
   if (lo_wgrad3_nsplit(g) > 0) {
     int nsplit = 0;
     const int total = geom_packed_elems(g);
@@ -1403,7 +1393,6 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
       int r = lo_wgrad3_run(g, x, dy, slab, st, &nsplit);
       if (r != LO_OK) return r;
     }
-    if (defer_reduce) return LO_OK;
     LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);
     hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
     LO_LAUNCH_CHECK("wgrad_reduce");
@@ -1442,7 +1431,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
 #undef LO_WG
   }
   LO_LAUNCH_CHECK("wgrad_tn");
-  if (a.direct || defer_reduce) return LO_OK;
+  if (a.direct) return LO_OK;
   int total = a.packed_elems;
   LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (a.nsplit + 1), st);
   hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);

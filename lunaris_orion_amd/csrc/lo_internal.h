@@ -19,6 +19,7 @@ struct LoGnBwdFuse {
   bool keep_out = false;    // with dv: store the activation gradient too (somebody else reads it: the decoder's skip gradients)
 };
 bool lo_conv_gnb_apply_tiles(const LoGeom& gd, int* mts, int* nt);
+int lo_conv_splitk_plan(const LoGeom& g);     // K splits for the few-rows convolutions (128 x 128 split-K tiles + a fused slab pass), 0 = no
 // teacher epilogue: LeakyReLU(0.2), per-channel BN partial sums; out_pitch > 0: the output tensor has out_pitch channels per pixel
 // and this op writes its Cout channels starting at channel out_choff (writing straight into a concatenated tensor)
 struct LoConvExtra { int act; float* bn_partial; int out_pitch = 0; int out_choff = 0; };
@@ -61,12 +62,7 @@ int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* ou
 int lo_wgrad_nsplit(const LoGeom& g);
 int lo_wgrad3_nsplit(const LoGeom& g);   // multi-tap 3x3 stride-1 weight-gradient kernel: pixel splits, 0 = does not apply
 int lo_wgrad3_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, hipStream_t st, int* nsplit_out);
-int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st, bool defer_reduce = false);
-// the slab reductions of several layers in one launch (job table in device memory)
-struct LoWgradRedJob { const float* slab; size_t grad_off; int total, nsplit, block0, pad_; LoGeom g; };
-int lo_wgrad_slab_splits(const LoGeom& g);      // splits lo_wgrad_run writes for g; 0 = direct (no slab)
-int lo_wgrad_reduce_blocks(const LoGeom& g);
-int lo_wgrad_reduce_all(const LoWgradRedJob* jobs_dev, int njobs, int nblocks, int block_base, float* G, float scale, hipStream_t st);
+int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st);
 size_t lo_wgrad_slab_bytes(const LoGeom& g);
 size_t lo_packed_weight_elems(const LoGeom& g);
 
@@ -85,6 +81,17 @@ struct LoGnFinJobs { LoGnFinJob j[LO_GN_FIN_MAX]; int n; };
 int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta,
                       f16* ds, f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st, int np1 = 0);
 int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st);
+// Split-K convolution outputs (fp32 slabs [nsplit][B*HW][C]) consumed by ONE (sample, group)-local pass each:
+//   forward:  v = fp16(bias + sum of the slabs), GroupNorm statistics of the group, y = GroupNorm + Mish (lo_gn_fwd's modes)
+//   backward: dy = fp16(sum of the slabs + add_src), then the one-pass GroupNorm backward of lo_gn_bwd_local (plain mode)
+int lo_splitk_gn_fwd(const float* slab, int nsplit, const float* bias, const float* gamma, const float* beta, const f16* other, f16* v,
+                     f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st);
+int lo_splitk_gn_bwd(const float* slab, int nsplit, const f16* add_src, const f16* v, const float* stats, const float* gamma,
+                     const float* beta, f16* dy_out, f16* dv, float* P1, float* P2, int B, int HW, int C, hipStream_t st);
+// reduce + apply in one pass where a (sample, group) fits a workgroup; ONE row of P1 / P2 per sample
+bool lo_gn_bwd_local_applies(int HW, int C);
+int lo_gn_bwd_local(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta, f16* ds,
+                    f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st);
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st);
 int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st, uint8_t* dst8 = nullptr);
 int lo_nhwc_f16_to_nchw_f32(const f16* src, float* dst, int B, int HW, int C, float scale, hipStream_t st);   // module-boundary forms

@@ -328,6 +328,141 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// (sample, group)-LOCAL backward: where one GroupNorm group of one sample fits a workgroup (HW * C/8 <= 8192 elements: the
+// 16 x 16 x 256 and 8 x 8 x 512 layers), reduce and apply are ONE pass -- dy, v (and the identity of a ResBlock tail) are read once
+// and kept in registers between the two phases, the group sums never leave the workgroup.  Replaces lo_gn_bwd_reduce +
+// lo_gn_bwd_apply (two launches, two reads of every operand) for the layers whose reduction is not already fused into a
+// data-gradient epilogue: the ResBlock tails of encoder stages 3 and 4.  One P1 / P2 row per sample.
+//   grid (8 groups, B); thread = (8-channel chunk of the group, row slot); E = rows per thread <= 4.
+// ---------------------------------------------------------------------------------------------
+// SLAB: the activation gradient is not a tensor yet but the K-split partial sums of the data-gradient convolution that produces it
+// (fp32 slabs [nsplit][B*HW][C]) plus an optional residual gradient: summed here, rounded to fp16 (what the tensor would have held)
+// and, when somebody else reads it too (dy_out), stored.
+struct GnSlabSrc { const float* slab; int nsplit; const f16* add_src; f16* dy_out; size_t split_stride; };
+template <bool RES, int E, bool SLAB = false>
+__global__ __launch_bounds__(256) void lo_gn_bwd_local_kernel(GnBwdArgs a, GnSlabSrc ss) {
+  const int a_mode = RES ? GN_MODE_RES : GN_MODE_PLAIN;
+  __shared__ float s_red[256 * 16];
+  __shared__ float s_g[64 * 2];
+  __shared__ float s_c[2];
+  const int tid = threadIdx.x, grp = blockIdx.x, n = blockIdx.y;
+  const int C = a.C, G = C >> 3, CG = G >> 3;             // CG = 16-byte chunks per pixel row inside the group
+  const int cc = tid % CG, slot = tid / CG, nslot = 256 / CG;
+  const int c0 = grp * G + cc * 8;
+  const float mean = a.stats[n * 16 + grp * 2], rstd = a.stats[n * 16 + grp * 2 + 1];
+  const float nmr = -mean * rstd;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float gm = a.gamma[c0 + j];
+    sc[j] = gm * rstd;
+    sh[j] = __builtin_fmaf(nmr, gm, a.beta[c0 + j]);
+  }
+  const size_t base = (size_t)n * a.HW * C + c0;
+  lo_f2 du[E][4], xh[E][4];
+  f16x8 h[E], d[E], o[RES ? E : 1];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = slot + e * nslot;
+    if (r < a.HW) {
+      const size_t off = base + (size_t)r * C;
+      h[e] = *reinterpret_cast<const f16x8*>(a.v + off);
+      if constexpr (SLAB) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < ss.nsplit; ++sp) {
+          s0 += *reinterpret_cast<const f32x4*>(ss.slab + (size_t)sp * ss.split_stride + off);
+          s1 += *reinterpret_cast<const f32x4*>(ss.slab + (size_t)sp * ss.split_stride + off + 4);
+        }
+        f16x8 dd = {(f16)s0[0], (f16)s0[1], (f16)s0[2], (f16)s0[3], (f16)s1[0], (f16)s1[1], (f16)s1[2], (f16)s1[3]};
+        if (ss.add_src) {
+          const f16x8 rr = *reinterpret_cast<const f16x8*>(ss.add_src + off);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dd[j] = (f16)((float)dd[j] + (float)rr[j]);
+        }
+        if (ss.dy_out) *reinterpret_cast<f16x8*>(ss.dy_out + off) = dd;
+        d[e] = dd;
+      } else {
+        d[e] = *reinterpret_cast<const f16x8*>(a.dy + off);
+      }
+      if constexpr (RES) o[e] = *reinterpret_cast<const f16x8*>(a.other + off);
+    }
+  }
+  lo_f2 a1[4], a2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a1[j] = (lo_f2){0.f, 0.f}; a2[j] = (lo_f2){0.f, 0.f}; }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = slot + e * nslot;
+    if (r < a.HW) {
+      f16x8 dso;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        lo_f2 dsv;
+        lo_f2 ov = {0.f, 0.f};
+        if constexpr (RES) ov = (lo_f2){(float)o[e][j], (float)o[e][j + 1]};
+        gn_du2(a_mode, (lo_f2){(float)h[e][j], (float)h[e][j + 1]}, (lo_f2){(float)d[e][j], (float)d[e][j + 1]}, ov, (lo_f2){sc[j], sc[j + 1]},
+               (lo_f2){sh[j], sh[j + 1]}, (lo_f2){rstd, rstd}, (lo_f2){nmr, nmr}, du[e][j >> 1], xh[e][j >> 1], dsv);
+        a1[j >> 1] += du[e][j >> 1];
+        a2[j >> 1] += du[e][j >> 1] * xh[e][j >> 1];
+        dso[j] = (f16)dsv[0];
+        dso[j + 1] = (f16)dsv[1];
+      }
+      if (RES) *reinterpret_cast<f16x8*>(a.ds + base + (size_t)r * C) = dso;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { du[e][j] = (lo_f2){0.f, 0.f}; xh[e][j] = (lo_f2){0.f, 0.f}; }
+    }
+  }
+  // per-channel sums over the row slots (fixed order) -> P1 row of this sample; gamma-weighted group sums
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s_red[tid * 16 + j * 2] = a1[j >> 1][j & 1]; s_red[tid * 16 + j * 2 + 1] = a2[j >> 1][j & 1]; }
+  __syncthreads();
+  for (int q = tid; q < G * 2; q += 256) {
+    const int c = q >> 1, w = q & 1, ccx = c >> 3, j = c & 7;
+    float tot = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) tot += s_red[(sl * CG + ccx) * 16 + j * 2 + w];
+    a.P1[((size_t)n * C + grp * G + c) * 2 + w] = tot;
+    s_g[c * 2 + w] = a.gamma[grp * G + c] * tot;
+  }
+  __syncthreads();
+  if (tid < 2) {
+    float tot = 0.f;
+    for (int c = 0; c < G; ++c) tot += s_g[c * 2 + tid];
+    s_c[tid] = tot / ((float)a.HW * (float)G);
+  }
+  __syncthreads();
+  const float kb = rstd * s_c[0], kc = rstd * s_c[1];
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = slot + e * nslot;
+    if (r < a.HW) {
+      f16x8 out;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const lo_f2 dv = lo_gn_dv2(du[e][j >> 1], xh[e][j >> 1], (lo_f2){sc[j], sc[j + 1]}, kb, kc);
+        const f16 d0 = (f16)dv[0], d1 = (f16)dv[1];
+        out[j] = d0; out[j + 1] = d1;
+        acc[j] += (float)d0; acc[j + 1] += (float)d1;
+      }
+      *reinterpret_cast<f16x8*>(a.dv + base + (size_t)r * C) = out;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = tid; c < G; c += 256) {
+    const int ccx = c >> 3, j = c & 7;
+    float tot = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) tot += s_red[(sl * CG + ccx) * 8 + j];
+    a.P2[(size_t)n * C + grp * G + c] = tot;
+  }
+}
+
 // dgamma, dbeta, dbias from the partials (fixed summation order): block = 16 channels x 16 row-lanes
 __global__ __launch_bounds__(256) void lo_gn_param_finalize_kernel(const float* __restrict__ P1, const float* __restrict__ P2,
                                                                    float* dgamma, float* dbeta, float* dbias, int nblk, int C,
@@ -483,6 +618,128 @@ int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float
     }
   }
   LO_LAUNCH_CHECK("gn_bwd_apply");
+  return LO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward counterpart for split-K convolutions: one workgroup per (sample, group) sums the K-split slabs of its 8-channel chunks,
+// adds the bias, rounds to fp16 (v, stored: the backward needs it), takes the group's mean / rstd over those fp16 values (fixed-order
+// sums, double at the end like lo_gn_group_stats) and applies GroupNorm + Mish (lo_gn_apply8: the modes of lo_gn_fwd).
+// ---------------------------------------------------------------------------------------------
+struct SplitkGnFwdArgs {
+  const float* slab; int nsplit; size_t split_stride;
+  const float* bias; const float* gamma; const float* beta; const f16* other;
+  f16* v; f16* y; float* stats;
+  int HW, C, mode;
+};
+template <int E>
+__global__ __launch_bounds__(256) void lo_splitk_gn_fwd_kernel(SplitkGnFwdArgs a) {
+  __shared__ float s_red[256 * 2];
+  __shared__ float s_stat[2];
+  const int tid = threadIdx.x, grp = blockIdx.x, n = blockIdx.y;
+  const int C = a.C, G = C >> 3, CG = G >> 3;
+  const int cc = tid % CG, slot = tid / CG, nslot = 256 / CG;
+  const int c0 = grp * G + cc * 8;
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + c0), b1 = *reinterpret_cast<const f32x4*>(a.bias + c0 + 4);
+  const size_t base = (size_t)n * a.HW * C + c0;
+  f16x8 h[E];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = slot + e * nslot;
+    if (r < a.HW) {
+      const size_t off = base + (size_t)r * C;
+      f32x4 s0 = b0, s1 = b1;
+      for (int sp = 0; sp < a.nsplit; ++sp) {
+        s0 += *reinterpret_cast<const f32x4*>(a.slab + (size_t)sp * a.split_stride + off);
+        s1 += *reinterpret_cast<const f32x4*>(a.slab + (size_t)sp * a.split_stride + off + 4);
+      }
+      h[e] = (f16x8){(f16)s0[0], (f16)s0[1], (f16)s0[2], (f16)s0[3], (f16)s1[0], (f16)s1[1], (f16)s1[2], (f16)s1[3]};
+      *reinterpret_cast<f16x8*>(a.v + off) = h[e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float x = (float)h[e][j]; s += x; q += x * x; }
+    }
+  }
+  s_red[tid * 2] = s; s_red[tid * 2 + 1] = q;
+  __syncthreads();
+  if (tid < 2) {
+    double tot = 0.0;
+    for (int t = 0; t < 256; ++t) tot += (double)s_red[t * 2 + tid];
+    s_stat[tid] = (float)tot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double inv_m = 1.0 / ((double)a.HW * (double)G);
+    const double mean = (double)s_stat[0] * inv_m;
+    double var = (double)s_stat[1] * inv_m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)1e-5f));
+    s_stat[0] = mf; s_stat[1] = rf;
+    a.stats[n * 16 + grp * 2] = mf; a.stats[n * 16 + grp * 2 + 1] = rf;
+  }
+  __syncthreads();
+  const float mean = s_stat[0], rstd = s_stat[1];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lo_gn_scale_shift(a.gamma[c0 + j], a.beta[c0 + j], mean, rstd, sc[j], sh[j]);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = slot + e * nslot;
+    if (r < a.HW) {
+      const size_t off = base + (size_t)r * C;
+      f16x8 o = h[e];
+      if (a.mode != 0) o = *reinterpret_cast<const f16x8*>(a.other + off);
+      *reinterpret_cast<f16x8*>(a.y + off) = lo_gn_apply8(h[e], sc, sh, a.mode, o);
+    }
+  }
+}
+int lo_splitk_gn_fwd(const float* slab, int nsplit, const float* bias, const float* gamma, const float* beta, const f16* other, f16* v,
+                     f16* y, float* stats, int B, int HW, int C, int mode, hipStream_t st) {
+  LO_REQUIRE(lo_gn_bwd_local_applies(HW, C) && slab && bias && v && y && stats && nsplit >= 1 && (mode == 0 || other),
+             "lo_splitk_gn_fwd: bad arguments (HW=%d, C=%d)", HW, C);
+  SplitkGnFwdArgs a{slab, nsplit, (size_t)B * HW * C, bias, gamma, beta, other, v, y, stats, HW, C, mode};
+  const int E = HW / (256 / ((C >> 3) >> 3));
+  LoProfScope _p(gn_layer_name("lo_splitk_gn_fwd", C, HW, mode), 0, (double)B * HW * C * (4.0 * nsplit + 4.0 + (mode ? 2.0 : 0.0)), st);
+  const dim3 grid(8, B);
+  if (E <= 1) hipLaunchKernelGGL((lo_splitk_gn_fwd_kernel<1>), grid, dim3(256), 0, st, a);
+  else if (E == 2) hipLaunchKernelGGL((lo_splitk_gn_fwd_kernel<2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((lo_splitk_gn_fwd_kernel<4>), grid, dim3(256), 0, st, a);
+  LO_LAUNCH_CHECK("splitk_gn_fwd");
+  return LO_OK;
+}
+int lo_splitk_gn_bwd(const float* slab, int nsplit, const f16* add_src, const f16* v, const float* stats, const float* gamma,
+                     const float* beta, f16* dy_out, f16* dv, float* P1, float* P2, int B, int HW, int C, hipStream_t st) {
+  LO_REQUIRE(lo_gn_bwd_local_applies(HW, C) && slab && v && stats && dv && P1 && P2 && nsplit >= 1, "lo_splitk_gn_bwd: bad arguments (HW=%d, C=%d)", HW, C);
+  GnBwdArgs a{nullptr, v, nullptr, stats, gamma, beta, nullptr, dv, P1, P2, HW, C, 1, GN_MODE_PLAIN, 1};
+  const GnSlabSrc ss{slab, nsplit, add_src, dy_out, (size_t)B * HW * C};
+  const int E = HW / (256 / ((C >> 3) >> 3));
+  LoProfScope _p(gn_layer_name("lo_splitk_gn_bwd", C, HW, 0), 0, (double)B * HW * C * (4.0 * nsplit + 4.0 + (add_src ? 2.0 : 0.0)), st);
+  const dim3 grid(8, B);
+  if (E <= 1) hipLaunchKernelGGL((lo_gn_bwd_local_kernel<false, 1, true>), grid, dim3(256), 0, st, a, ss);
+  else if (E == 2) hipLaunchKernelGGL((lo_gn_bwd_local_kernel<false, 2, true>), grid, dim3(256), 0, st, a, ss);
+  else hipLaunchKernelGGL((lo_gn_bwd_local_kernel<false, 4, true>), grid, dim3(256), 0, st, a, ss);
+  LO_LAUNCH_CHECK("splitk_gn_bwd");
+  return LO_OK;
+}
+
+// the one-pass (sample, group)-local form: P1 / P2 get ONE row per sample
+bool lo_gn_bwd_local_applies(int HW, int C) {
+  const int G = C >> 3;
+  return C % 64 == 0 && G <= 64 && (long)HW * G <= 8192 && HW % (256 / (G >> 3)) == 0 && HW / (256 / (G >> 3)) <= 4;
+}
+int lo_gn_bwd_local(const f16* dy, const f16* v, const f16* other, const float* stats, const float* gamma, const float* beta, f16* ds,
+                    f16* dv, float* P1, float* P2, int B, int HW, int C, int mode, hipStream_t st) {
+  LO_REQUIRE(lo_gn_bwd_local_applies(HW, C), "lo_gn_bwd_local: HW=%d, C=%d does not fit one workgroup per (sample, group)", HW, C);
+  GnBwdArgs a{dy, v, other, stats, gamma, beta, ds, dv, P1, P2, HW, C, 1, mode, 1};
+  const int E = HW / (256 / ((C >> 3) >> 3));
+  LoProfScope _p(gn_layer_name("lo_gn_bwd_local", C, HW, mode), 0, 2.0 * B * HW * C * (mode == 2 ? 5 : 3), st);
+  const dim3 grid(8, B);
+  const GnSlabSrc ss{nullptr, 0, nullptr, nullptr, 0};
+#define LO_GNL(RES_, E_) hipLaunchKernelGGL((lo_gn_bwd_local_kernel<RES_, E_>), grid, dim3(256), 0, st, a, ss)
+  if (mode == GN_MODE_RES) { if (E <= 1) LO_GNL(true, 1); else if (E == 2) LO_GNL(true, 2); else LO_GNL(true, 4); }
+  else { if (E <= 1) LO_GNL(false, 1); else if (E == 2) LO_GNL(false, 2); else LO_GNL(false, 4); }
+#undef LO_GNL
+  LO_LAUNCH_CHECK("gn_bwd_local");
   return LO_OK;
 }
 

@@ -1,8 +1,9 @@
-"""GroupNorm + Mish inside the producing convolution's epilogue (csrc/lo_common.h: LoGnFuse -- the workgroups that hold one sample's
-tiles exchange their partial sums and wait for each other) against the separate lo_gn_fwd pass it replaces (LO_GN_FUSE=0): same
-statistics, same arithmetic, so every output, every saved activation and every gradient of a training step must agree BIT FOR BIT, at
-the oracle's batch size and at BASELINE's batch 64 (where the grids are longer than the chip and workgroups of different samples
-interleave); the bounded wait never runs out; golden parity of the fused default is what every other GPU test runs."""
+"""GroupNorm inside the convolution epilogues through a per-sample rendezvous (csrc/lo_common.h: LoGnFuse; lo_internal.h:
+LoGnBwdFuse::dv -- the workgroups that hold one sample's tiles exchange their partial sums and wait for each other) against the
+separate passes: the forward form (LO_GN_FUSE=1, opt-in) against lo_gn_fwd, the backward apply (default) against lo_gn_bwd_apply.
+Same statistics, same arithmetic, so every output, every saved activation and every gradient of a training step must agree BIT FOR
+BIT, at the oracle's batch size and at BASELINE's batch 64 (where the grids are longer than the chip and workgroups of different
+samples interleave); the bounded wait never runs out."""
 import os
 import subprocess
 import sys
@@ -64,7 +65,7 @@ def _run(tmp_path, tag, B, L, env_extra):
 
 @pytest.mark.parametrize("B,L", [(2, 256), (5, 256), (64, 512)])
 def test_fused_groupnorm_epilogue_equals_the_separate_pass_bit_for_bit(tmp_path, B, L):
-    fused = _run(tmp_path, "fused", B, L, {"LO_GNB_APPLY_FUSE": "0"})
+    fused = _run(tmp_path, "fused", B, L, {"LO_GN_FUSE": "1", "LO_GNB_APPLY_FUSE": "0"})      # opt-in: 2 % slower on the step
     plain = _run(tmp_path, "plain", B, L, {"LO_GN_FUSE": "0", "LO_GNB_APPLY_FUSE": "0"})
     assert int(plain["fused_layers"]) == 0 and int(fused["fused_layers"]) >= 8, (int(fused["fused_layers"]), int(plain["fused_layers"]))
     assert int(fused["sync_fail"].item()) == 0
