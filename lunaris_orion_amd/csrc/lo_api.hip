@@ -535,6 +535,9 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
     // have workgroups ready, the dispatcher serves the chain first and the side work fills what it leaves (LO_SIDE_PRIO=0: default
     // priority, the round-1 behaviour).  Timeline before (tools/timeline.py): the first GroupNorm pass of a step took 302 us instead of
     // 17 beside the side stream's AdamW, data-gradient launches 55-65 us instead of 36-44 beside the weight gradients.
+    // (A CU-masked side stream -- hipExtStreamCreateWithCUMask with 64 / 128 / 192 / all 256 bits set -- was tried in round 3 to
+    // fence the side work off: 10 300-12 700 sprites/s against 22 300 with ANY mask, the full one included, so the masked queue
+    // itself is the cost on this stack; what does help is fewer, longer side workgroups: see lo_wgrad3_nsplit / lo_wgrad2_nsplit.)
     int prio_least = 0, prio_greatest = 0;
     bool ok;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest)

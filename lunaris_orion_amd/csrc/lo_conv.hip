@@ -1357,9 +1357,17 @@ static inline int wgrad_bnw(const LoGeom& g) { return g.Cin % 128 == 0 ? 128 : 6
 
 static inline int wgrad_bkp(const LoGeom& g) { return ((long)g.B * g.GH * g.GW) % 64 == 0 && (long)g.B * g.GH * g.GW >= 1024 ? 64 : 32; }
 
+// LO_WGRAD_S2=0: the stride-2 layers' weight gradients through the per-tap kernel lo_wgrad_tn (the round-2 path; A/B)
+static bool lo_wgrad_s2_enabled() {
+  static const bool on = [] { const char* e = getenv("LO_WGRAD_S2"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
 // number of pixel splits the wgrad launcher will use for this geometry (callers size the slab with it)
 int lo_wgrad_nsplit(const LoGeom& g) {
   if (int n3 = lo_wgrad3_nsplit(g)) return n3;   // multi-tap kernel (3x3 stride 1)
+  if (lo_wgrad_s2_enabled())
+    if (int n2 = lo_wgrad2_nsplit(g)) return n2; // multi-tap kernel of the stride-2 layers (k3 s2, transposed k4 s2)
   int bmw = wgrad_bmw(g), bnw = wgrad_bnw(g), bkp = wgrad_bkp(g);
   int taps = 0;
   for (int p = 0; p < g.n_phase; ++p) taps += g.T[p];
@@ -1391,6 +1399,19 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
     {
       LoProfScope _p(lo_prof_geom_name("lo_wgrad3x3_mt", g), geom_flops(g), geom_bytes(g), st);
       int r = lo_wgrad3_run(g, x, dy, slab, st, &nsplit);
+      if (r != LO_OK) return r;
+    }
+    LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);
+    hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
+    LO_LAUNCH_CHECK("wgrad_reduce");
+    return LO_OK;
+  }
+  if (lo_wgrad_s2_enabled() && lo_wgrad2_nsplit(g) > 0) {
+    int nsplit = 0;
+    const int total = geom_packed_elems(g);
+    {
+      LoProfScope _p(lo_prof_geom_name("lo_wgrad_s2_mt", g), geom_flops(g), geom_bytes(g), st);
+      int r = lo_wgrad2_run(g, x, dy, slab, st, &nsplit);
       if (r != LO_OK) return r;
     }
     LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);

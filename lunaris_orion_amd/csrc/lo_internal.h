@@ -62,6 +62,8 @@ int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* ou
 int lo_wgrad_nsplit(const LoGeom& g);
 int lo_wgrad3_nsplit(const LoGeom& g);   // multi-tap 3x3 stride-1 weight-gradient kernel: pixel splits, 0 = does not apply
 int lo_wgrad3_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, hipStream_t st, int* nsplit_out);
+int lo_wgrad2_nsplit(const LoGeom& g);   // multi-tap weight-gradient kernel of the stride-2 layers: position splits, 0 = does not apply
+int lo_wgrad2_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, hipStream_t st, int* nsplit_out);
 int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, float* grad, float scale, hipStream_t st);
 size_t lo_wgrad_slab_bytes(const LoGeom& g);
 size_t lo_packed_weight_elems(const LoGeom& g);

@@ -303,11 +303,15 @@ int lo_wgrad3_nsplit(const LoGeom& g) {
   if (!wgrad3_applies(g)) return 0;
   const long tiles = (long)(g.Cout / 64) * (g.Cin / 64);
   const long nchunks = (long)g.B * g.Hin * g.Win / 32;
-  constexpr int target = 512;      // 256 / 512 / 768 swept in round 2: inside +-0.5 %
+  // Workgroups per launch: these kernels run on the side stream BESIDE the dependent chain, and every CU one of their 512-thread
+  // workgroups holds is lost to the chain.  Round 3 on the step (sprites/s, interleaved on one box): target 512 / floor 256
+  // 22 154-22 259, 256 / 128 22 463-22 481, 128 / 128 22 516-22 591, 128 / 64 22 601-22 633 -- fewer, longer workgroups (and
+  // less slab traffic) win although the launch alone takes longer
+  constexpr int target = 128, flo = 64;
   long want = (target + tiles - 1) / tiles;
   const long slab_bytes = (long)g.Cout * 9 * g.Cin * 4;
   long cap = (24L << 20) / slab_bytes;                    // slab traffic (written here, re-read by the reduce pass)
-  const long floor_wgs = (256 + tiles - 1) / tiles;        // but at least one workgroup per CU
+  const long floor_wgs = (flo + tiles - 1) / tiles;        // but not below this many workgroups
   if (cap < floor_wgs) cap = floor_wgs;
   if (want > cap) want = cap;
   if (want > nchunks / 4) want = nchunks / 4 > 0 ? nchunks / 4 : 1;   // at least 4 chunks per split

@@ -100,6 +100,11 @@ WGRAD_CASES = [
     (KIND_T4, 2, 512, 256, 8),
     (KIND_T4, 2, 64, 32, 64),
     (KIND_T4, 2, 128, 64, 32),
+    (KIND_S2, 3, 128, 256, 32),          # stride-2 multi-tap kernel: odd batch (uneven chunk splits)
+    (KIND_S2, 1, 64, 128, 16),           # ... a single 8x8 coarse map (two chunks)
+    (KIND_T4, 3, 256, 128, 16),
+    (KIND_T4, 1, 64, 32, 8),             # ... 32 output channels: half of the F tile is padding
+    (KIND_T4, 5, 64, 64, 8),
 ]
 
 
