@@ -257,7 +257,7 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (tools/rocpd_extract.py traffic); null when absent
         roof["traffic"] = None
         try:
-            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r02_traffic.json", "r01_traffic.json")) if os.path.exists(pp))
+            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(pp))
             tr = json.load(open(tpath))["kernels"]
             roof["traffic_source"] = f"profiles/{os.path.basename(tpath)} (committed rocprofv3 PMC passes of this workload; not re-measured in this run)"
             key = next((k for k in tr if k in dom_name or dom_name.split("<")[0] in k), None)
@@ -271,7 +271,7 @@ def main():
         roof["launches_per_step"] = d_n / max(args.prof_steps, 1)
         roof["avg_launch_ms"] = d_ms / max(d_n, 1)
         roof["share_of_kernel_time"] = d_ms / total_ms
-        mfma = {k: r for k, r in rows.items() if r[2] > 0 and ("igemm" in k or "wgrad_tn" in k)}
+        mfma = {k: r for k, r in rows.items() if r[2] > 0 and any(t in k for t in ("igemm", "wgrad", "conv3x3_pp", "convt4"))}
         mf_ms = sum(r[0] for r in mfma.values())
         mf_fl = sum(r[2] for r in mfma.values())
         roof["all_mfma_kernels_tflops"] = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else None

@@ -249,11 +249,11 @@ int lo_wgrad2_nsplit(const LoGeom& g) {
   const int Ca = s2 ? g.Cout : g.Cin, Cf = s2 ? g.Cin : g.Cout;
   const long tiles = (long)(Ca / 64) * ((Cf + 63) / 64);
   const long nchunks = (long)g.B * Hc * Wc / 32;
-  // workgroups per launch: as in lo_wgrad3_nsplit, few and long.  With 512 / 256 this kernel LOST 1 % on the step against the
-  // per-tap kernel it replaces (21 014-21 067 against 21 215-21 251) although alone it is faster (0.243 ms against 0.304 ms for
-  // the seven layers): a multi-tap tile has 9 / 16 times fewer tiles per layer, so filling 256 CUs took up to 32 position splits
-  // and 64 MB of slab per layer.  128 / 128: 22 262-22 317 against 21 955-22 019 for the per-tap kernel on the same box (+1.3 %)
-  constexpr int tgt = 128, flo = 128, capmb = 24;
+  // workgroups per launch: as in lo_wgrad3_nsplit (same table), few and long.  With the per-tap kernel's policy (>= 256 workgroups)
+  // this kernel LOST 1 % on the step against the kernel it replaces (21 014-21 067 against 21 215-21 251) although alone it is
+  // faster: a multi-tap tile has 9 / 16 times fewer tiles per layer, so filling 256 CUs took up to 32 position splits and 64 MB of
+  // slab per layer.  With a floor of 128: 22 262-22 317 against 21 955-22 019 for the per-tap kernel on the same box (+1.3 %)
+  constexpr int tgt = 256, flo = 128, capmb = 24;
   long want = (tgt + tiles - 1) / tiles;
   long packed = 0;
   for (int p = 0; p < g.n_phase; ++p) packed += (long)g.Cout * g.T[p] * g.Cin;

@@ -304,10 +304,13 @@ int lo_wgrad3_nsplit(const LoGeom& g) {
   const long tiles = (long)(g.Cout / 64) * (g.Cin / 64);
   const long nchunks = (long)g.B * g.Hin * g.Win / 32;
   // Workgroups per launch: these kernels run on the side stream BESIDE the dependent chain, and every CU one of their 512-thread
-  // workgroups holds is lost to the chain.  Round 3 on the step (sprites/s, interleaved on one box): target 512 / floor 256
-  // 22 154-22 259, 256 / 128 22 463-22 481, 128 / 128 22 516-22 591, 128 / 64 22 601-22 633 -- fewer, longer workgroups (and
-  // less slab traffic) win although the launch alone takes longer
-  constexpr int target = 128, flo = 64;
+  // workgroups holds is lost to the chain.  Round 3, sprites/s on the step (interleaved on one box) | serial time of the 8 launches:
+  //   target 256 / floor 256 (one workgroup per CU at least)   21 854-21 994 | 0.240 ms
+  //   192 / 192                                                22 375-22 499 | 0.269 ms
+  //   256 / 128                                                22 513-22 706 | 0.303 ms   <- shipped
+  //   128 / 64                                                 22 544-22 747 | 0.340 ms
+  // fewer, longer workgroups (and less slab traffic) win on the step although the launch alone takes longer
+  constexpr int target = 256, flo = 128;
   long want = (target + tiles - 1) / tiles;
   const long slab_bytes = (long)g.Cout * 9 * g.Cin * 4;
   long cap = (24L << 20) / slab_bytes;                    // slab traffic (written here, re-read by the reduce pass)
