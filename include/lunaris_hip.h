@@ -206,6 +206,10 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
  * 32-bit word of the workspace that a workgroup sets to 1 if its wait ran out (results of that step are then invalid); the host
  * reads it with the step's metrics.  No reference counterpart (aten::native_group_norm is a separate op there). */
 int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* fused_layers);
+/* fp8 operand mode (LO_VAE_FP8_FWD, train_hybrid.py --mfma_precision fp8; BASELINE.json configs[4]): how many of the plan's 16
+ * forward conv layers actually run on e4m3 operands.  The count depends on the batch: layers a fused-tap or patch-resident fp16
+ * kernel owns at this batch size stay fp16 (11 at batch 2, 6 at batch 64).  0 when the mode is off. */
+int lo_vae_fp8_layers(const LoVae* h, int* layers);
 /* where lo_vae_forward left an intermediate tensor inside the workspace (fp16 NHWC; dims4 = B, H, W, C), for parity tests
  * against the reference's hooked module outputs (lunar_generate.py:94-120, 168-190): which 0 = raw encoder conv output
  * (stage s, k = 0 strided conv, 1 / 2 ResBlock convs), 1 = raw decoder transposed-conv output, 2 = encoder stage (ResBlock)

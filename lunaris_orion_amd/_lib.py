@@ -102,6 +102,7 @@ SIGNATURES = {
     "lo_dp_unpack_f16": (i32, [vp, f32p, sz, flt, vp]),
     "lo_dp_sum_shares": (i32, [vp, vp, i32, sz, i32, vp]),
     "lo_vae_sync_fail_word": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "lo_vae_fp8_layers": (i32, [vp, C.POINTER(C.c_int)]),
     "lo_vae_stage4_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 

@@ -608,6 +608,14 @@ extern "C" int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* f
   return LO_OK;
 }
 
+extern "C" int lo_vae_fp8_layers(const LoVae* h, int* layers) {
+  LO_REQUIRE(h && layers, "lo_vae_fp8_layers: null argument");
+  int n = 0;
+  for (int s = 0; s < 4; ++s) { for (int k = 0; k < 3; ++k) n += h->enc[s][k].f8 ? 1 : 0; n += h->dec[s].f8 ? 1 : 0; }
+  *layers = n;
+  return LO_OK;
+}
+
 #define WSP(T, off) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (off))
 #define PRM(i) (P + h->p_off[(i)])
 #define GRD(i) (G + h->p_off[(i)])
@@ -1123,7 +1131,10 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       gb.P1 = WSP(float, prod->o_P1);
       prod->np1 = lo_conv_gnb_rows(c.gd);
       int mts = 0, nt = 0;
-      if (h->fuse_gna && lo_conv_gnb_apply_tiles(c.gd, &mts, &nt) && mts == prod->np1) {
+      // ... only where the whole grid is resident at once (one workgroup per CU): on the 64-channel 64 x 64 layers (1 024 tiles at
+      // batch 64, two rounds of 512) the fused launch is 32-34 us longer than the 27 us pass it replaces, and the step is 0.6 %
+      // faster without it there (22 309-22 332 against 22 185-22 202; nowhere: 22 238-22 316)
+      if (h->fuse_gna && lo_conv_gnb_apply_tiles(c.gd, &mts, &nt) && mts == prod->np1 && h->B * mts * nt <= 256) {
         gb.dv = WSP(f16, prod->o_dv); gb.P2 = WSP(float, prod->o_P2);
         gb.counter = WSP(unsigned int, prod->o_bcnt);
         gb.target = (++prod->gba_epoch) * (unsigned)mts;

@@ -262,6 +262,9 @@ class _Engine:
         _lib.check(_lib.lib.lo_vae_sync_fail_word(self.handle, C.byref(off), C.byref(nf)), "lo_vae_sync_fail_word")
         self.fused_gn_layers = nf.value
         self.sync_fail = self.ws[off.value:off.value + 4].view(torch.int32)     # set by a fused-GroupNorm workgroup whose wait ran out
+        n8 = C.c_int()
+        _lib.check(_lib.lib.lo_vae_fp8_layers(self.handle, C.byref(n8)), "lo_vae_fp8_layers")
+        self.fp8_layers = n8.value      # forward conv layers on e4m3 operands at THIS batch size (0 unless mfma_precision="fp8")
 
     def __del__(self):
         try:
