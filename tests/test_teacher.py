@@ -55,7 +55,7 @@ def test_teacher_forward_matches_oracle_and_golden(training):
     # tolerances: fp16 activations through 24 full-resolution convs, then pooled to [B,128] vectors
     tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}
     for k, t in tol.items():
-        got = out[k].cpu()
+        got = out[k].detach().cpu()   # the outputs carry a graph since round 3 (like the reference module's)
         d = (got - ref[k]).abs().max().item()
         print(tag, k, d)
         assert d <= t, (k, d)
@@ -338,7 +338,7 @@ def test_teacher_dropout_forward_matches_reference_fixture_and_oracle():
         ref, new_stats = T.teacher_forward(x, S, training=True, masks=D.TeacherMasks(seed, p, B))
     tol = {"quality_scores": 2e-3, "expert_weights": 2e-3, "style_embedding": 2e-2, "prompt_embedding": 2e-2, "semantic_score": 2e-3}
     for k, t in tol.items():
-        got = out[k].cpu()
+        got = out[k].detach().cpu()   # the outputs carry a graph since round 3 (like the reference module's)
         d = (got - ref[k]).abs().max().item()
         print("dropout", k, d, "(masks move it by", float(g["nodrop_delta/" + k]), ")")
         assert d <= t, (k, d)
@@ -475,7 +475,7 @@ def test_wide_teacher_forward_matches_reference_fixture_and_oracle(F, B):
         with torch.no_grad():
             ref, new_stats = T.teacher_forward(x, S, training=training, masks=D.TeacherMasks(seed, p, B) if training else None)
         for k, t in tol.items():
-            got = out[k].cpu()
+            got = out[k].detach().cpu()   # the outputs carry a graph since round 3 (like the reference module's)
             d = (got - ref[k]).abs().max().item()
             print(f"F={F} {tag}", k, d)
             assert d <= t, (tag, k, d)
