@@ -370,3 +370,46 @@ print("ATTN_FP32_OK")
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, LO_ATTN_FP32="1"))
     assert "ATTN_FP32_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world,fp16_wire", [(2, True), (4, True), (8, True), (8, False), (3, True)])
+def test_direct_exchange_arithmetic_of_n_ranks_on_one_device(world, fp16_wire):
+    """The data-parallel exchange of lunaris_orion_amd/parallel.py (`mode="direct"`) for `world` ranks, with the two collectives
+    replaced by the copies they perform (all_to_all_single: recv_r[j] = body_j[chunk r]; all_gather_into_tensor: body[j] = share_j),
+    so the library kernels (lo_dp_pack_f16 / lo_dp_sum_shares / lo_dp_unpack_f16) see exactly the buffers an N-rank RCCL group
+    would hand them.  Result on every rank == the mean of the ranks' gradients: to fp32 rounding on the fp32 wire, to the fp16
+    wire's resolution (values * 1024 in fp16: 2^-11 relative per element, twice) on the fp16 wire."""
+    from lunaris_orion_amd import _lib
+    lib = L()
+    n = 1000 * world + 37 * world          # divisible by world (the remainder goes through a plain all-reduce in parallel.py)
+    g = torch.Generator().manual_seed(5)
+    grads = [(torch.randn(n, generator=g) * 10.0 ** torch.randint(-6, -2, (n,), generator=g).float()).cuda() for _ in range(world)]
+    ref = torch.stack([t.double() for t in grads]).mean(0)
+    st = _lib.stream_ptr()
+    chunk = n // world
+    if fp16_wire:
+        bodies = [torch.empty(n, dtype=torch.float16, device="cuda") for _ in range(world)]
+        for t, w in zip(grads, bodies):
+            _lib.check(lib.lib.lo_dp_pack_f16(t.data_ptr(), w.data_ptr(), n, 1024.0, st), "pack")
+    else:
+        bodies = [t.clone() for t in grads]
+    shares = []
+    for r in range(world):                                          # rank r's side of the all-to-all + its share sum
+        recv = torch.cat([bodies[j][r * chunk:(r + 1) * chunk] for j in range(world)])
+        share = torch.empty(chunk, dtype=recv.dtype, device="cuda")
+        _lib.check(lib.lib.lo_dp_sum_shares(recv.data_ptr(), share.data_ptr(), world, chunk, 1 if fp16_wire else 0, st), "sum")
+        shares.append(share)
+    gathered = torch.cat(shares)                                     # what all_gather_into_tensor leaves in every rank's body
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    if fp16_wire:
+        _lib.check(lib.lib.lo_dp_unpack_f16(gathered.data_ptr(), out.data_ptr(), n, 1.0 / 1024.0, st), "unpack")
+    else:
+        out.copy_(gathered)
+    sync()
+    err = (out.double().cpu() - ref.cpu()).abs()
+    scale = torch.stack([t.abs().double() for t in grads]).max(0).values.cpu()
+    if fp16_wire:
+        # fp16 normal range after the x1024 scale starts at 6e-8 / 1024: smaller elements lose relative precision, bound absolutely
+        assert (err <= 1.5e-3 * scale + 1e-10).all(), (err / (scale + 1e-30)).max().item()
+    else:
+        assert (err <= 1e-6 * scale + 1e-30).all(), (err / (scale + 1e-30)).max().item()
