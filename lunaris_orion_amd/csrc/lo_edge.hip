@@ -156,12 +156,37 @@ __global__ __launch_bounds__(256) void lo_first_conv_wgrad_mfma_kernel(const flo
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the global loads of row oy + 1 (this thread's share: two 16-byte pieces of the dv row, up to five input elements) are issued
+  // into registers before row oy is built and multiplied, and land in LDS at the top of the next iteration: the row loop was a
+  // chain of load -> barrier -> build -> barrier -> MFMA with the load latency exposed four times per workgroup
+  constexpr int XN = (3 * 3 * (FC_W + 2) + 255) / 256;
+  f16x8 pd[2];
+  float px[XN];
+  auto prefetch = [&](int oy) __attribute__((always_inline)) {
+    const f16* src = dv + (((size_t)n * 64 + oy) * 64) * FC_CO;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pd[j] = reinterpret_cast<const f16x8*>(src)[tid + 256 * j];
+#pragma unroll
+    for (int j = 0; j < XN; ++j) {
+      const int i = tid + 256 * j;
+      const int col = i % (FC_W + 2), r = (i / (FC_W + 2)) % 3, ci = i / (3 * (FC_W + 2));
+      const int iy = 2 * oy - 1 + r, ix = col - 1;
+      float v = 0.f;
+      if (i < 3 * 3 * (FC_W + 2) && (unsigned)iy < 128u && (unsigned)ix < 128u) v = x[(((size_t)n * 3 + ci) * 128 + iy) * 128 + ix];
+      px[j] = v;
+    }
+  };
+  prefetch(rb * ROWS);
   for (int oy = rb * ROWS; oy < rb * ROWS + ROWS; ++oy) {
     __syncthreads();
-    fc_stage_rows(x, xs, n, oy, tid);
-    const f16* src = dv + (((size_t)n * 64 + oy) * 64) * FC_CO;
-    for (int i = tid; i < 64 * FC_CO / 8; i += 256)
-      reinterpret_cast<f16x8*>(&ds[0][0])[i] = reinterpret_cast<const f16x8*>(src)[i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) reinterpret_cast<f16x8*>(&ds[0][0])[tid + 256 * j] = pd[j];
+#pragma unroll
+    for (int j = 0; j < XN; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 3 * 3 * (FC_W + 2)) (&xs[0][0][0])[i] = px[j];
+    }
+    if (oy + 1 < rb * ROWS + ROWS) prefetch(oy + 1);
     __syncthreads();
     for (int i = tid; i < 32 * 64; i += 256) {
       const int k = i >> 6, p = i & 63;
