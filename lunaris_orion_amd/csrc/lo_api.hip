@@ -204,6 +204,7 @@ struct ConvLayer {           // conv + GroupNorm + Mish
   size_t o_bcnt;
   unsigned gba_epoch;
   bool dv_done; int np2;
+  hipEvent_t ev_ready;   // dv_done: the event bound to the launch that wrote this layer's dv (null: none was bound)
   // few-rows layers (the 8 x 8 stage): forward / data gradient as a K-split 128 x 128-tile GEMM into fp32 slabs + ONE fused
   // (sample, group)-local pass (slab sum + bias + GroupNorm [+ Mish | backward]); 0 = the one-launch kernel
   int sk_fwd, sk_dgrad;
@@ -252,7 +253,7 @@ struct LoVae {
   int dec_skips;             // how many skip maps the last decoder forward added (3 inside lo_vae_forward)
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
-  hipEvent_t ev_dv[2], ev_join, ev_pre;
+  hipEvent_t ev_dv[4], ev_join, ev_pre;
   // Operand refresh on the side stream in five levels, one event each, recorded in this order (waiting for a level implies the
   // lower ones): 1 packed convs of encoder stages 1..3; 2 encoder stage 4 (parameters + packs); 3 the encoder heads (fc_mu /
   // fc_logvar: parameters + fp16 copy); 4 decoder.fc + decoder convs; 5 the transposed Linear copies only the backward reads
@@ -263,13 +264,9 @@ struct LoVae {
   struct { bool pending; float* P; const float* G; float* M; float* V; void* ws; const float* norm; float lr, beta1, beta2, eps, wd; int step; } defer;
   int n_packjobs_s4, pack_blocks_s4, n_packjobs8_s4, pack_blocks8_s4;   // job-table prefix up to and including encoder stage 4
   int bwd_layer;      // conv layers processed so far in the current backward (selects the dv buffer / events)
-  // LO_WGRAD_PAIR=1: the weight gradients are handed to the side stream two layers at a time (one event per pair instead of one
-  // per layer: every event record costs the caller's stream a 6-7 us bubble, tools/timeline.py)
   size_t o_skslab;    // slabs of the split-K convolutions (one launch at a time on the caller's stream)
   bool gn_local;      // LO_GN_LOCAL=0: never use the one-pass (sample, group)-local GroupNorm backward
-  bool pair_wgrad;
-  struct { ConvLayer* c; const f16* layer_in; } pend[2];
-  int npend, nevent;
+  int nevent;         // hand-over events handed out so far (ev_dv[nevent & 3])
   bool overlap;
   float* norm_scratch;   // lo_vae_set_gradnorm_scratch: where a single-call backward leaves the early part of the gradient norm
   bool fuse_gnb;      // fuse the GroupNorm-backward reduction into the producing data-gradient epilogue
@@ -319,7 +316,7 @@ static int setup_conv_layer(ConvLayer& c, int kind, int B, int H, int W, int Cin
   c.o_xbuf = ar.take((size_t)B * LO_GNF_MAX_TILES * 128);
   c.o_xcnt = ar.take((size_t)B * 4);
   c.o_bcnt = ar.take((size_t)B * 8 * 4);
-  c.gba_epoch = 0; c.dv_done = false; c.np2 = 0;
+  c.gba_epoch = 0; c.dv_done = false; c.np2 = 0; c.ev_ready = nullptr;
   c.sk_fwd = c.sk_dgrad = 0;
   return LO_OK;
 }
@@ -504,9 +501,8 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   // was not bitwise reproducible while a weight-gradient kernel ran beside it (tools/gnb_det.py: 1365 mismatching tensors
   // in 24 runs; 0 with this form) -- the determinism tests of tests/test_fullsize_gpu.py and test_vae_gpu.py guard it
   h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
-  h->pair_wgrad = getenv("LO_WGRAD_PAIR") && atoi(getenv("LO_WGRAD_PAIR")) != 0;
   h->gn_local = !(getenv("LO_GN_LOCAL") && atoi(getenv("LO_GN_LOCAL")) == 0);
-  h->npend = 0; h->nevent = 0;
+  h->nevent = 0;
   // GroupNorm + Mish in the conv epilogue (LO_GN_FUSE=1; the default is the separate lo_gn_fwd pass after every conv).  Built,
   // bitwise equal to the separate pass (tests/test_gn_fuse_gpu.py) and measured at batch 64 in two interleaved rounds: 20 403 /
   // 20 414 sprites/s against 20 821 / 20 859 -- 2 % SLOWER.  Per layer the fused conv launches take 7-22 us longer than before while
@@ -544,7 +540,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
       ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least) == hipSuccess;
     else
       ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i)
+    for (int i = 0; i < 4 && ok; ++i)
       ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess;
@@ -561,7 +557,7 @@ extern "C" void lo_vae_destroy(LoVae* h) {
   if (h->overlap) {
     (void)vae_flush_deferred(h, nullptr);     // an optimizer step must not be lost with its engine
     (void)hipStreamDestroy(h->side);
-    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->ev_dv[i]);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev_dv[i]);
     (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre);
     for (int l = 1; l < 6; ++l) (void)hipEventDestroy(h->ev_lvl[l]);
   }
@@ -616,6 +612,10 @@ extern "C" int lo_vae_fp8_layers(const LoVae* h, int* layers) {
   return LO_OK;
 }
 
+static bool lo_event_marker() {   // LO_EVENT_MARKER=1: hipEventRecord behind the launch, as before round 3 (A/B: -0.5 %)
+  static const bool on = getenv("LO_EVENT_MARKER") != nullptr;
+  return on;
+}
 #define WSP(T, off) reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(ws) + (off))
 #define PRM(i) (P + h->p_off[(i)])
 #define GRD(i) (G + h->p_off[(i)])
@@ -829,8 +829,12 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
     LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
     return lo_vae_pack(h, P, ws, stream);
   }
-  LO_TRY(lo_adamw(P, G, M, V, b4, norm, lr, beta1, beta2, eps, weight_decay, step, st));
-  LO_HIP(hipEventRecord(h->ev_pre, st));
+  if (!lo_event_marker()) g_lo_stop_event = h->ev_pre;    // the hand-over event rides on the AdamW launch (LO_LAUNCH_STOP)
+  {
+    int r_ = lo_adamw(P, G, M, V, b4, norm, lr, beta1, beta2, eps, weight_decay, step, st);
+    if (r_ != LO_OK) { g_lo_stop_event = nullptr; return r_; }
+  }
+  if (g_lo_stop_event || lo_event_marker()) { g_lo_stop_event = nullptr; LO_HIP(hipEventRecord(h->ev_pre, st)); }
   LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
   hipStream_t sd = h->side;
   LO_TRY(lo_pack_all(WSP(LoPackJob, h->o_packjobs), h->n_packjobs_enc, h->pack_blocks_enc, sd));
@@ -1054,17 +1058,22 @@ extern "C" int lo_vae_loss(LoVae* h, void* ws, float recon_weight, float kl_weig
   return LO_OK;
 }
 
-// hand the weight gradients whose dv is ready over to the side stream: ONE event for all of them
-static int vae_flush_wgrads(LoVae* h, float* G, void* ws, float inv_scale, hipStream_t st) {
-  if (h->npend == 0) return LO_OK;
-  const int e = (h->nevent++) & 1;
-  LO_HIP(hipEventRecord(h->ev_dv[e], st));
-  LO_HIP(hipStreamWaitEvent(h->side, h->ev_dv[e], 0));
-  for (int i = 0; i < h->npend; ++i) {
-    ConvLayer& c = *h->pend[i].c;
-    LO_TRY(lo_wgrad_run(c.gf, h->pend[i].layer_in, WSP(f16, c.o_dv), WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
+// Hand-over of a layer's dv to the side stream.  The event rides on the launch that writes dv (LO_LAUNCH_STOP, lo_common.h): a
+// hipEventRecord behind that launch costs the caller's stream 3.5-4.7 us per hand-over (a marker packet the next kernel waits
+// for), the kernel's own completion signal 0.9-1.3 us (tools/probe/ev_probe.hip).
+//   vae_arm_handover:   call right before the launcher whose LAST launch writes dv; returns the event (null without a side stream)
+//   vae_armed_handover: call right after it; records the event the classic way if no launch picked it up
+static hipEvent_t vae_arm_handover(LoVae* h, bool ov) {
+  if (!ov) return nullptr;
+  hipEvent_t e = h->ev_dv[(h->nevent++) & 3];
+  if (!lo_event_marker()) g_lo_stop_event = e;
+  return e;
+}
+static int vae_armed_handover(hipEvent_t e, hipStream_t st) {
+  if (e && (g_lo_stop_event || lo_event_marker())) {   // nobody consumed it (a launcher path without LO_LAUNCH_STOP): fall back to a marker
+    g_lo_stop_event = nullptr;
+    LO_HIP(hipEventRecord(e, st));
   }
-  h->npend = 0;
   return LO_OK;
 }
 
@@ -1082,7 +1091,10 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
   const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
   // c.dv_done: the data gradient of the consuming layer has already turned this layer's activation gradient into dv (and P2) in
   // its epilogue -- `dy` was never stored
+  hipEvent_t ready = nullptr;         // completes when dv is final
+  if (c.dv_done) { ready = c.ev_ready; c.ev_ready = nullptr; }
   if (!c.dv_done) {
+    ready = vae_arm_handover(h, ov);
     if (c.np1 == 0 && h->gn_local && lo_gn_bwd_local_applies(c.Ho * c.Wo, c.Cout)) {
       // nobody has reduced this layer yet and a (sample, group) fits a workgroup: reduce + apply in ONE pass (the ResBlock tails of
       // the 16 x 16 and 8 x 8 stages), one P1 / P2 row per sample
@@ -1093,10 +1105,15 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       LO_TRY(lo_gn_bwd_nofinal(dy, WSP(f16, c.o_v), other, WSP(float, c.o_stats), PRM(c.p_gw), PRM(c.p_gb), ds, dv,
                                WSP(float, c.o_P1), WSP(float, c.o_P2), h->B, c.Ho * c.Wo, c.Cout, mode, st, c.np1));
     }
+    LO_TRY(vae_armed_handover(ready, st));
   }
   if (ov) {
-    h->pend[h->npend].c = &c; h->pend[h->npend].layer_in = layer_in; ++h->npend;
-    if (!h->pair_wgrad || h->npend == 2) LO_TRY(vae_flush_wgrads(h, G, ws, inv_scale, st));
+    if (!ready) {                      // dv came from a launch that carried no event: classic record
+      ready = h->ev_dv[(h->nevent++) & 3];
+      LO_HIP(hipEventRecord(ready, st));
+    }
+    LO_HIP(hipStreamWaitEvent(h->side, ready, 0));
+    LO_TRY(lo_wgrad_run(c.gf, layer_in, dv, WSP(float, h->o_wslab), GRD(c.p_w), inv_scale, h->side));
   } else {
     static char wtag[32][64];
     if (g_lo_prof_on && g_lo_prof_layers) {
@@ -1118,9 +1135,13 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
     int r_ = lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_skslab), c.sk_dgrad, st);
     g_lo_prof_tag = nullptr;
     if (r_ != LO_OK) return r_;
-    LO_TRY(lo_splitk_gn_bwd(WSP(float, h->o_skslab), c.sk_dgrad, add_src, WSP(f16, prod->o_v), WSP(float, prod->o_stats), PRM(prod->p_gw),
-                            PRM(prod->p_gb), din_has_other_readers ? din : nullptr, WSP(f16, prod->o_dv), WSP(float, prod->o_P1),
-                            WSP(float, prod->o_P2), h->B, prod->Ho * prod->Wo, prod->Cout, st));
+    hipEvent_t pe = vae_arm_handover(h, ov);       // the pass below writes prod's dv: its launch carries prod's hand-over event
+    int r2_ = lo_splitk_gn_bwd(WSP(float, h->o_skslab), c.sk_dgrad, add_src, WSP(f16, prod->o_v), WSP(float, prod->o_stats), PRM(prod->p_gw),
+                               PRM(prod->p_gb), din_has_other_readers ? din : nullptr, WSP(f16, prod->o_dv), WSP(float, prod->o_P1),
+                               WSP(float, prod->o_P2), h->B, prod->Ho * prod->Wo, prod->Cout, st);
+    if (r2_ != LO_OK) { g_lo_stop_event = nullptr; return r2_; }
+    LO_TRY(vae_armed_handover(pe, st));
+    prod->ev_ready = pe;
     prod->dv_done = true; prod->np1 = 1; prod->np2 = 1;
     return LO_OK;
   }
@@ -1150,9 +1171,11 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       snprintf(dtag[k & 31], 64, "dgrad L%02d kind%d %dx%d %d->%d", k, c.kind, c.Ho, c.Wo, c.gd.Cin, c.gd.Cout);
       g_lo_prof_tag = dtag[k & 31];
     }
+    hipEvent_t pe = (gbp && gbp->dv) ? vae_arm_handover(h, ov) : nullptr;   // this launch writes prod's dv: it carries prod's event
     int r_ = lo_conv_run(c.gd, dv, WSP(f16, c.o_wp_d), nullptr, add_src, din, nullptr, nullptr, 1, st, gbp);
     g_lo_prof_tag = nullptr;
-    if (r_ != LO_OK) { if (gbp && gbp->dv) { --prod->gba_epoch; prod->dv_done = false; } return r_; }
+    if (r_ != LO_OK) { g_lo_stop_event = nullptr; if (gbp && gbp->dv) { --prod->gba_epoch; prod->dv_done = false; } return r_; }
+    if (gbp && gbp->dv) { LO_TRY(vae_armed_handover(pe, st)); prod->ev_ready = pe; }
   }
   return LO_OK;
 }
@@ -1264,8 +1287,8 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   if (phase == 0 || phase == 1 || phase == 5 || phase == 6) {
     h->bwd_layer = 0;
     for (int s = 0; s < 4; ++s) {
-      for (int k = 0; k < 3; ++k) { h->enc[s][k].np1 = 0; h->enc[s][k].dv_done = false; h->enc[s][k].np2 = 0; }
-      h->dec[s].np1 = 0; h->dec[s].dv_done = false; h->dec[s].np2 = 0;
+      for (int k = 0; k < 3; ++k) { h->enc[s][k].np1 = 0; h->enc[s][k].dv_done = false; h->enc[s][k].np2 = 0; h->enc[s][k].ev_ready = nullptr; }
+      h->dec[s].np1 = 0; h->dec[s].dv_done = false; h->dec[s].np2 = 0; h->dec[s].ev_ready = nullptr;
     }
   }
   if (phase == 0 || phase == 1 || phase == 5) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
@@ -1294,7 +1317,6 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     gout = din;
   }
   // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
-  LO_TRY(vae_flush_wgrads(h, G, ws, inv, st));
   // ---- decoder.fc
   LO_TRY(lo_nhwc_to_nchw_f16(Ga, Gb, B, 64, 512, st));                       // Gb = dy of decoder.fc, [B][32768] c-major
   LO_TRY(lo_colsum_f16(Gb, GRD(h->idx_dfc_b), B, 32768, inv, st));
@@ -1380,7 +1402,6 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
                                  WSP(float, c0.o_P1), WSP(float, c0.o_P2), B, 64 * 64, 64, 0, st, c0.np1));
       LO_TRY(lo_first_conv_wgrad(x, dv0, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
-    if (s == s_lo) LO_TRY(vae_flush_wgrads(h, G, ws, inv, st));      // nothing may be left pending at the join below
   }
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer
   if (h->overlap && !g_lo_prof_on) {

@@ -2,6 +2,7 @@
 // Internal header: the public C ABI is include/lunaris_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef _Float16 f16;
@@ -65,6 +66,21 @@ struct LoProfScope {
     if (on) lo_prof_end(st);
   }
 };
+
+// Cross-stream hand-over without a marker packet.  hipEventRecord after a kernel puts a barrier packet with a signal behind it, and
+// the NEXT kernel of that stream waits for the packet: measured (tools/probe/ev_probe.hip, MI355X) +3.5 .. 4.7 us on the producing
+// stream per hand-over.  hipExtLaunchKernelGGL(..., stopEvent) binds the event to the kernel's own completion signal instead:
+// +0.9 .. 1.3 us.  The host code that wants the launch which writes a buffer to carry an event sets g_lo_stop_event right before
+// calling the launcher; the launch sites that can be that last launch use LO_LAUNCH_STOP, which consumes the variable (thread-local:
+// engines may be driven from several host threads).  A caller checks that it was consumed and falls back to hipEventRecord if not.
+extern thread_local hipEvent_t g_lo_stop_event;
+#define LO_LAUNCH_STOP(kern, grid, block, lds, st, ...)                                                  \
+  do {                                                                                                   \
+    hipEvent_t se__ = g_lo_stop_event;                                                                   \
+    g_lo_stop_event = nullptr;                                                                           \
+    if (se__) hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, se__, 0, __VA_ARGS__);          \
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                    \
+  } while (0)
 
 // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at LDS offset lds_off, lane-linear) as inline asm.
 // Kernels whose fragments come from ds_read_b64_tr_b16 use this form instead of __builtin_amdgcn_global_load_lds: after

@@ -1023,7 +1023,7 @@ static int igemm_launch(dim3 grid, const IgemmArgs& a, hipStream_t st) {
       attr = true;
     }
   }
-  hipLaunchKernelGGL((lo_igemm_nt<BM, BN, BK, NS, SK, F8>), grid, dim3(256), lds, st, a);
+  LO_LAUNCH_STOP((lo_igemm_nt<BM, BN, BK, NS, SK, F8>), grid, dim3(256), lds, st, a);   // may carry the hand-over event of the dv it writes
   return LO_OK;
 }
 

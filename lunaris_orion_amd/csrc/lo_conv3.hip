@@ -683,10 +683,10 @@ int lo_conv3_run(const LoGeom& g, const f16* in, const f16* wp, const float* bia
   if (add_src) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cout;
   if (gb) bytes += 2.0 * g.B * g.Hin * g.Win * g.Cout;
   LoProfScope _p(lo_prof_intern(name), flops, bytes, st);
-  if (th == 8) hipLaunchKernelGGL((lo_conv3x3_pp<128, 8, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
-  else if (bn == 64 && g.Cin == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, LO_PP_PLAIN, true>), dim3(tiles), dim3(512), 0, st, a);
-  else if (bn == 64) hipLaunchKernelGGL((lo_conv3x3_pp<64, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((lo_conv3x3_pp<128, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
+  if (th == 8) LO_LAUNCH_STOP((lo_conv3x3_pp<128, 8, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
+  else if (bn == 64 && g.Cin == 64) LO_LAUNCH_STOP((lo_conv3x3_pp<64, 16, LO_PP_PLAIN, true>), dim3(tiles), dim3(512), 0, st, a);
+  else if (bn == 64) LO_LAUNCH_STOP((lo_conv3x3_pp<64, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
+  else LO_LAUNCH_STOP((lo_conv3x3_pp<128, 16, LO_PP_PLAIN>), dim3(tiles), dim3(512), 0, st, a);
   LO_LAUNCH_CHECK("conv3x3_pp");
   return LO_OK;
 }

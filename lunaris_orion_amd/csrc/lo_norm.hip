@@ -610,11 +610,11 @@ int lo_gn_bwd_nofinal(const f16* dy, const f16* v, const f16* other, const float
     LoProfScope _p(gn_layer_name("lo_gn_bwd_apply", C, HW, mode), 0, 2.0 * B * HW * C * (mode == 2 ? 4 : 3), st);
     const bool g4 = C == 32;
     if (mode == GN_MODE_RES) {
-      if (g4) hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<true, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<true, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      if (g4) LO_LAUNCH_STOP((lo_gn_bwd_apply_kernel<true, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      else LO_LAUNCH_STOP((lo_gn_bwd_apply_kernel<true, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
     } else {
-      if (g4) hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<false, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((lo_gn_bwd_apply_kernel<false, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      if (g4) LO_LAUNCH_STOP((lo_gn_bwd_apply_kernel<false, true>), dim3(a.nchunk, B), dim3(256), 0, st, a);
+      else LO_LAUNCH_STOP((lo_gn_bwd_apply_kernel<false, false>), dim3(a.nchunk, B), dim3(256), 0, st, a);
     }
   }
   LO_LAUNCH_CHECK("gn_bwd_apply");
@@ -715,9 +715,9 @@ int lo_splitk_gn_bwd(const float* slab, int nsplit, const f16* add_src, const f1
   const int E = HW / (256 / ((C >> 3) >> 3));
   LoProfScope _p(gn_layer_name("lo_splitk_gn_bwd", C, HW, 0), 0, (double)B * HW * C * (4.0 * nsplit + 4.0 + (add_src ? 2.0 : 0.0)), st);
   const dim3 grid(8, B);
-  if (E <= 1) hipLaunchKernelGGL((lo_gn_bwd_local_kernel<false, 1, true>), grid, dim3(256), 0, st, a, ss);
-  else if (E == 2) hipLaunchKernelGGL((lo_gn_bwd_local_kernel<false, 2, true>), grid, dim3(256), 0, st, a, ss);
-  else hipLaunchKernelGGL((lo_gn_bwd_local_kernel<false, 4, true>), grid, dim3(256), 0, st, a, ss);
+  if (E <= 1) LO_LAUNCH_STOP((lo_gn_bwd_local_kernel<false, 1, true>), grid, dim3(256), 0, st, a, ss);
+  else if (E == 2) LO_LAUNCH_STOP((lo_gn_bwd_local_kernel<false, 2, true>), grid, dim3(256), 0, st, a, ss);
+  else LO_LAUNCH_STOP((lo_gn_bwd_local_kernel<false, 4, true>), grid, dim3(256), 0, st, a, ss);
   LO_LAUNCH_CHECK("splitk_gn_bwd");
   return LO_OK;
 }
@@ -735,7 +735,7 @@ int lo_gn_bwd_local(const f16* dy, const f16* v, const f16* other, const float* 
   LoProfScope _p(gn_layer_name("lo_gn_bwd_local", C, HW, mode), 0, 2.0 * B * HW * C * (mode == 2 ? 5 : 3), st);
   const dim3 grid(8, B);
   const GnSlabSrc ss{nullptr, 0, nullptr, nullptr, 0};
-#define LO_GNL(RES_, E_) hipLaunchKernelGGL((lo_gn_bwd_local_kernel<RES_, E_>), grid, dim3(256), 0, st, a, ss)
+#define LO_GNL(RES_, E_) LO_LAUNCH_STOP((lo_gn_bwd_local_kernel<RES_, E_>), grid, dim3(256), 0, st, a, ss)
   if (mode == GN_MODE_RES) { if (E <= 1) LO_GNL(true, 1); else if (E == 2) LO_GNL(true, 2); else LO_GNL(true, 4); }
   else { if (E <= 1) LO_GNL(false, 1); else if (E == 2) LO_GNL(false, 2); else LO_GNL(false, 4); }
 #undef LO_GNL

@@ -410,7 +410,7 @@ int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float
   constexpr int max_blocks = 256;   // 256 / 512 / 1024 / 2048 measured in round 2: no difference on the step; one workgroup per CU
   const size_t want = (n / 4 + 255) / 256;
   const int nblk = want >= (size_t)max_blocks ? max_blocks : (want < 1 ? 1 : (int)want);
-  hipLaunchKernelGGL(lo_adamw_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
+  LO_LAUNCH_STOP(lo_adamw_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, norm, lr, beta1, beta2, eps, wd,
                      (float)bc1d, (float)sqrt(bc2d), cast);
   LO_LAUNCH_CHECK("adamw");
   return LO_OK;

@@ -17,6 +17,7 @@ int lo_check_hip(hipError_t e, const char* what) {
 #include <string>
 #include <vector>
 bool g_lo_prof_on = false;
+thread_local hipEvent_t g_lo_stop_event = nullptr;   // see LO_LAUNCH_STOP (lo_common.h)
 bool g_lo_prof_layers = false;     // per-layer record names (lo_prof_enable(2), or LO_PROF_LAYERS in the environment)
 const char* g_lo_prof_tag = nullptr;
 namespace {
