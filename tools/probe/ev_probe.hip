@@ -54,5 +54,31 @@ int main() {
       printf("iters %6d  %-48s %.2f us per chain kernel\n", iters, names[mode], best * 1e3f / N);
     }
   }
+  // ---- cost of a wait that is already satisfied (the forward's level waits, the join): A waits for an event B recorded long ago
+  {
+    hipEvent_t done;
+    CK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    hipLaunchKernelGGL(spin, dim3(64), dim3(256), 0, B, b, 100);
+    CK(hipEventRecord(done, B));
+    CK(hipDeviceSynchronize());
+    for (int iters : {200, 20000}) {
+      for (int mode = 0; mode < 2; ++mode) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(t0, A));
+          for (int i = 0; i < N; ++i) {
+            if (mode == 1) CK(hipStreamWaitEvent(A, done, 0));
+            hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, A, a, iters);
+          }
+          CK(hipEventRecord(t1, A));
+          CK(hipDeviceSynchronize());
+          float ms; CK(hipEventElapsedTime(&ms, t0, t1));
+          if (ms < best) best = ms;
+        }
+        printf("iters %6d  %-48s %.2f us per chain kernel\n", iters, mode ? "satisfied hipStreamWaitEvent before each kernel" : "plain chain", best * 1e3f / N);
+      }
+    }
+  }
   return 0;
 }
