@@ -239,7 +239,7 @@ struct LoVae {
   size_t o_xflat, o_slab_head, o_eps, o_z, o_klp, o_mu, o_lv, o_yfc, o_h0;
   size_t o_msep, o_losses, o_coefs;
   // backward scratch
-  size_t o_G[6], o_skipg[3], o_P1, o_P2, o_wslab, o_wslab_lin, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz;
+  size_t o_G[6], o_skipg[3], o_P1, o_P2, o_wslab, o_wslab_lin, o_fcw_part, o_lc_part, o_dz, o_dml, o_slab_dz, o_gfc;
   size_t o_packjobs;
   std::vector<LoPackJob> packjobs_host;   // kept alive: source of the asynchronous table upload
   int n_packjobs, pack_blocks;
@@ -444,6 +444,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->o_lc_part = ar.take((size_t)B * 64 * 867 * 4);
   h->o_dz = ar.take((size_t)B * L * 2);
   h->o_dml = ar.take((size_t)B * 2 * L * 2);
+  h->o_gfc = ar.take((size_t)B * 32768 * 2);    // dy of decoder.fc, channel-major: its own buffer (the side-stream weight gradient reads it while the chain reuses Gb)
   h->o_slab_dz = ar.take((size_t)h->dfcd_split * B * L * 4);
   h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
@@ -1280,6 +1281,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(vae_wait_level(h, st, 5));   // the transposed Linear copies (and, after a lo_vae_pack between forward and backward, everything)
   const int B = h->B, L = h->L;
   const float inv = 1.0f / loss_scale;
+  hipEvent_t early_ev = nullptr;      // ev_pre when part A's last launch carries it (single-call backward with the early gradient norm)
   f16* Ga = WSP(f16, h->o_G[0]);
   f16* Gb = WSP(f16, h->o_G[1]);
   f16* Gc = WSP(f16, h->o_G[2]);
@@ -1299,9 +1301,13 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   {
     ConvLayer& u4 = h->dec[3];
     if (fused || drecon) {
-      LO_TRY(lo_final_conv_bwd(WSP(f16, u4.o_a), PRM(h->idx_final_w), recon, fused ? target : nullptr, fused ? nullptr : drecon,
-                               fused ? WSP(float, h->o_coefs) : nullptr, loss_scale, Ga, WSP(float, h->o_lc_part),
-                               GRD(h->idx_final_w), GRD(h->idx_final_b), B, inv, st));
+      const bool ov0 = h->overlap && !g_lo_prof_on && !lo_event_marker();
+      hipEvent_t e = vae_arm_handover(h, ov0);          // rides on the kernel; the dw / db column sums follow it on the side stream
+      int r_ = lo_final_conv_bwd(WSP(f16, u4.o_a), PRM(h->idx_final_w), recon, fused ? target : nullptr, fused ? nullptr : drecon,
+                                 fused ? WSP(float, h->o_coefs) : nullptr, loss_scale, Ga, WSP(float, h->o_lc_part),
+                                 GRD(h->idx_final_w), GRD(h->idx_final_b), B, inv, st, ov0 ? h->side : nullptr, e);
+      g_lo_stop_event = nullptr;
+      if (r_ != LO_OK) return r_;
     } else {
       LO_HIP(hipMemsetAsync(Ga, 0, (size_t)B * 128 * 128 * 32 * 2, st));
     }
@@ -1318,10 +1324,22 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   }
   // gout == Ga: gradient wrt h0 [B,8,8,512] NHWC
   // ---- decoder.fc
-  LO_TRY(lo_nhwc_to_nchw_f16(Ga, Gb, B, 64, 512, st));                       // Gb = dy of decoder.fc, [B][32768] c-major
-  LO_TRY(lo_colsum_f16(Gb, GRD(h->idx_dfc_b), B, 32768, inv, st));
-  LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gb, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, st));
-  LO_TRY(lo_conv_run(h->g_dfc_d, Gb, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
+  // The bias and weight gradients of the two Linear layers feed nothing on the dependent chain (72 us of it in round 2): with a
+  // side stream they run there, behind an event that rides on the launch producing their operand (LO_LAUNCH_STOP).  o_wslab_lin
+  // stays theirs alone (two launches, in order on one stream); Gfc is a buffer of its own because the chain reuses Gb.
+  const bool ovl = h->overlap && !g_lo_prof_on;
+  hipStream_t gs = ovl ? h->side : st;
+  f16* Gfc = WSP(f16, h->o_gfc);
+  {
+    hipEvent_t e = vae_arm_handover(h, ovl);
+    int r_ = lo_nhwc_to_nchw_f16(Ga, Gfc, B, 64, 512, st);                   // Gfc = dy of decoder.fc, [B][32768] c-major
+    if (r_ != LO_OK) { g_lo_stop_event = nullptr; return r_; }
+    LO_TRY(vae_armed_handover(e, st));
+    if (ovl) LO_HIP(hipStreamWaitEvent(h->side, e, 0));
+  }
+  LO_TRY(lo_colsum_f16(Gfc, GRD(h->idx_dfc_b), B, 32768, inv, gs));
+  LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gfc, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, gs));
+  LO_TRY(lo_conv_run(h->g_dfc_d, Gfc, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
                      h->dfcd_split, st));
   LO_TRY(lo_splitk_reduce(WSP(float, h->o_slab_dz), nullptr, phase == 5 ? sp->dz : nullptr, WSP(f16, h->o_dz), B, L, h->dfcd_split, st));
   if (phase == 5) {
@@ -1337,14 +1355,26 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     return vae_gn_finalize(h, 0u, true, G, ws, inv, st);
   }
   // ---- latent: KL + reparameterisation backward (train_hybrid.py:862; lunar_generate.py:259-261)
-  LO_TRY(lo_latent_bwd(WSP(f16, h->o_dz), WSP(float, h->o_mu), WSP(float, h->o_lv), WSP(float, h->o_eps),
-                       fused ? WSP(float, h->o_coefs) : nullptr, fused ? nullptr : gmu, fused ? nullptr : glv, loss_scale,
-                       WSP(f16, h->o_dml), B, L, st));
-  // ---- encoder heads
-  LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, st));
-  LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, st));
+  {
+    hipEvent_t e = vae_arm_handover(h, ovl);
+    int r_ = lo_latent_bwd(WSP(f16, h->o_dz), WSP(float, h->o_mu), WSP(float, h->o_lv), WSP(float, h->o_eps),
+                           fused ? WSP(float, h->o_coefs) : nullptr, fused ? nullptr : gmu, fused ? nullptr : glv, loss_scale,
+                           WSP(f16, h->o_dml), B, L, st);
+    if (r_ != LO_OK) { g_lo_stop_event = nullptr; return r_; }
+    LO_TRY(vae_armed_handover(e, st));
+    if (ovl) LO_HIP(hipStreamWaitEvent(h->side, e, 0));
+  }
+  // ---- encoder heads (bias + weight gradient beside the chain, see decoder.fc above)
+  LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, gs));
+  LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, gs));
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
-  LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));                       // Ga = gradient wrt enc4 output, NHWC
+  early_ev = (phase == 0 && h->norm_scratch && ovl && !lo_event_marker()) ? h->ev_pre : nullptr;
+  if (early_ev) g_lo_stop_event = early_ev;                                  // the early-norm hand-over rides on part A's last launch
+  {
+    int r_ = lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st);                    // Ga = gradient wrt enc4 output, NHWC
+    if (r_ != LO_OK) { g_lo_stop_event = nullptr; return r_; }
+  }
+  if (g_lo_stop_event) { g_lo_stop_event = nullptr; early_ev = nullptr; }    // not picked up: the marker below
   }                   // ---------------- end of part A
   if (phase == 6) {
     // Encoder.forward's backward on its own: upstream gradients of mu / logvar and of the three skip maps (fp32 NCHW; NULL = zero)
@@ -1365,7 +1395,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   if (phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on) {
     // everything from fc_mu.weight on is final once the decoder's side-stream weight gradients are: order the early
     // sum of squares after both streams' part A and let it run on the side stream beside the encoder backward
-    LO_HIP(hipEventRecord(h->ev_pre, st));
+    if (!early_ev) LO_HIP(hipEventRecord(h->ev_pre, st));
     LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
     LO_TRY(vae_gn_finalize(h, 0u, true, G, ws, inv, h->side));      // the decoder's GroupNorm / bias gradients belong to the range
     LO_TRY(lo_sumsq_range(G, h->p_off[h->idx_fc_mu_w], h->flat_elems, h->norm_scratch, h->side));

@@ -551,12 +551,15 @@ int lo_final_conv_fwd(const f16* a4, const float* w, const float* bias, const fl
 // partial: B*64*867 floats ; dw [3][32][3][3], db [3]
 int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const float* target, const float* drecon,
                       const float* coef, float gscale, f16* da4, float* partial, float* dw, float* db, int B, float scale,
-                      hipStream_t st) {
+                      hipStream_t st, hipStream_t sum_st, hipEvent_t sum_after) {
   LcBwdArgs a{a4, w, recon, target, drecon, coef, gscale, da4, partial};
   LoProfScope _p("lo_final_conv_bwd(+sums)", 4.0 * B * 16384 * 3 * 288, (double)B * 16384 * (32 * 2 * 2 + 3 * 4 * 2), st);
   constexpr int rows = 8;    // 8 tiles (a whole row of tiles) per workgroup; 4 / 2 measured in round 2: 86 / 108 / 147 us
-  hipLaunchKernelGGL(lo_final_conv_bwd_kernel<8>, dim3(rows, B), dim3(256), 0, st, a);
+  // the two column sums only feed the gradient buffer: with sum_st they run beside the chain, behind the event the caller armed
+  // for this launch (LO_LAUNCH_STOP; sum_after is that event)
+  LO_LAUNCH_STOP(lo_final_conv_bwd_kernel<8>, dim3(rows, B), dim3(256), 0, st, a);
   LO_LAUNCH_CHECK("final_conv_bwd");
+  if (sum_st && sum_after) { LO_HIP(hipStreamWaitEvent(sum_st, sum_after, 0)); st = sum_st; }
   hipLaunchKernelGGL(lo_colsum_kernel, dim3((864 + 15) / 16), dim3(256), 0, st, partial, dw, B * rows, 864, 867, scale);
   LO_LAUNCH_CHECK("final_conv_dw");
   // bias: columns 864..866 of the same partial matrix

@@ -107,7 +107,7 @@ int lo_final_conv_fwd(const f16* a4, const float* w, const float* bias, const fl
                       float* mse_partial, int B, hipStream_t st);
 int lo_final_conv_bwd(const f16* a4, const float* w, const float* recon, const float* target, const float* drecon,
                       const float* coef, float gscale, f16* da4, float* partial, float* dw, float* db, int B, float scale,
-                      hipStream_t st);
+                      hipStream_t st, hipStream_t sum_st = nullptr, hipEvent_t sum_after = nullptr);   // sum_st: where the two column sums (dw, db) run
 
 // lo_train.hip
 int lo_head_reduce(const float* slab, const float* bias, const float* eps_in, uint64_t seed, float* mu, float* logvar,

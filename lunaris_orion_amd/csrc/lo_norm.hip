@@ -767,14 +767,14 @@ int lo_gn_finalize_all(const LoGnFinJobs& jobs, float scale, hipStream_t st) {
 int lo_nhwc_to_nchw_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st) {
   LO_REQUIRE(HW % 64 == 0 && C % 64 == 0, "lo_nhwc_to_nchw_f16: HW=%d, C=%d must be multiples of 64", HW, C);
   LoProfScope _p("lo_layout_transpose", 0, 4.0 * B * HW * C, st);
-  hipLaunchKernelGGL(lo_transpose_tile_kernel, dim3(C / 64, HW / 64, B), dim3(256), 0, st, src, dst, (uint8_t*)nullptr, HW, C);
+  LO_LAUNCH_STOP(lo_transpose_tile_kernel, dim3(C / 64, HW / 64, B), dim3(256), 0, st, src, dst, (uint8_t*)nullptr, HW, C);
   LO_LAUNCH_CHECK("nhwc_to_nchw");
   return LO_OK;
 }
 int lo_nchw_to_nhwc_f16(const f16* src, f16* dst, int B, int HW, int C, hipStream_t st, uint8_t* dst8) {
   LO_REQUIRE(HW % 64 == 0 && C % 64 == 0, "lo_nchw_to_nhwc_f16: HW=%d, C=%d must be multiples of 64", HW, C);
   LoProfScope _p("lo_layout_transpose", 0, 4.0 * B * HW * C, st);
-  hipLaunchKernelGGL(lo_transpose_tile_kernel, dim3(HW / 64, C / 64, B), dim3(256), 0, st, src, dst, dst8, C, HW);
+  LO_LAUNCH_STOP(lo_transpose_tile_kernel, dim3(HW / 64, C / 64, B), dim3(256), 0, st, src, dst, dst8, C, HW);
   LO_LAUNCH_CHECK("nchw_to_nhwc");
   return LO_OK;
 }

@@ -338,7 +338,7 @@ int lo_latent_bwd(const f16* dz, const float* mu, const float* logvar, const flo
                   const float* gmu, const float* glv, float gscale, f16* dml, int B, int L, hipStream_t st) {
   int n = B * L;
   LoProfScope _p("lo_latent_bwd", 0, 0, st);
-  hipLaunchKernelGGL(lo_latent_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dz, mu, logvar, eps, coefs, gmu, glv,
+  LO_LAUNCH_STOP(lo_latent_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dz, mu, logvar, eps, coefs, gmu, glv,
                      gscale, dml, B, L);
   LO_LAUNCH_CHECK("latent_bwd");
   return LO_OK;
