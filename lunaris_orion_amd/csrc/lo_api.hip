@@ -1425,6 +1425,8 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
       LO_TRY(conv_gn_bwd(h, c0, Gc, nullptr, 0, WSP(f16, h->o_eout[s - 1]), nullptr, Ga, WSP(f16, h->o_skipg[s - 1]), P, G,
                          ws, inv, st));
     } else {
+      // (the first conv's weight gradient on the side stream with the finalize below beside it: neutral in round 2 and again in round 3
+      // with launch-bound events, 22 900-23 137 against 22 864-23 106 -- it stays on this stream)
       const f16* dv0 = Gd;
       if (c0.dv_done) dv0 = WSP(f16, c0.o_dv);      // conv1's data gradient has already applied this layer's GroupNorm backward
       else
@@ -1433,14 +1435,15 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
       LO_TRY(lo_first_conv_wgrad(x, dv0, WSP(float, h->o_fcw_part), GRD(c0.p_w), B, inv, st));
     }
   }
+  // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or those of the stages this call ran.
+  // Reads P1 / P2 rows only (all written on this stream): before the join, beside the side stream's last weight gradients
+  const bool early_norm = phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on;   // decoder layers finalized above
+  LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0 && !early_norm, G, ws, inv, st));
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer
   if (h->overlap && !g_lo_prof_on) {
     LO_HIP(hipEventRecord(h->ev_join, h->side));
     LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   }
-  // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or those of the stages this call ran
-  const bool early_norm = phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on;   // decoder layers finalized above
-  LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0 && !early_norm, G, ws, inv, st));
   return LO_OK;
 }
 
