@@ -1296,7 +1296,9 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   if (phase == 0 || phase == 1 || phase == 5) {   // ---------------- part A: final conv, decoder, Linear layers (their gradients are complete afterwards)
   // padding elements of the flat gradient buffer are zero afterwards; every other element is overwritten (never accumulated
   // into) by exactly one gradient kernel
-  LO_TRY(vae_zero_gaps(h, G, st));
+  // (gradient-only and independent of everything on the chain: on the side stream when there is one -- in order behind the previous
+  // optimizer tail there, in front of every weight gradient of this backward, and joined before anybody reads the buffer)
+  LO_TRY(vae_zero_gaps(h, G, (h->overlap && !g_lo_prof_on) ? h->side : st));
   // ---- final conv (+tanh, + fused MSE gradient)
   {
     ConvLayer& u4 = h->dec[3];
