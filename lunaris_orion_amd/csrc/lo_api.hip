@@ -529,8 +529,8 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   if (h->overlap) {
     // The side stream carries work that has slack (weight gradients, the tail of the optimizer step, operand refresh); the
     // caller's stream carries the dependent chain that decides the step time.  Lowest queue priority for the side stream: when both
-    // have workgroups ready, the dispatcher serves the chain first and the side work fills what it leaves (LO_SIDE_PRIO=0: default
-    // priority, the round-1 behaviour).  Timeline before (tools/timeline.py): the first GroupNorm pass of a step took 302 us instead of
+    // have workgroups ready, the dispatcher serves the chain first and the side work fills what it leaves (default priority was the
+    // round-1 behaviour).  Timeline before (tools/timeline.py): the first GroupNorm pass of a step took 302 us instead of
     // 17 beside the side stream's AdamW, data-gradient launches 55-65 us instead of 36-44 beside the weight gradients.
     // (A CU-masked side stream -- hipExtStreamCreateWithCUMask with 64 / 128 / 192 / all 256 bits set -- was tried in round 3 to
     // fence the side work off: 10 300-12 700 sprites/s against 22 300 with ANY mask, the full one included, so the masked queue
