@@ -613,6 +613,8 @@ extern "C" int lo_vae_fp8_layers(const LoVae* h, int* layers) {
   return LO_OK;
 }
 
+// an armed event never outlives the function that armed it (error returns included)
+struct LoStopEventGuard { ~LoStopEventGuard() { g_lo_stop_event = nullptr; } };
 static bool lo_event_marker() {   // LO_EVENT_MARKER=1: hipEventRecord behind the launch, as before round 3 (A/B: -0.5 %)
   static const bool on = getenv("LO_EVENT_MARKER") != nullptr;
   return on;
@@ -830,6 +832,7 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
     LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
     return lo_vae_pack(h, P, ws, stream);
   }
+  LoStopEventGuard stop_guard_;
   if (!lo_event_marker()) g_lo_stop_event = h->ev_pre;    // the hand-over event rides on the AdamW launch (LO_LAUNCH_STOP)
   {
     int r_ = lo_adamw(P, G, M, V, b4, norm, lr, beta1, beta2, eps, weight_decay, step, st);
@@ -1087,6 +1090,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
                        ConvLayer* prod = nullptr, bool din_has_other_readers = false) {
   // every layer has its own dv buffer: the side-stream weight gradient of layer k may still be reading it while the main
   // stream produces the dv of the following layers (no event back from the side stream: two host calls per layer less)
+  LoStopEventGuard stop_guard_;
   const int k = h->bwd_layer++;
   f16* dv = WSP(f16, c.o_dv);
   const bool ov = h->overlap && !g_lo_prof_on;   // per-launch profiling keeps everything on one stream
@@ -1281,6 +1285,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(vae_wait_level(h, st, 5));   // the transposed Linear copies (and, after a lo_vae_pack between forward and backward, everything)
   const int B = h->B, L = h->L;
   const float inv = 1.0f / loss_scale;
+  LoStopEventGuard stop_guard_;
   hipEvent_t early_ev = nullptr;      // ev_pre when part A's last launch carries it (single-call backward with the early gradient norm)
   f16* Ga = WSP(f16, h->o_G[0]);
   f16* Gb = WSP(f16, h->o_G[1]);
