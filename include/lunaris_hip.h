@@ -145,6 +145,11 @@ void lo_vae_destroy(LoVae* h);
  * lo_clip_adamw_step_presummed(.., presummed_begin = begin of that range, ..) reads only the rest.  lo_vae_gradnorm_presummed
  * says whether the next backward will do so (it needs the library's side stream).  NULL scratch: off. */
 int lo_vae_set_gradnorm_scratch(LoVae* h, float* scratch);
+/* The same partial sum for a caller that exchanges gradients between processes (data parallel: the norm is that of the AVERAGED
+ * gradients, so the library cannot take it inside the backward): sum of squares of flat_grads[begin, end) into scratch[512..1024),
+ * to be enqueued behind the exchange of that range, on whatever stream ran it; lo_clip_adamw_step_presummed / the `presummed` form
+ * of lo_vae_optimizer_step then read only [0, begin).  clip_grad_norm_'s norm (train_hybrid.py:913), split in two. */
+int lo_gradnorm_early_range(const float* flat_grads, size_t begin, size_t end, float* scratch, void* stream);
 int lo_vae_gradnorm_presummed(const LoVae* h);
 /* parameters live in ONE flat fp32 buffer; tensor i (state_dict order, 72 tensors) starts at this element offset */
 int lo_vae_num_params(const LoVae* h);

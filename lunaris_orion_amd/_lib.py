@@ -75,6 +75,7 @@ SIGNATURES = {
     "lo_vae_create": (i32, [i32, i32, C.POINTER(C.c_void_p)]),
     "lo_vae_create_ex": (i32, [i32, i32, C.c_uint, C.POINTER(C.c_void_p)]),
     "lo_vae_set_gradnorm_scratch": (i32, [vp, f32p]),
+    "lo_gradnorm_early_range": (i32, [f32p, sz, sz, f32p, vp]),
     "lo_vae_optimizer_step": (i32, [vp, f32p, f32p, f32p, f32p, vp, flt, flt, flt, flt, flt, flt, i32, f32p, i32, vp]),
     "lo_vae_join": (i32, [vp, vp]),
     "lo_vae_gradnorm_presummed": (i32, [vp]),

@@ -605,6 +605,11 @@ extern "C" int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* f
   return LO_OK;
 }
 
+extern "C" int lo_gradnorm_early_range(const float* flat_grads, size_t begin, size_t end, float* scratch, void* stream) {
+  LO_REQUIRE(flat_grads && scratch && end > begin, "lo_gradnorm_early_range: bad argument");
+  return lo_sumsq_range(flat_grads, begin, end, scratch, S(stream));
+}
+
 extern "C" int lo_vae_fp8_layers(const LoVae* h, int* layers) {
   LO_REQUIRE(h && layers, "lo_vae_fp8_layers: null argument");
   int n = 0;

@@ -40,6 +40,8 @@ class FlatGradSync:
     `begin(range)` ... `finish()`: each `begin` enqueues the complete exchange of one range behind the work already on the current
     stream; `finish()` makes the current stream wait for all of them.  `sync(flat)` = `begin` + `finish`."""
 
+    supports_then = True        # begin(range, then=...) runs a callable behind the exchange (VAEStepper: early gradient norm)
+
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, compress_fp16: bool = False, force: bool = False,
                  wire_scale: float = 1024.0, mode: str = "allreduce", time_exposed: bool = False):
         if not dist.is_initialized():
@@ -132,14 +134,17 @@ class FlatGradSync:
             self._unpack(wire, g)
 
     # ---- public ---------------------------------------------------------------------------------------------------------------
-    def begin(self, g: torch.Tensor) -> None:
+    def begin(self, g: torch.Tensor, then=None) -> bool:
+        """Enqueue the exchange of `g`.  `then` (GPU path only): a callable run right behind the exchange with the communication
+        stream current, i.e. on the averaged values and still beside the backward (the early part of the gradient norm).  Returns
+        whether `then` was enqueued."""
         if (self.world == 1 and not self.force) or g.numel() == 0:
-            return
+            return False
         self._phase_bytes.append(g.numel() * (2 if self.compress else g.element_size()))
         if not g.is_cuda:
             self._run(g)                                  # CPU tensors (gloo tests): synchronous
             self._pending.append(None)
-            return
+            return False
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=g.device)
         ready = torch.cuda.Event()
@@ -147,9 +152,12 @@ class FlatGradSync:
         self._comm.wait_event(ready)
         with torch.cuda.stream(self._comm):
             self._run(g)
+            if then is not None:
+                then()
             done = torch.cuda.Event()
             done.record()
         self._pending.append(done)
+        return then is not None
 
     def finish(self) -> None:
         ev = None

@@ -171,7 +171,17 @@ class VAEStepper:
             _lib.check(_lib.lib.lo_vae_stage4_grad_range(eng.handle, C.byref(b4), C.byref(e4)), "lo_vae_stage4_grad_range")
             assert e4.value == b.value and e.value == self.grads.numel()
             _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 1, *bargs), "lo_vae_backward_phase(1)")
-            self.grad_sync.begin(self.grads[b.value:e.value])
+            # ... and so is the sum of squares of that range for clip_grad_norm_ (of the AVERAGED gradients): taken right behind the
+            # exchange on the communication stream, beside the encoder backward; the tail of the step reads only the encoder range
+            def early_norm():
+                _lib.check(_lib.lib.lo_gradnorm_early_range(self.grads.data_ptr(), b.value, e.value, self.scratch.data_ptr(),
+                                                            _lib.stream_ptr()), "lo_gradnorm_early_range")
+            early = os.environ.get("LO_EARLY_NORM", "1") != "0" and getattr(self.grad_sync, "supports_then", False)
+            if early:
+                if self.grad_sync.begin(self.grads[b.value:e.value], then=early_norm):
+                    self._presummed_begin = b.value
+            else:
+                self.grad_sync.begin(self.grads[b.value:e.value])
             if self.dp_three_phase:
                 _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 3, *bargs), "lo_vae_backward_phase(3)")
                 self.grad_sync.begin(self.grads[b4.value:e4.value])
