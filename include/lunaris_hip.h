@@ -150,6 +150,13 @@ int lo_vae_set_gradnorm_scratch(LoVae* h, float* scratch);
  * to be enqueued behind the exchange of that range, on whatever stream ran it; lo_clip_adamw_step_presummed / the `presummed` form
  * of lo_vae_optimizer_step then read only [0, begin).  clip_grad_norm_'s norm (train_hybrid.py:913), split in two. */
 int lo_gradnorm_early_range(const float* flat_grads, size_t begin, size_t end, float* scratch, void* stream);
+/* Asynchronous hand-over of the phased backward's gradient ranges (data parallel).  By default lo_vae_backward_phase(1) and (3)
+ * return with `stream` ordered behind everything that writes their range (the library's side stream is joined).  With on = 1 they
+ * do not hold `stream` up: the range's completion is left as an event, and lo_vae_wait_handover(h, s) makes stream `s` -- the one
+ * that runs the exchange -- wait for it.  Call it once per phase 1 / 3, before phase 3 / 4 is enqueued.  Phases 2 and 4 and the
+ * single-call backward are unchanged.  No reference counterpart (DDP's bucket hooks are the nearest thing). */
+int lo_vae_set_async_handover(LoVae* h, int on);
+int lo_vae_wait_handover(LoVae* h, void* stream);
 int lo_vae_gradnorm_presummed(const LoVae* h);
 /* parameters live in ONE flat fp32 buffer; tensor i (state_dict order, 72 tensors) starts at this element offset */
 int lo_vae_num_params(const LoVae* h);
@@ -303,6 +310,8 @@ int lo_vae_stage4_grad_range(const LoVae* h, size_t* begin_elem, size_t* end_ele
  * order; fp16 or fp32 elements);  g[i] = float(wire[i]) * inv_scale. */
 int lo_dp_pack_f16(const float* g, void* wire, size_t n, float scale, void* stream);
 int lo_dp_unpack_f16(const void* wire, float* g, size_t n, float inv_scale, void* stream);
+/* ... and, in the same pass, the sum of squares of the unpacked range into scratch[512..1024) (lo_gradnorm_early_range's result) */
+int lo_dp_unpack_f16_sumsq(const void* wire, float* g, size_t n, float inv_scale, float* scratch, void* stream);
 int lo_dp_sum_shares(const void* recv, void* share, int world, size_t chunk, int is_f16, void* stream);
 
 #ifdef __cplusplus

@@ -76,6 +76,8 @@ SIGNATURES = {
     "lo_vae_create_ex": (i32, [i32, i32, C.c_uint, C.POINTER(C.c_void_p)]),
     "lo_vae_set_gradnorm_scratch": (i32, [vp, f32p]),
     "lo_gradnorm_early_range": (i32, [f32p, sz, sz, f32p, vp]),
+    "lo_vae_set_async_handover": (i32, [vp, i32]),
+    "lo_vae_wait_handover": (i32, [vp, vp]),
     "lo_vae_optimizer_step": (i32, [vp, f32p, f32p, f32p, f32p, vp, flt, flt, flt, flt, flt, flt, i32, f32p, i32, vp]),
     "lo_vae_join": (i32, [vp, vp]),
     "lo_vae_gradnorm_presummed": (i32, [vp]),
@@ -101,6 +103,7 @@ SIGNATURES = {
     "lo_vae_debug_tensor": (i32, [vp, i32, i32, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "lo_dp_pack_f16": (i32, [f32p, vp, sz, flt, vp]),
     "lo_dp_unpack_f16": (i32, [vp, f32p, sz, flt, vp]),
+    "lo_dp_unpack_f16_sumsq": (i32, [vp, f32p, sz, flt, f32p, vp]),
     "lo_dp_sum_shares": (i32, [vp, vp, i32, sz, i32, vp]),
     "lo_vae_sync_fail_word": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "lo_vae_fp8_layers": (i32, [vp, C.POINTER(C.c_int)]),

@@ -163,6 +163,10 @@ extern "C" int lo_dp_pack_f16(const float* g, void* wire, size_t n, float scale,
   LO_REQUIRE(g && wire, "lo_dp_pack_f16: null argument");
   return lo_dp_pack_f16_run(g, (f16*)wire, n, scale, S(stream));
 }
+extern "C" int lo_dp_unpack_f16_sumsq(const void* wire, float* g, size_t n, float inv_scale, float* scratch, void* stream) {
+  LO_REQUIRE(g && wire && scratch, "lo_dp_unpack_f16_sumsq: null argument");
+  return lo_dp_unpack_f16_sumsq_run((const f16*)wire, g, n, inv_scale, scratch, S(stream));
+}
 extern "C" int lo_dp_unpack_f16(const void* wire, float* g, size_t n, float inv_scale, void* stream) {
   LO_REQUIRE(g && wire, "lo_dp_unpack_f16: null argument");
   return lo_dp_unpack_f16_run((const f16*)wire, g, n, inv_scale, S(stream));
@@ -253,7 +257,8 @@ struct LoVae {
   int dec_skips;             // how many skip maps the last decoder forward added (3 inside lo_vae_forward)
   // weight-gradient GEMMs run on a side stream, concurrently with the data-gradient / GroupNorm chain
   hipStream_t side;
-  hipEvent_t ev_dv[4], ev_join, ev_pre;
+  hipEvent_t ev_dv[4], ev_join, ev_pre, ev_range;
+  bool async_handover, range_pending;   // lo_vae_set_async_handover: phase 1 / 3 leave their range's completion as an event on the side stream
   // Operand refresh on the side stream in five levels, one event each, recorded in this order (waiting for a level implies the
   // lower ones): 1 packed convs of encoder stages 1..3; 2 encoder stage 4 (parameters + packs); 3 the encoder heads (fc_mu /
   // fc_logvar: parameters + fp16 copy); 4 decoder.fc + decoder convs; 5 the transposed Linear copies only the backward reads
@@ -504,6 +509,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->fuse_gnb = !(getenv("LO_GNB_FUSE") && atoi(getenv("LO_GNB_FUSE")) == 0);
   h->gn_local = !(getenv("LO_GN_LOCAL") && atoi(getenv("LO_GN_LOCAL")) == 0);
   h->nevent = 0;
+  h->async_handover = false; h->range_pending = false;
   // GroupNorm + Mish in the conv epilogue (LO_GN_FUSE=1; the default is the separate lo_gn_fwd pass after every conv).  Built,
   // bitwise equal to the separate pass (tests/test_gn_fuse_gpu.py) and measured at batch 64 in two interleaved rounds: 20 403 /
   // 20 414 sprites/s against 20 821 / 20 859 -- 2 % SLOWER.  Per layer the fused conv launches take 7-22 us longer than before while
@@ -543,6 +549,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
       ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i)
       ok = hipEventCreateWithFlags(&h->ev_dv[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_range, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess;
     for (int l = 1; l < 6 && ok; ++l) ok = hipEventCreateWithFlags(&h->ev_lvl[l], hipEventDisableTiming) == hipSuccess;
@@ -559,7 +566,7 @@ extern "C" void lo_vae_destroy(LoVae* h) {
     (void)vae_flush_deferred(h, nullptr);     // an optimizer step must not be lost with its engine
     (void)hipStreamDestroy(h->side);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(h->ev_dv[i]);
-    (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre);
+    (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pre); (void)hipEventDestroy(h->ev_range);
     for (int l = 1; l < 6; ++l) (void)hipEventDestroy(h->ev_lvl[l]);
   }
   delete h;
@@ -605,6 +612,19 @@ extern "C" int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* f
   return LO_OK;
 }
 
+extern "C" int lo_vae_set_async_handover(LoVae* h, int on) {
+  LO_REQUIRE(h, "lo_vae_set_async_handover: null handle");
+  h->async_handover = on != 0;
+  return LO_OK;
+}
+extern "C" int lo_vae_wait_handover(LoVae* h, void* stream) {
+  LO_REQUIRE(h, "lo_vae_wait_handover: null handle");
+  if (h->range_pending) {
+    LO_HIP(hipStreamWaitEvent(S(stream), h->ev_range, 0));
+    h->range_pending = false;
+  }
+  return LO_OK;
+}
 extern "C" int lo_gradnorm_early_range(const float* flat_grads, size_t begin, size_t end, float* scratch, void* stream) {
   LO_REQUIRE(flat_grads && scratch && end > begin, "lo_gradnorm_early_range: bad argument");
   return lo_sumsq_range(flat_grads, begin, end, scratch, S(stream));
@@ -1380,7 +1400,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, gs));
   LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, gs));
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
-  early_ev = (phase == 0 && h->norm_scratch && ovl && !lo_event_marker()) ? h->ev_pre : nullptr;
+  early_ev = (((phase == 0 && h->norm_scratch) || (phase == 1 && h->async_handover)) && ovl && !lo_event_marker()) ? h->ev_pre : nullptr;
   if (early_ev) g_lo_stop_event = early_ev;                                  // the early-norm hand-over rides on part A's last launch
   {
     int r_ = lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st);                    // Ga = gradient wrt enc4 output, NHWC
@@ -1416,6 +1436,17 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     // two-call form: every gradient from fc_mu.weight to the end of the buffer is complete now -> join the side
     // stream (decoder weight gradients) and finish the decoder's GroupNorm / bias gradients, so that the caller can
     // start exchanging that range while the encoder backward runs
+    if (h->overlap && !g_lo_prof_on && h->async_handover) {
+      // asynchronous hand-over (lo_vae_set_async_handover): this stream is NOT held up until the decoder's side-stream weight
+      // gradients have finished; the side stream waits for part A, finalizes the decoder's GroupNorm / bias gradients and leaves
+      // "the range is final" as an event that lo_vae_wait_handover puts in front of the exchange
+      if (!early_ev) LO_HIP(hipEventRecord(h->ev_pre, st));
+      LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
+      LO_TRY(vae_gn_finalize(h, 0u, true, G, ws, inv, h->side));
+      LO_HIP(hipEventRecord(h->ev_range, h->side));
+      h->range_pending = true;
+      return LO_OK;
+    }
     if (h->overlap && !g_lo_prof_on) {
       LO_HIP(hipEventRecord(h->ev_join, h->side));
       LO_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1449,6 +1480,14 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   }
   // ---- GroupNorm affine + conv bias gradients: all 16 layers in one launch (single call), or those of the stages this call ran.
   // Reads P1 / P2 rows only (all written on this stream): before the join, beside the side stream's last weight gradients
+  if (phase == 3 && h->overlap && !g_lo_prof_on && h->async_handover) {      // see phase 1: the stage-4 range, without a join
+    LO_HIP(hipEventRecord(h->ev_pre, st));
+    LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
+    LO_TRY(vae_gn_finalize(h, 0x8u, false, G, ws, inv, h->side));
+    LO_HIP(hipEventRecord(h->ev_range, h->side));
+    h->range_pending = true;
+    return LO_OK;
+  }
   const bool early_norm = phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on;   // decoder layers finalized above
   LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0 && !early_norm, G, ws, inv, st));
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer

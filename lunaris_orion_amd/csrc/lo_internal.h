@@ -123,6 +123,7 @@ int lo_cast_f32_f16(const float* src, f16* dst, size_t n, hipStream_t st);
 int lo_scale_f32(float* x, size_t n, float scale, hipStream_t st);
 int lo_dp_pack_f16_run(const float* g, f16* wire, size_t n, float scale, hipStream_t st);     // data-parallel exchange helpers
 int lo_dp_unpack_f16_run(const f16* wire, float* g, size_t n, float inv_scale, hipStream_t st);
+int lo_dp_unpack_f16_sumsq_run(const f16* wire, float* g, size_t n, float inv_scale, float* scratch, hipStream_t st);
 int lo_dp_sum_shares_run(const void* recv, void* share, int world, size_t chunk, int is_f16, float inv_world, hipStream_t st);
 int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st);
 int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st);

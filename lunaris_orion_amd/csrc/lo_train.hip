@@ -455,6 +455,28 @@ __global__ __launch_bounds__(256) void lo_dp_unpack_f16_kernel(const f16* __rest
     }
   }
 }
+// unpack + the partial sums of squares of the unpacked values (the early part of the gradient norm: partial[blockIdx.x], same
+// layout as lo_sumsq_partial_kernel with gridDim.x blocks): one pass over the range instead of two
+__global__ __launch_bounds__(256) void lo_dp_unpack_f16_sumsq_kernel(const f16* __restrict__ wire, float* __restrict__ g, size_t n, float inv_scale,
+                                                                     float* __restrict__ partial) {
+  __shared__ float red[4];
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  float acc = 0.f;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const f16x4 v = *reinterpret_cast<const f16x4*>(wire + i);
+      const float a = (float)v[0] * inv_scale, b = (float)v[1] * inv_scale, c = (float)v[2] * inv_scale, d = (float)v[3] * inv_scale;
+      *reinterpret_cast<float4*>(g + i) = make_float4(a, b, c, d);
+      acc += a * a + b * b + c * c + d * d;
+    } else {
+      for (size_t j = i; j < n; ++j) { const float a = (float)wire[j] * inv_scale; g[j] = a; acc += a * a; }
+    }
+  }
+  const float w = lo_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 template <typename T>
 __global__ __launch_bounds__(256) void lo_dp_sum_shares_kernel(const T* __restrict__ recv, T* __restrict__ share, int world, size_t chunk, float inv_world) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -478,6 +500,12 @@ int lo_dp_unpack_f16_run(const f16* wire, float* g, size_t n, float inv_scale, h
   LoProfScope _p("lo_dp_unpack_f16", 0, 6.0 * n, st);
   hipLaunchKernelGGL(lo_dp_unpack_f16_kernel, dim3(lo_dp_blocks((n + 3) / 4)), dim3(256), 0, st, wire, g, n, inv_scale);
   LO_LAUNCH_CHECK("dp_unpack_f16");
+  return LO_OK;
+}
+int lo_dp_unpack_f16_sumsq_run(const f16* wire, float* g, size_t n, float inv_scale, float* scratch, hipStream_t st) {
+  LoProfScope _p("lo_dp_unpack_f16(+sumsq)", 0, 6.0 * n, st);
+  hipLaunchKernelGGL(lo_dp_unpack_f16_sumsq_kernel, dim3(LO_NORM_BLOCKS / 2), dim3(256), 0, st, wire, g, n, inv_scale, scratch + LO_NORM_BLOCKS / 2);
+  LO_LAUNCH_CHECK("dp_unpack_f16_sumsq");
   return LO_OK;
 }
 int lo_dp_sum_shares_run(const void* recv, void* share, int world, size_t chunk, int is_f16, float inv_world, hipStream_t st) {

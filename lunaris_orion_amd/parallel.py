@@ -51,6 +51,7 @@ class FlatGradSync:
         self.backend = dist.get_backend(group)
         self.compress = compress_fp16
         self.wire_scale = float(wire_scale)      # overflow on the wire needs a gradient element > 64
+        self.compress_min_elems = 4 << 20        # ranges below 16 MB (fp32) stay on the fp32 wire
         self.force = force                       # tests: issue the collectives even in a one-rank group
         if mode not in ("allreduce", "direct"):
             raise ValueError(f"unknown exchange mode {mode!r}")
@@ -80,9 +81,13 @@ class FlatGradSync:
             torch.mul(g, self.wire_scale, out=wire)
         return wire
 
-    def _unpack(self, wire: torch.Tensor, g: torch.Tensor) -> None:
+    def _unpack(self, wire: torch.Tensor, g: torch.Tensor, sumsq_scratch: Optional[int] = None) -> None:
         if g.is_cuda:
             from . import _lib
+            if sumsq_scratch is not None:        # the early part of the gradient norm in the same pass over the range
+                _lib.check(_lib.lib.lo_dp_unpack_f16_sumsq(wire.data_ptr(), g.data_ptr(), g.numel(), 1.0 / self.wire_scale, sumsq_scratch,
+                                                           _lib.stream_ptr()), "lo_dp_unpack_f16_sumsq")
+                return
             _lib.check(_lib.lib.lo_dp_unpack_f16(wire.data_ptr(), g.data_ptr(), g.numel(), 1.0 / self.wire_scale, _lib.stream_ptr()), "lo_dp_unpack_f16")
         else:
             g.copy_(wire)
@@ -127,20 +132,29 @@ class FlatGradSync:
             if self.backend != "nccl":
                 buf.div_(self.world)
 
-    def _run(self, g: torch.Tensor) -> None:
-        wire = self._pack(g) if self.compress else None
+    def _run(self, g: torch.Tensor, sumsq_scratch: Optional[int] = None) -> None:
+        # small ranges stay on the fp32 wire: the last range of a step (7.7 MB) is exposed and latency-bound, and two launches
+        # less on its chain are worth more than 4 MB less on the links
+        wire = self._pack(g) if self.compress and g.numel() >= self.compress_min_elems else None
         self._exchange(wire if wire is not None else g)
         if wire is not None:
-            self._unpack(wire, g)
+            self._unpack(wire, g, sumsq_scratch)
+        elif sumsq_scratch is not None and g.is_cuda:
+            from . import _lib
+            _lib.check(_lib.lib.lo_gradnorm_early_range(g.data_ptr(), 0, g.numel(), sumsq_scratch, _lib.stream_ptr()), "lo_gradnorm_early_range")
 
     # ---- public ---------------------------------------------------------------------------------------------------------------
-    def begin(self, g: torch.Tensor, then=None) -> bool:
+    def begin(self, g: torch.Tensor, then=None, pre=None, sumsq_scratch: Optional[int] = None) -> bool:
         """Enqueue the exchange of `g`.  `then` (GPU path only): a callable run right behind the exchange with the communication
-        stream current, i.e. on the averaged values and still beside the backward (the early part of the gradient norm).  Returns
-        whether `then` was enqueued."""
+        stream current, i.e. on the averaged values and still beside the backward (the early part of the gradient norm).  `pre`
+        (GPU path only): a callable run in front of the exchange with the communication stream current -- it makes that stream wait
+        for whoever finishes the range (lo_vae_wait_handover: the library's side stream; the compute stream is then not held up).
+        `sumsq_scratch` (GPU path only): device address of the optimizer's scratch -- the sum of squares of the averaged range is
+        left in scratch[512..1024) (lo_gradnorm_early_range), in the unpack pass itself on the fp16 wire.
+        Returns whether the hooks were enqueued (False: nothing was exchanged, or CPU tensors)."""
         if (self.world == 1 and not self.force) or g.numel() == 0:
             return False
-        self._phase_bytes.append(g.numel() * (2 if self.compress else g.element_size()))
+        self._phase_bytes.append(g.numel() * (2 if (self.compress and g.numel() >= self.compress_min_elems) else g.element_size()))
         if not g.is_cuda:
             self._run(g)                                  # CPU tensors (gloo tests): synchronous
             self._pending.append(None)
@@ -151,13 +165,15 @@ class FlatGradSync:
         ready.record()                                    # `g` is final once the work enqueued so far has run
         self._comm.wait_event(ready)
         with torch.cuda.stream(self._comm):
-            self._run(g)
+            if pre is not None:
+                pre()
+            self._run(g, sumsq_scratch)
             if then is not None:
                 then()
             done = torch.cuda.Event()
             done.record()
         self._pending.append(done)
-        return then is not None
+        return True
 
     def finish(self) -> None:
         ev = None

@@ -170,21 +170,25 @@ class VAEStepper:
             _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
             _lib.check(_lib.lib.lo_vae_stage4_grad_range(eng.handle, C.byref(b4), C.byref(e4)), "lo_vae_stage4_grad_range")
             assert e4.value == b.value and e.value == self.grads.numel()
+            # FlatGradSync runs the exchange on its own stream: the phases then hand their range over as an event for THAT stream
+            # (lo_vae_set_async_handover) instead of holding this one up until the side stream's weight gradients have finished
+            hooks = getattr(self.grad_sync, "supports_then", False)
+            _lib.check(_lib.lib.lo_vae_set_async_handover(eng.handle, 1 if hooks else 0), "lo_vae_set_async_handover")
+            def wait_range():
+                _lib.check(_lib.lib.lo_vae_wait_handover(eng.handle, _lib.stream_ptr()), "lo_vae_wait_handover")
+            kw = {"pre": wait_range} if hooks else {}
             _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 1, *bargs), "lo_vae_backward_phase(1)")
             # ... and so is the sum of squares of that range for clip_grad_norm_ (of the AVERAGED gradients): taken right behind the
             # exchange on the communication stream, beside the encoder backward; the tail of the step reads only the encoder range
-            def early_norm():
-                _lib.check(_lib.lib.lo_gradnorm_early_range(self.grads.data_ptr(), b.value, e.value, self.scratch.data_ptr(),
-                                                            _lib.stream_ptr()), "lo_gradnorm_early_range")
-            early = os.environ.get("LO_EARLY_NORM", "1") != "0" and getattr(self.grad_sync, "supports_then", False)
+            early = os.environ.get("LO_EARLY_NORM", "1") != "0" and hooks
             if early:
-                if self.grad_sync.begin(self.grads[b.value:e.value], then=early_norm):
+                if self.grad_sync.begin(self.grads[b.value:e.value], sumsq_scratch=self.scratch.data_ptr(), **kw):
                     self._presummed_begin = b.value
             else:
-                self.grad_sync.begin(self.grads[b.value:e.value])
+                self.grad_sync.begin(self.grads[b.value:e.value], **kw)
             if self.dp_three_phase:
                 _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 3, *bargs), "lo_vae_backward_phase(3)")
-                self.grad_sync.begin(self.grads[b4.value:e4.value])
+                self.grad_sync.begin(self.grads[b4.value:e4.value], **kw)
                 _lib.check(_lib.lib.lo_vae_backward_phase(eng.handle, 4, *bargs), "lo_vae_backward_phase(4)")
                 self.grad_sync.begin(self.grads[:b4.value])
             else:                    # two-call form: the whole encoder range after phase 2

@@ -51,9 +51,18 @@ def _worker(rank, world, port, q):
     n = flat16.numel()
     b1, b2 = (n // 10) * 3 + 1, (n // 10) * 1 + 3                # odd boundaries: remainder paths in every range
     d16 = FlatGradSync(mode="direct", compress_fp16=True)
+    d16.compress_min_elems = 0               # the fp16 wire on every range (the product keeps ranges below 16 MB on the fp32 wire)
     d16.begin(flat16[b1:]); d16.begin(flat16[b2:b1]); d16.begin(flat16[:b2])
     d16.finish()
     assert d16.bytes_per_phase() == [2 * (n - b1), 2 * (b1 - b2), 2 * b2]
+    # the product's rule: a range below `compress_min_elems` stays on the fp32 wire (the last, exposed range of a step)
+    mixed = FlatGradSync(mode="direct", compress_fp16=True)
+    mixed.compress_min_elems = b1 - b2 + 1
+    fm = torch.cat([g.flatten() for g in R.OracleTrainer(P).step(xs, es, 0.0, do_update=False)["grads"].values()])
+    mixed.begin(fm[b1:]); mixed.begin(fm[b2:b1]); mixed.begin(fm[:b2])
+    mixed.finish()
+    assert mixed.bytes_per_phase() == [2 * (n - b1), 4 * (b1 - b2), 4 * b2]
+    assert (fm[:b1] - flat[:b1]).abs().max().item() <= 1e-6 * flat.abs().max().item()      # fp32 wire: the all-reduce average
     # plain Python objects only (tensors through a spawn-context Queue need the producer to stay alive)
     res = {"sum": flat.double().sum().item(), "l2": flat.double().norm().item(),
            "direct_vs_allreduce": (flat_direct - flat[:-1]).abs().max().item(),

@@ -356,7 +356,9 @@ assert abs(out[0]["recon_loss"] - out[3]["recon_loss"]) <= 1e-5 and abs(out[0]["
 # ... and the default of an N > 1 run: the same on the fp16 wire (pack / share sum / unpack by the library's kernels, every range chained
 # on the communication stream)
 assert abs(out[0]["recon_loss"] - out[4]["recon_loss"]) < 1e-4 and abs(out[0]["grad_norm"] - out[4]["grad_norm"]) <= 2e-3 * out[0]["grad_norm"], out
-assert sync.exposed_ms_per_step() is not None and len(sync.bytes_per_phase()) == 3 and sum(sync.bytes_per_phase()) == 2 * m.flat_parameters().numel()
+nb = sync.bytes_per_phase(); nf = m.flat_parameters().numel()
+# ranges of 4 Mi elements and more travel as fp16, smaller ones (the last, exposed range) as fp32
+assert sync.exposed_ms_per_step() is not None and len(nb) == 3 and 2 * nf <= sum(nb) < 2.3 * nf, (nb, nf)
 # the hybrid step under data parallelism: gradient ranges of both models + the 5-float reward-mean exchange
 from oracle import teacher_ref as T
 from lunaris_orion_amd.teacher import LunarMoETeacher
