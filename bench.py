@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this stack needs dmabuf IPC (hipIpcGetMemHandle fails in the legacy mode); harmless for one process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 

@@ -26,6 +26,9 @@ import sys
 import time
 from pathlib import Path
 
+# multi-process GPU work on this stack needs dmabuf IPC (hipIpcGetMemHandle fails in the legacy mode); harmless for one process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
