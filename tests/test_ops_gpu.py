@@ -403,6 +403,18 @@ def test_direct_exchange_arithmetic_of_n_ranks_on_one_device(world, fp16_wire):
     out = torch.empty(n, dtype=torch.float32, device="cuda")
     if fp16_wire:
         _lib.check(lib.lib.lo_dp_unpack_f16(gathered.data_ptr(), out.data_ptr(), n, 1.0 / 1024.0, st), "unpack")
+        # the fused form (unpack + the early part of the gradient norm in one pass): same values bit for bit, and scratch[512..1024)
+        # holds the partial sums of squares lo_gradnorm_early_range would leave there
+        out2 = torch.empty_like(out)
+        scratch = torch.zeros(1028, dtype=torch.float32, device="cuda")
+        scratch2 = torch.zeros(1028, dtype=torch.float32, device="cuda")
+        _lib.check(lib.lib.lo_dp_unpack_f16_sumsq(gathered.data_ptr(), out2.data_ptr(), n, 1.0 / 1024.0, scratch.data_ptr(), st), "unpack_sumsq")
+        _lib.check(lib.lib.lo_gradnorm_early_range(out.data_ptr(), 0, n, scratch2.data_ptr(), st), "early_range")
+        sync()
+        assert torch.equal(out, out2)
+        ss = out.double().pow(2).sum().item()
+        assert abs(scratch[512:1024].double().sum().item() - ss) <= 1e-6 * ss and abs(scratch2[512:1024].double().sum().item() - ss) <= 1e-6 * ss
+        assert scratch[:512].abs().sum().item() == 0 and scratch[1024:].abs().sum().item() == 0
     else:
         out.copy_(gathered)
     sync()
