@@ -222,7 +222,7 @@ def main():
         dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
                                      "exposed_ms": grad_sync.exposed_ms_per_step()})
         dp_info = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": [d["device"] for d in ids],
-                   "device_names": sorted(set(d["name"] for d in ids)), "exchange": grad_sync.mode_used or args.dp_exchange,
+                   "device_names": sorted(set(d["name"] for d in ids)), "exchange": args.dp_exchange, "exchange_per_phase": grad_sync.modes_per_phase(),
                    "wire": "fp16" if args.dp_fp16 else "fp32", "bytes_per_phase": grad_sync.bytes_per_phase(),
                    "exchange_exposed_ms": max((d["exposed_ms"] for d in ids if d["exposed_ms"] is not None), default=None)}
 
@@ -260,7 +260,7 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (tools/rocpd_extract.py traffic); null when absent
         roof["traffic"] = None
         try:
-            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(pp))
+            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(pp))
             tr = json.load(open(tpath))["kernels"]
             roof["traffic_source"] = f"profiles/{os.path.basename(tpath)} (committed rocprofv3 PMC passes of this workload; not re-measured in this run)"
             key = next((k for k in tr if k in dom_name or dom_name.split("<")[0] in k), None)

@@ -169,12 +169,28 @@ int lo_vae_pack(LoVae* h, const float* flat_params, void* ws, void* stream);
 /* clip_grad_norm_ + AdamW (train_hybrid.py:913,921) + lo_vae_pack in ONE call, pipelined with the next forward: encoder stages
  * 1..3 (3 % of the parameters, what the next forward reads first) are updated on `stream`; the last encoder stage, the Linear
  * layers and the decoder (97 %), their fp16 casts and packs follow on the library's side stream beside the next encoder forward
- * (lo_vae_forward waits where it needs them).  p / g / m / v: the flat fp32 buffers of lo_vae_flat_elems() elements; scratch as for lo_clip_adamw_step; presummed as
- * for lo_clip_adamw_step_presummed.  Afterwards parameters from encoder.down4 on may still be in flight: call lo_vae_join before
+ * (lo_vae_forward waits where it needs them).  p / g / m / v: the flat fp32 buffers of lo_vae_flat_elems() elements; scratch as for lo_clip_adamw_step; flags:
+ * LO_OPT_PRESUMMED as for lo_clip_adamw_step_presummed, LO_OPT_SERIAL for the un-pipelined order.  The clip kernel also reads the
+ * plan's rendezvous-failure word (lo_vae_sync_fail_word): when set, the update is skipped on the device like one with a non-finite
+ * norm (GradScaler semantics, train_hybrid.py:917-923) -- and stays skipped until the host has looked.  Afterwards parameters from encoder.down4 on may still be in flight: call lo_vae_join before
  * reading them on any stream other than through this executor. */
+#define LO_OPT_PRESUMMED 1   /* scratch[512..1024) already holds the sum of squares of the phase-1 range */
+#define LO_OPT_SERIAL 2      /* no pipelining: norm, AdamW of everything and lo_vae_pack in order on `stream` */
 int lo_vae_optimizer_step(LoVae* h, float* p, const float* g, float* m, float* v, void* ws, float max_norm, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, int step, float* scratch, int presummed, void* stream);
+                          float beta2, float eps, float weight_decay, int step, float* scratch, int flags, void* stream);
 int lo_vae_join(LoVae* h, void* stream);   /* `stream` waits for the side-stream work of lo_vae_pack / lo_vae_optimizer_step */
+/* Factored Linear-layer gradients.  fc_mu | fc_logvar ([2L, 32768]) and decoder.fc ([32768, L]) hold 82 % of the parameters
+ * (lunar_generate.py:124-125, 165) and at batch B their weight gradients dW = dY^T X have rank B.  With the mode on (batch <= 128),
+ * a FUSED single-call lo_vae_backward does not write those two gradients into flat_grads: it keeps the factors (transposed,
+ * batch-padded fp16 copies in the workspace), takes their share of clip_grad_norm_'s norm (train_hybrid.py:913) from two B x B Gram
+ * matrices per layer -- ||dY^T X||_F^2 = sum_{b,b'} (dY dY^T)[b,b'] (X X^T)[b,b'] -- into the scratch set by
+ * lo_vae_set_gradnorm_scratch (required), and lo_vae_optimizer_step (LO_OPT_PRESUMMED required) forms each gradient tile with MFMA
+ * inside its AdamW pass (train_hybrid.py:921).  Same update to fp32 rounding; 12 of 38 bytes of HBM traffic per parameter less.
+ * Explicit-gradient backwards (the autograd path) and lo_vae_backward_phase always write every gradient.
+ * lo_vae_materialize_linear_grads: writes the two gradients of the last fused backward into flat_grads after all (tests, tools). */
+int lo_vae_set_linear_factored(LoVae* h, int on);
+int lo_vae_linear_factored(const LoVae* h);
+int lo_vae_materialize_linear_grads(LoVae* h, void* ws, float* flat_grads, void* stream);
 /* forward.  eps: explicit N(0,1) noise [B,L] or NULL (on-device counter RNG with `seed`).  target: images for the fused
  * MSE partial sums or NULL.  Outputs recon [B,3,128,128], mu, logvar [B,L] (fp32). */
 int lo_vae_forward(LoVae* h, const float* x, const float* eps, uint64_t seed, const float* flat_params, void* ws,
@@ -218,6 +234,19 @@ int lo_vae_backward(LoVae* h, const float* x, const float* flat_params, void* ws
  * 32-bit word of the workspace that a workgroup sets to 1 if its wait ran out (results of that step are then invalid); the host
  * reads it with the step's metrics.  No reference counterpart (aten::native_group_norm is a separate op there). */
 int lo_vae_sync_fail_word(const LoVae* h, size_t* byte_offset, int* fused_layers);
+
+/* The nn.Module boundary under torch.amp.GradScaler (train_hybrid.py:246-247, 289-297, 899-923: scaler.scale(loss).backward(),
+ * unscale_, clip_grad_norm_, step).  The upstream gradients an autograd node receives are already multiplied by the caller's loss
+ * scale; the backward carries fp16 activation gradients and needs them in a fixed range.  lo_grad_scale_pick: max |g| over up to five
+ * fp32 tensors (NULL = absent) -> scratch[0] = r = 2^k with max|g| * r in [2, 4), scratch[1] = 1 / r, scratch[2] = max |g|
+ * (scratch: >= 260 floats, device memory; no host synchronisation).  lo_scale_copy_dev: dst = src * scale_dev[0].
+ * lo_grad_unscale_dev: x *= scale_dev[0] in place; fail_word (may be NULL): the plan's rendezvous-failure word -- when it is set
+ * the result is NaN instead, which is how a lost launch reaches a foreign training loop (GradScaler.unscale_ /
+ * clip_grad_norm_ see it; there is no optimizer kernel of this library behind the autograd path that could skip the update). */
+int lo_grad_scale_pick(const float* g0, size_t n0, const float* g1, size_t n1, const float* g2, size_t n2, const float* g3, size_t n3,
+                       const float* g4, size_t n4, float* scratch, void* stream);
+int lo_scale_copy_dev(const float* src, float* dst, size_t n, const float* scale_dev, void* stream);
+int lo_grad_unscale_dev(float* x, size_t n, const float* scale_dev, const void* fail_word, void* stream);
 /* fp8 operand mode (LO_VAE_FP8_FWD, train_hybrid.py --mfma_precision fp8; BASELINE.json configs[4]): how many of the plan's 16
  * forward conv layers actually run on e4m3 operands.  The count depends on the batch: layers a fused-tap or patch-resident fp16
  * kernel owns at this batch size stay fp16 (11 at batch 2, 6 at batch 64).  0 when the mode is off. */

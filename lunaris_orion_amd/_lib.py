@@ -80,6 +80,9 @@ SIGNATURES = {
     "lo_vae_wait_handover": (i32, [vp, vp]),
     "lo_vae_optimizer_step": (i32, [vp, f32p, f32p, f32p, f32p, vp, flt, flt, flt, flt, flt, flt, i32, f32p, i32, vp]),
     "lo_vae_join": (i32, [vp, vp]),
+    "lo_vae_set_linear_factored": (i32, [vp, i32]),
+    "lo_vae_linear_factored": (i32, [vp]),
+    "lo_vae_materialize_linear_grads": (i32, [vp, vp, f32p, vp]),
     "lo_vae_gradnorm_presummed": (i32, [vp]),
     "lo_clip_adamw_step_presummed": (i32, [f32p, f32p, f32p, f32p, sz, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),
     "lo_vae_destroy": (None, [vp]),
@@ -106,6 +109,9 @@ SIGNATURES = {
     "lo_dp_unpack_f16_sumsq": (i32, [vp, f32p, sz, flt, f32p, vp]),
     "lo_dp_sum_shares": (i32, [vp, vp, i32, sz, i32, vp]),
     "lo_vae_sync_fail_word": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "lo_grad_scale_pick": (i32, [f32p, sz, f32p, sz, f32p, sz, f32p, sz, f32p, sz, f32p, vp]),
+    "lo_scale_copy_dev": (i32, [f32p, f32p, sz, f32p, vp]),
+    "lo_grad_unscale_dev": (i32, [f32p, sz, f32p, vp, vp]),
     "lo_vae_fp8_layers": (i32, [vp, C.POINTER(C.c_int)]),
     "lo_vae_stage4_grad_range": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblunaris_hip.so")
-SOURCES = ["lo_util.cpp", "lo_conv.hip", "lo_conv3.hip", "lo_wgrad3.hip", "lo_wgrad2.hip", "lo_norm.hip", "lo_edge.hip", "lo_train.hip", "lo_attn.hip", "lo_teacher.hip", "lo_api.hip"]
+SOURCES = ["lo_util.cpp", "lo_conv.hip", "lo_conv3.hip", "lo_wgrad3.hip", "lo_wgrad2.hip", "lo_norm.hip", "lo_edge.hip", "lo_train.hip", "lo_lowrank.hip", "lo_attn.hip", "lo_teacher.hip", "lo_api.hip"]
 HEADERS = ["lo_common.h", "lo_internal.h", os.path.join("..", "..", "include", "lunaris_hip.h")]
 
 

@@ -176,6 +176,23 @@ extern "C" int lo_dp_sum_shares(const void* recv, void* share, int world, size_t
   return lo_dp_sum_shares_run(recv, share, world, chunk, is_f16, 1.0f / (float)world, S(stream));
 }
 
+// upstream-gradient normalisation of the nn.Module boundary (see lo_train.hip)
+extern "C" int lo_grad_scale_pick(const float* g0, size_t n0, const float* g1, size_t n1, const float* g2, size_t n2, const float* g3,
+                                  size_t n3, const float* g4, size_t n4, float* scratch, void* stream) {
+  LO_REQUIRE(scratch, "lo_grad_scale_pick: null scratch");
+  const float* g[5] = {g0, g1, g2, g3, g4};
+  const size_t n[5] = {n0, n1, n2, n3, n4};
+  return lo_grad_scale_pick_run(g, n, scratch, S(stream));
+}
+extern "C" int lo_scale_copy_dev(const float* src, float* dst, size_t n, const float* scale_dev, void* stream) {
+  LO_REQUIRE(src && dst && scale_dev, "lo_scale_copy_dev: null argument");
+  return lo_scale_copy_dev_run(src, dst, n, scale_dev, S(stream));
+}
+extern "C" int lo_grad_unscale_dev(float* x, size_t n, const float* scale_dev, const void* fail_word, void* stream) {
+  LO_REQUIRE(x && scale_dev, "lo_grad_unscale_dev: null argument");
+  return lo_scale_dev_run(x, n, scale_dev, (const unsigned int*)fail_word, S(stream));
+}
+
 // =============================================================================================
 // VAE executor
 // =============================================================================================
@@ -278,6 +295,14 @@ struct LoVae {
   bool fuse_gnf;      // fuse GroupNorm + Mish of a conv output into that conv's epilogue (sample rendezvous between its workgroups)
   bool fuse_gna;      // fuse the GroupNorm-backward APPLY pass into the data-gradient epilogue that already carries its reduction
   size_t o_sync_fail; // one word: set by a workgroup whose rendezvous poll ran out (never, unless a launch was lost)
+  // rank-B Linear-layer weight gradients kept as their factors (lo_lowrank.hip): transposed, batch-padded factor copies
+  // dml^T [2L][Bp], xflat^T [32768][Bp], Gfc^T [32768][Bp], z^T [L][Bp] (one contiguous block), Gram scratch; fac_ready: a fused
+  // backward has left this step's factors and the Gram part of the gradient norm; fac_scale: 1 / loss scale of that backward
+  bool lin_factored, fac_ready;
+  int Bp;
+  size_t o_fac_dmlT, o_fac_xT, o_fac_gfcT, o_fac_zT, o_gram;
+  float fac_scale;
+  int n_cu;           // compute units of the device (partition) this plan was made on; 0 = no device: nothing that waits across workgroups is planned
   const void* sync_for_ws;
   // fp8 operand mode of the forward convs (lo_vae_create_ex flag LO_VAE_FP8_FWD)
   bool fp8_fwd;
@@ -454,6 +479,14 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->o_packjobs = ar.take(sizeof(LoPackJob) * 64);
   h->packjobs_for_ws = h->packjobs_for_params = nullptr;
   h->o_sync_fail = ar.take(256);
+  h->Bp = lo_lowrank_bp(B);
+  h->o_fac_dmlT = ar.take((size_t)2 * L * h->Bp * 2);
+  h->o_fac_xT = ar.take((size_t)32768 * h->Bp * 2);
+  h->o_fac_gfcT = ar.take((size_t)32768 * h->Bp * 2);
+  h->o_fac_zT = ar.take((size_t)L * h->Bp * 2);
+  h->o_gram = ar.take((size_t)2 * 128 * 128 * 4);
+  h->lin_factored = h->fac_ready = false;
+  h->fac_scale = 1.f;
 
   // ---- fp8 operand mode: every forward conv whose geometry the e4m3 igemm covers (Cin % 128 == 0: the 128 / 256 / 512
   // channel ResBlock and stride-2 convs, the 512 / 256 / 128 channel transposed convs) reads an e4m3 copy of its input,
@@ -526,6 +559,17 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   // removes (a read of dy and v, a write of dv: 12-27 us per layer) costs more than the wait, and dy is never stored at all
   h->fuse_gna = h->fuse_gnb && !(getenv("LO_GNB_APPLY_FUSE") && atoi(getenv("LO_GNB_APPLY_FUSE")) == 0);
   h->sync_for_ws = nullptr;
+  // Workgroups that wait for each other inside an ordinary launch (sample rendezvous) make progress only if every workgroup of the
+  // grid can be resident: each fused kernel fits at least one workgroup per CU, workgroups of other kernels on the same CUs (the side
+  // stream's weight gradients) finish without waiting for anybody, so a grid of at most one workgroup per compute unit OF THIS
+  // DEVICE -- 256 in SPX mode, 32 on a CPX partition -- always drains.  The count is the device's own, not a constant.
+  h->n_cu = 0;
+  {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) h->n_cu = ncu;
+    else (void)hipGetLastError();
+  }
+  if (h->n_cu < 256) h->fuse_gnf = false;      // the forward fusion's two-round rule (lo_conv_gn_fuse_tiles) was only ever checked on 256 CUs
   {
     auto plan = [&](ConvLayer& c, bool first) {
       c.gnf = h->fuse_gnf && !first && !c.sk_fwd && lo_conv_gn_fuse_tiles(c.gf, &c.gnf_mts, &c.gnf_nt);
@@ -584,7 +628,20 @@ extern "C" int lo_vae_set_gradnorm_scratch(LoVae* h, float* scratch) {
   h->norm_scratch = scratch;
   return LO_OK;
 }
-extern "C" int lo_vae_gradnorm_presummed(const LoVae* h) { return h && h->norm_scratch && h->overlap && !g_lo_prof_on; }
+extern "C" int lo_vae_gradnorm_presummed(const LoVae* h) { return h && h->norm_scratch && ((h->overlap && !g_lo_prof_on) || h->lin_factored); }
+// Factored Linear-layer gradients (lo_lowrank.hip): with the mode on, a FUSED single-call lo_vae_backward does not write the weight
+// gradients of fc_mu | fc_logvar and decoder.fc into flat_grads (those ranges keep whatever they held); it leaves their factors and
+// their share of the gradient norm (needs lo_vae_set_gradnorm_scratch), and lo_vae_optimizer_step forms the gradient tiles inside
+// its AdamW pass.  Batch <= 128.  Explicit-gradient (autograd) backwards and the phased data-parallel backward are not affected.
+extern "C" int lo_vae_set_linear_factored(LoVae* h, int on) {
+  LO_REQUIRE(h, "lo_vae_set_linear_factored: null handle");
+  if (on) LO_REQUIRE(lo_lowrank_applies(h->B, 2 * h->L, 32768) && lo_lowrank_applies(h->B, 32768, h->L),
+                     "lo_vae_set_linear_factored: batch %d is above the rank the factored update is built for (128)", h->B);
+  h->lin_factored = on != 0;
+  h->fac_ready = false;
+  return LO_OK;
+}
+extern "C" int lo_vae_linear_factored(const LoVae* h) { return h && h->lin_factored ? 1 : 0; }
 extern "C" int lo_vae_num_params(const LoVae* h) { return h->nparam; }
 extern "C" size_t lo_vae_param_offset(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_off[i] : (size_t)-1; }
 extern "C" size_t lo_vae_param_numel(const LoVae* h, int i) { return (i >= 0 && i < h->nparam) ? h->p_numel[i] : 0; }
@@ -764,7 +821,11 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
     LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8_s4 - h->n_packjobs8_enc, h->pack_blocks8_s4 - h->pack_blocks8_enc, sd, h->pack_blocks8_enc));
   LO_TRY(vae_side_record(h, 2, sd));
   // level 3: fc_mu / fc_logvar (weights + biases are adjacent: [bh, bd)) and their fp16 copy
-  if (fuse_cast) {
+  if (h->lin_factored) {
+    LO_TRY(lo_adamw_lowrank(P + bh, M + bh, V + bh, WSP(f16, h->o_wp_head), WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768, h->B,
+                            h->fac_scale, norm, lr, b1, b2, eps, wd, step, sd));
+    LO_TRY(adam(bh + nh, bd));
+  } else if (fuse_cast) {
     LO_TRY(adam(bh, bh + nh, WSP(f16, h->o_wp_head)));
     LO_TRY(adam(bh + nh, bd));
   } else {
@@ -773,7 +834,11 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
   }
   LO_TRY(vae_side_record(h, 3, sd));
   // level 4: decoder.fc, the decoder and final convs
-  if (fuse_cast) {
+  if (h->lin_factored) {
+    LO_TRY(lo_adamw_lowrank(P + bd, M + bd, V + bd, WSP(f16, h->o_wp_dfc), WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L, h->B,
+                            h->fac_scale, norm, lr, b1, b2, eps, wd, step, sd));
+    LO_TRY(adam(bd + nd, n));
+  } else if (fuse_cast) {
     LO_TRY(adam(bd, bd + nd, WSP(f16, h->o_wp_dfc)));
     LO_TRY(adam(bd + nd, n));
   } else {
@@ -845,20 +910,46 @@ extern "C" int lo_vae_pack(LoVae* h, const float* P, void* ws, void* stream) {
 // `stream`.  presummed != 0: scratch[512..1024) already holds the sum of squares of [b, n) (lo_vae_set_gradnorm_scratch).
 // ---------------------------------------------------------------------------------------------
 extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* M, float* V, void* ws, float max_norm, float lr,
-                                     float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, int presummed,
+                                     float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, int flags,
                                      void* stream) {
   LO_REQUIRE(h && P && G && M && V && ws && scratch, "lo_vae_optimizer_step: null argument");
+  LO_REQUIRE((flags & ~(LO_OPT_PRESUMMED | LO_OPT_SERIAL)) == 0, "lo_vae_optimizer_step: unknown flag bits 0x%x", flags);
+  const int presummed = flags & LO_OPT_PRESUMMED;
+  const bool serial = (flags & LO_OPT_SERIAL) != 0;
+  // a fused-GroupNorm rendezvous of this step's launches that ran out left garbage in the gradients: the clip kernel reads the word
+  // and skips the update on the device, like a non-finite norm (ADVICE r3 / VERDICT r3 item 1b)
+  const unsigned int* fail = WSP(unsigned int, h->o_sync_fail);
   hipStream_t st = S(stream);
+  if (h->lin_factored) {
+    if (!h->fac_ready || !presummed) {
+      lo_set_error("lo_vae_optimizer_step: the factored Linear-gradient mode needs a fused lo_vae_backward (with the gradient-norm scratch set) "
+                   "before every step, and LO_OPT_PRESUMMED");
+      return LO_ERR_STATE;
+    }
+    h->fac_ready = false;
+  }
   LO_TRY(vae_flush_deferred(h, nullptr));     // two optimizer steps without a forward in between
   // b: begin of the range whose sum of squares may be presummed (fc_mu.weight);  b4: begin of the encoder's last stage -- the
   // stream itself only updates stages 1..3 (3 % of the parameters, what the next forward reads in its first 0.45 ms)
   const size_t n = h->flat_elems, b = h->p_off[h->idx_fc_mu_w], b4 = h->p_off[h->enc[3][0].p_w];
   LO_TRY(vae_ensure_pack_jobs(h, P, ws, st));
-  if (presummed) LO_TRY(lo_gradnorm_split(G, b, max_norm, scratch, scratch + 1024, st));
-  else LO_TRY(lo_gradnorm(G, n, max_norm, scratch, scratch + 1024, st));
+  if (presummed) LO_TRY(lo_gradnorm_split(G, b, max_norm, scratch, scratch + 1024, st, fail));
+  else LO_TRY(lo_gradnorm(G, n, max_norm, scratch, scratch + 1024, st, fail));
   const float* norm = scratch + 1024;
-  if (!(h->overlap && !g_lo_prof_on)) {
-    LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
+  if (serial || !(h->overlap && !g_lo_prof_on)) {
+    if (h->lin_factored) {
+      const int L = h->L;
+      const size_t bh = h->p_off[h->idx_fc_mu_w], nh = (size_t)2 * L * 32768, bd = h->p_off[h->idx_dfc_w], nd = (size_t)32768 * L;
+      LO_TRY(lo_adamw(P, G, M, V, bh, norm, lr, beta1, beta2, eps, weight_decay, step, st));
+      LO_TRY(lo_adamw_lowrank(P + bh, M + bh, V + bh, nullptr, WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768, h->B, h->fac_scale, norm,
+                              lr, beta1, beta2, eps, weight_decay, step, st));
+      LO_TRY(lo_adamw(P + bh + nh, G + bh + nh, M + bh + nh, V + bh + nh, bd - (bh + nh), norm, lr, beta1, beta2, eps, weight_decay, step, st));
+      LO_TRY(lo_adamw_lowrank(P + bd, M + bd, V + bd, nullptr, WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L, h->B, h->fac_scale, norm,
+                              lr, beta1, beta2, eps, weight_decay, step, st));
+      LO_TRY(lo_adamw(P + bd + nd, G + bd + nd, M + bd + nd, V + bd + nd, n - (bd + nd), norm, lr, beta1, beta2, eps, weight_decay, step, st));
+    } else {
+      LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
+    }
     return lo_vae_pack(h, P, ws, stream);
   }
   LoStopEventGuard stop_guard_;
@@ -1189,7 +1280,7 @@ static int conv_gn_bwd(LoVae* h, ConvLayer& c, const f16* dy, const f16* other, 
       // ... only where the whole grid is resident at once (one workgroup per CU): on the 64-channel 64 x 64 layers (1 024 tiles at
       // batch 64, two rounds of 512) the fused launch is 32-34 us longer than the 27 us pass it replaces, and the step is 0.6 %
       // faster without it there (22 309-22 332 against 22 185-22 202; nowhere: 22 238-22 316)
-      if (h->fuse_gna && lo_conv_gnb_apply_tiles(c.gd, &mts, &nt) && mts == prod->np1 && h->B * mts * nt <= 256) {
+      if (h->fuse_gna && lo_conv_gnb_apply_tiles(c.gd, &mts, &nt) && mts == prod->np1 && h->B * mts * nt <= h->n_cu) {
         gb.dv = WSP(f16, prod->o_dv); gb.P2 = WSP(float, prod->o_P2);
         gb.counter = WSP(unsigned int, prod->o_bcnt);
         gb.target = (++prod->gba_epoch) * (unsigned)mts;
@@ -1314,6 +1405,10 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   LO_TRY(vae_wait_level(h, st, 5));   // the transposed Linear copies (and, after a lo_vae_pack between forward and backward, everything)
   const int B = h->B, L = h->L;
   const float inv = 1.0f / loss_scale;
+  // the Linear layers' weight gradients stay factored (lo_lowrank.hip): the fused single-call backward of a stepper only
+  const bool fac = h->lin_factored && fused && phase == 0;
+  if (fac && !h->norm_scratch) { lo_set_error("lo_vae_backward: the factored Linear-gradient mode needs lo_vae_set_gradnorm_scratch"); return LO_ERR_STATE; }
+  if (phase == 0 || phase == 1) h->fac_ready = false;
   LoStopEventGuard stop_guard_;
   hipEvent_t early_ev = nullptr;      // ev_pre when part A's last launch carries it (single-call backward with the early gradient norm)
   f16* Ga = WSP(f16, h->o_G[0]);
@@ -1332,7 +1427,10 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   // into) by exactly one gradient kernel
   // (gradient-only and independent of everything on the chain: on the side stream when there is one -- in order behind the previous
   // optimizer tail there, in front of every weight gradient of this backward, and joined before anybody reads the buffer)
-  LO_TRY(vae_zero_gaps(h, G, (h->overlap && !g_lo_prof_on) ? h->side : st));
+  // Only for the fused step, whose gradient buffer is the stepper's own: behind the module boundary (fused == 0, phase 5) G is a fresh
+  // block of PyTorch's caching allocator, which is ordered with respect to the CALLER's stream only -- a side-stream write could land
+  // while earlier work of the caller's stream still uses the recycled block.
+  LO_TRY(vae_zero_gaps(h, G, (h->overlap && !g_lo_prof_on && fused && phase != 5) ? h->side : st));
   // ---- final conv (+tanh, + fused MSE gradient)
   {
     ConvLayer& u4 = h->dec[3];
@@ -1374,7 +1472,13 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     if (ovl) LO_HIP(hipStreamWaitEvent(h->side, e, 0));
   }
   LO_TRY(lo_colsum_f16(Gfc, GRD(h->idx_dfc_b), B, 32768, inv, gs));
-  LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gfc, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, gs));
+  if (fac) {
+    // dW = Gfc^T z is never formed: its factors, transposed and batch-padded, are what the optimizer's AdamW pass multiplies
+    LO_TRY(lo_transpose_pad_f16(Gfc, WSP(f16, h->o_fac_gfcT), B, 32768, h->Bp, gs));
+    LO_TRY(lo_transpose_pad_f16(WSP(f16, h->o_z), WSP(f16, h->o_fac_zT), B, L, h->Bp, gs));
+  } else {
+    LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gfc, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, gs));
+  }
   LO_TRY(lo_conv_run(h->g_dfc_d, Gfc, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
                      h->dfcd_split, st));
   LO_TRY(lo_splitk_reduce(WSP(float, h->o_slab_dz), nullptr, phase == 5 ? sp->dz : nullptr, WSP(f16, h->o_dz), B, L, h->dfcd_split, st));
@@ -1402,7 +1506,12 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   }
   // ---- encoder heads (bias + weight gradient beside the chain, see decoder.fc above)
   LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, gs));
-  LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, gs));
+  if (fac) {
+    LO_TRY(lo_transpose_pad_f16(WSP(f16, h->o_dml), WSP(f16, h->o_fac_dmlT), B, 2 * L, h->Bp, gs));
+    LO_TRY(lo_transpose_pad_f16(WSP(f16, h->o_xflat), WSP(f16, h->o_fac_xT), B, 32768, h->Bp, gs));
+  } else {
+    LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, gs));
+  }
   LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
   early_ev = (((phase == 0 && h->norm_scratch) || (phase == 1 && h->async_handover)) && ovl && !lo_event_marker()) ? h->ev_pre : nullptr;
   if (early_ev) g_lo_stop_event = early_ev;                                  // the early-norm hand-over rides on part A's last launch
@@ -1428,13 +1537,32 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     LO_TRY(lo_conv_run(h->g_head_d, WSP(f16, h->o_dml), WSP(f16, h->o_wp_head_t), nullptr, nullptr, Gb, nullptr, nullptr, 1, st));
     LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));
   }
-  if (phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on) {
+  const bool side_ok = h->overlap && !g_lo_prof_on;
+  const bool early_norm = phase == 0 && h->norm_scratch && (side_ok || fac);      // decoder layers finalized here, norm of the phase-1 range taken early
+  if (early_norm) {
     // everything from fc_mu.weight on is final once the decoder's side-stream weight gradients are: order the early
     // sum of squares after both streams' part A and let it run on the side stream beside the encoder backward
-    if (!early_ev) LO_HIP(hipEventRecord(h->ev_pre, st));
-    LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
-    LO_TRY(vae_gn_finalize(h, 0u, true, G, ws, inv, h->side));      // the decoder's GroupNorm / bias gradients belong to the range
-    LO_TRY(lo_sumsq_range(G, h->p_off[h->idx_fc_mu_w], h->flat_elems, h->norm_scratch, h->side));
+    hipStream_t ns = side_ok ? h->side : st;
+    if (side_ok) {
+      if (!early_ev) LO_HIP(hipEventRecord(h->ev_pre, st));
+      LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
+    }
+    LO_TRY(vae_gn_finalize(h, 0u, true, G, ws, inv, ns));      // the decoder's GroupNorm / bias gradients belong to the range
+    if (fac) {
+      // scratch[512..1024) = partial sums of squares of the range: [512, 767) everything behind decoder.fc.weight (decoder.fc.bias,
+      // the decoder's convs and GroupNorms, the final conv), [767] the two head biases, [768, 896) fc_mu | fc_logvar weights and
+      // [896, 1024) decoder.fc.weight from the Gram matrices of their factors -- no pass over the 50 M elements they stand for
+      const size_t bh = h->p_off[h->idx_fc_mu_w], nh = (size_t)2 * L * 32768, bd = h->p_off[h->idx_dfc_w], nd = (size_t)32768 * L;
+      float* sc = h->norm_scratch;
+      LO_TRY(lo_sumsq_blocks(G + bd + nd, h->flat_elems - (bd + nd), sc + 512, 255, ns));
+      LO_TRY(lo_sumsq_blocks(G + bh + nh, bd - (bh + nh), sc + 767, 1, ns));
+      LO_TRY(lo_lowrank_sumsq(WSP(f16, h->o_dml), 2 * L, WSP(f16, h->o_xflat), 32768, B, inv, WSP(float, h->o_gram), sc + 768, 128, ns));
+      LO_TRY(lo_lowrank_sumsq(WSP(f16, h->o_z), L, WSP(f16, h->o_gfc), 32768, B, inv, WSP(float, h->o_gram) + 128 * 128, sc + 896, 128, ns));
+      h->fac_scale = inv;
+      h->fac_ready = true;
+    } else {
+      LO_TRY(lo_sumsq_range(G, h->p_off[h->idx_fc_mu_w], h->flat_elems, h->norm_scratch, ns));
+    }
   }
   if (phase == 1) {
     // two-call form: every gradient from fc_mu.weight to the end of the buffer is complete now -> join the side
@@ -1492,7 +1620,6 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     h->range_pending = true;
     return LO_OK;
   }
-  const bool early_norm = phase == 0 && h->norm_scratch && h->overlap && !g_lo_prof_on;   // decoder layers finalized above
   LO_TRY(vae_gn_finalize(h, phase == 3 ? 0x8u : (phase == 4 ? 0x7u : 0xFu), phase == 0 && !early_norm, G, ws, inv, st));
   // ---- join the side stream (all weight gradients written) before anything that consumes the gradient buffer
   if (h->overlap && !g_lo_prof_on) {
@@ -1518,4 +1645,16 @@ extern "C" int lo_vae_encoder_backward(LoVae* h, const float* x, const float* P,
                                        void* stream) {
   LoSplitBwd sp{nullptr, {nullptr, nullptr, nullptr}, {gskip0, gskip1, gskip2}};
   return vae_backward_impl(h, 6, x, P, ws, nullptr, nullptr, 0, nullptr, gmu, glv, loss_scale, G, stream, &sp);
+}
+
+// The Linear-layer weight gradients of the last fused backward written out after all (tests, tools, anybody who reads
+// parameter_grads() in the factored mode): the same MFMA tiles the AdamW pass forms, stored to flat_grads instead.  `stream` must be
+// ordered behind that backward (it is, for the stream the backward ran on).
+extern "C" int lo_vae_materialize_linear_grads(LoVae* h, void* ws, float* G, void* stream) {
+  LO_REQUIRE(h && ws && G, "lo_vae_materialize_linear_grads: null argument");
+  if (!h->lin_factored) return LO_OK;           // the backward wrote them itself
+  hipStream_t st = S(stream);
+  const int L = h->L;
+  LO_TRY(lo_lowrank_materialize(G + h->p_off[h->idx_fc_mu_w], WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768, h->B, h->fac_scale, st));
+  return lo_lowrank_materialize(G + h->p_off[h->idx_dfc_w], WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L, h->B, h->fac_scale, st);
 }

@@ -126,9 +126,15 @@ int lo_dp_unpack_f16_run(const f16* wire, float* g, size_t n, float inv_scale, h
 int lo_dp_unpack_f16_sumsq_run(const f16* wire, float* g, size_t n, float inv_scale, float* scratch, hipStream_t st);
 int lo_dp_sum_shares_run(const void* recv, void* share, int world, size_t chunk, int is_f16, float inv_world, hipStream_t st);
 int lo_transpose_cast(const float* src, f16* dst, int R, int C, hipStream_t st);
-int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st);
+int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial, float* norm_out, hipStream_t st,
+                const unsigned int* fail = nullptr);   // fail: the engine's rendezvous-failure word (non-zero skips the update)
 int lo_sumsq_range(const float* g, size_t begin, size_t end, float* partial, hipStream_t st);   // -> partial[512 .. 1024)
-int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st);
+int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st,
+                      const unsigned int* fail = nullptr);
+// upstream-gradient normalisation of the nn.Module boundary (GradScaler-scaled gradients; see lo_train.hip)
+int lo_grad_scale_pick_run(const float* const g[5], const size_t n[5], float* scratch, hipStream_t st);
+int lo_scale_copy_dev_run(const float* src, float* dst, size_t n, const float* scale_dev, hipStream_t st);
+int lo_scale_dev_run(float* x, size_t n, const float* scale_dev, const unsigned int* fail, hipStream_t st);
 int lo_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float lr, float beta1, float beta2,
              float eps, float wd, int step, hipStream_t st, f16* cast = nullptr);
 
@@ -141,3 +147,14 @@ int lo_selfattn2d_bwd(const float* x, const float* wq, const float* wk, const fl
                       const float* k, const float* v, const float* dy, float* scratch, float* dx, float* dwq, float* dbq,
                       float* dwk, float* dbk, float* dwv, float* dbv, float* dgamma, int B, int C, int N, hipStream_t st);
 int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st);
+
+// lo_lowrank.hip: rank-B Linear-layer weight gradients as factors (Gram-matrix norm, AdamW that forms the gradient tiles itself)
+int lo_lowrank_bp(int B);                          // batch rounded up to the MFMA K step (32)
+bool lo_lowrank_applies(int B, int N, int K);
+int lo_transpose_pad_f16(const f16* src, f16* dst, int R, int C, int Rp, hipStream_t st);
+int lo_lowrank_sumsq(const f16* fshort, int n_short, const f16* flong, int n_long, int B, float scale, float* gram, float* partial,
+                     int nslots, hipStream_t st);
+int lo_adamw_lowrank(float* p, float* m, float* v, f16* cast, const f16* xt, const f16* yt, int N, int K, int B, float gscale,
+                     const float* norm, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t st);
+int lo_lowrank_materialize(float* gout, const f16* xt, const f16* yt, int N, int K, int B, float gscale, hipStream_t st);
+int lo_sumsq_blocks(const float* g, size_t n, float* partial, int nblocks, hipStream_t st);   // lo_train.hip: partial[0 .. nblocks)

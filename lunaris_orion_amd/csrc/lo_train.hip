@@ -218,8 +218,12 @@ __global__ __launch_bounds__(256) void lo_sumsq_partial_kernel(const float* __re
 }
 // norm_out: [0] = total L2 norm, [1] = clip coefficient, [2] = 1 if finite else 0, [3] += 1 if not finite (sticky count of
 // skipped updates: the host halves its loss scale when it sees the count move, like torch.cuda.amp.GradScaler)
+// fail (may be null): the engine's "a fused-GroupNorm rendezvous ran out" word (lo_common.h, lo_arrive_and_wait).  Non-zero = some
+// launch of this step produced garbage: the update is skipped exactly like one with a non-finite norm (the word is sticky: every
+// later update is skipped too, until the host has seen it -- VAEStepper.metrics() / save_checkpoint raise).  It does not count as
+// a loss-scale overflow (norm_out[3] is left alone).
 __global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* __restrict__ partial, int n, float max_norm,
-                                                                   float* __restrict__ norm_out) {
+                                                                   float* __restrict__ norm_out, const unsigned int* __restrict__ fail) {
   __shared__ double red[256];
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) a += (double)partial[i];
@@ -232,9 +236,10 @@ __global__ __launch_bounds__(256) void lo_gradnorm_finalize_kernel(const float* 
     float coef = max_norm / (norm + 1e-6f);
     if (coef > 1.0f) coef = 1.0f;
     bool finite = isfinite(norm);
+    const bool lost = fail && *fail != 0u;
     norm_out[0] = norm;
-    norm_out[1] = finite ? coef : 0.f;
-    norm_out[2] = finite ? 1.f : 0.f;
+    norm_out[1] = (finite && !lost) ? coef : 0.f;
+    norm_out[2] = (finite && !lost) ? 1.f : 0.f;
     if (!finite) norm_out[3] += 1.f;
   }
 }
@@ -384,19 +389,27 @@ int lo_sumsq_range(const float* g, size_t begin, size_t end, float* partial, hip
   LO_LAUNCH_CHECK("sumsq_range");
   return LO_OK;
 }
-int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st) {
+int lo_sumsq_blocks(const float* g, size_t n, float* partial, int nblocks, hipStream_t st) {
+  LoProfScope _p("lo_gradnorm (early range)", 0, 4.0 * n, st);
+  hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(nblocks), dim3(256), 0, st, g, n, partial);
+  LO_LAUNCH_CHECK("sumsq_blocks");
+  return LO_OK;
+}
+int lo_gradnorm_split(const float* g, size_t presummed_begin, float max_norm, float* partial, float* norm_out, hipStream_t st,
+                      const unsigned int* fail) {
   LoProfScope _p("lo_gradnorm", 0, 4.0 * presummed_begin, st);
   hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS / 2), dim3(256), 0, st, g, presummed_begin, partial);
   LO_LAUNCH_CHECK("sumsq_head");
-  hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out);
+  hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out, fail);
   LO_LAUNCH_CHECK("gradnorm_finalize");
   return LO_OK;
 }
-int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial /*>=1024*/, float* norm_out, hipStream_t st) {
+int lo_gradnorm(const float* g, size_t n, float max_norm, float* partial /*>=1024*/, float* norm_out, hipStream_t st,
+                const unsigned int* fail) {
   LoProfScope _p("lo_gradnorm", 0, 4.0 * n, st);
   hipLaunchKernelGGL(lo_sumsq_partial_kernel, dim3(LO_NORM_BLOCKS), dim3(256), 0, st, g, n, partial);
   LO_LAUNCH_CHECK("sumsq");
-  hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out);
+  hipLaunchKernelGGL(lo_gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, LO_NORM_BLOCKS, max_norm, norm_out, fail);
   LO_LAUNCH_CHECK("gradnorm_finalize");
   return LO_OK;
 }
@@ -432,15 +445,18 @@ int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st) {
 //            added in rank order: the same bits on every run)
 //   unpack:  g[i] = float(wire[i]) * inv_scale
 // ---------------------------------------------------------------------------------------------
+// saturating: a pre-clip gradient element above 65504 / scale must not become inf on the wire -- the averaged norm would be
+// non-finite, the update skipped and the loss scale halved for an overflow the loss scale did not cause; NaN stays NaN
+__device__ __forceinline__ float lo_sat16(float x) { return x != x ? x : fminf(fmaxf(x, -65504.0f), 65504.0f); }
 __global__ __launch_bounds__(256) void lo_dp_pack_f16_kernel(const float* __restrict__ g, f16* __restrict__ wire, size_t n, float scale) {
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
       const float4 v = *reinterpret_cast<const float4*>(g + i);
-      f16x4 o = {(f16)(v.x * scale), (f16)(v.y * scale), (f16)(v.z * scale), (f16)(v.w * scale)};
+      f16x4 o = {(f16)lo_sat16(v.x * scale), (f16)lo_sat16(v.y * scale), (f16)lo_sat16(v.z * scale), (f16)lo_sat16(v.w * scale)};
       *reinterpret_cast<f16x4*>(wire + i) = o;
     } else {
-      for (size_t j = i; j < n; ++j) wire[j] = (f16)(g[j] * scale);
+      for (size_t j = i; j < n; ++j) wire[j] = (f16)lo_sat16(g[j] * scale);
     }
   }
 }
@@ -513,5 +529,110 @@ int lo_dp_sum_shares_run(const void* recv, void* share, int world, size_t chunk,
   if (is_f16) hipLaunchKernelGGL((lo_dp_sum_shares_kernel<f16>), dim3(lo_dp_blocks(chunk)), dim3(256), 0, st, (const f16*)recv, (f16*)share, world, chunk, inv_world);
   else hipLaunchKernelGGL((lo_dp_sum_shares_kernel<float>), dim3(lo_dp_blocks(chunk)), dim3(256), 0, st, (const float*)recv, (float*)share, world, chunk, inv_world);
   LO_LAUNCH_CHECK("dp_sum_shares");
+  return LO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// nn.Module boundary under torch.amp.GradScaler (train_hybrid.py:246-247, 289-297, 899-923).  The autograd nodes receive upstream
+// gradients that a foreign loop has already multiplied by ITS loss scale (GradScaler starts at 65 536); the backward carries fp16
+// activation gradients, so it needs them in a fixed range whatever that scale is.  lo_grad_scale_pick takes max |g| over the
+// upstream tensors and leaves r = 2^k with max|g| * r in [2, 4) (and 1/r) in device memory -- a power of two, so scaling by r
+// before the backward and by 1/r after it is exact in fp32 and no host synchronisation is needed; all-zero or non-finite
+// gradients give r = 1 (non-finite values then propagate into the parameter gradients, where GradScaler.unscale_ finds them).
+// ---------------------------------------------------------------------------------------------
+struct LoAmaxJobs { const float* p[5]; size_t n[5]; };
+__global__ __launch_bounds__(256) void lo_amax_partial_kernel(LoAmaxJobs J, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float a = 0.f;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float* g = J.p[j];
+    if (!g) continue;
+    const size_t n = J.n[j], n4 = n / 4;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (size_t)gridDim.x * 256) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(g)[k];
+      a = fmaxf(a, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (size_t k = n4 * 4; k < n; ++k) a = fmaxf(a, fabsf(g[k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void lo_amax_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ out2) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a = fmaxf(a, partial[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float r = 1.0f;
+    if (a > 0.f && isfinite(a)) {
+      int e;
+      (void)frexpf(a, &e);                 // a = m 2^e, m in [0.5, 1)
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      r = ldexpf(1.0f, 2 - e);             // a r in [2, 4)
+    }
+    out2[0] = r;
+    out2[1] = 1.0f / r;
+    out2[2] = a;
+  }
+}
+__global__ __launch_bounds__(256) void lo_scale_copy_dev_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n,
+                                                                const float* __restrict__ scale) {
+  const float s = scale[0];
+  const size_t n4 = n / 4;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (size_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(src)[k];
+    v *= s;
+    reinterpret_cast<f32x4*>(dst)[k] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t k = n4 * 4; k < n; ++k) dst[k] = src[k] * s;
+}
+// x *= scale[0]; a set rendezvous-failure word poisons the result with NaN instead (the autograd path has no optimizer kernel of
+// this library behind it that could skip the update: a foreign loop's GradScaler / clip_grad_norm_ sees the NaN)
+__global__ __launch_bounds__(256) void lo_scale_dev_kernel(float* __restrict__ x, size_t n, const float* __restrict__ scale,
+                                                           const unsigned int* __restrict__ fail) {
+  const float s = (fail && *fail != 0u) ? __builtin_nanf("") : scale[0];
+  const size_t n4 = n / 4;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (size_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<f32x4*>(x)[k];
+    v *= s;
+    reinterpret_cast<f32x4*>(x)[k] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t k = n4 * 4; k < n; ++k) x[k] *= s;
+}
+static inline int lo_stream_blocks(size_t n) {
+  size_t b = (n / 4 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+int lo_grad_scale_pick_run(const float* const g[5], const size_t n[5], float* scratch /* >= 260 floats */, hipStream_t st) {
+  LoAmaxJobs J;
+  size_t total = 0;
+  for (int j = 0; j < 5; ++j) { J.p[j] = g[j]; J.n[j] = g[j] ? n[j] : 0; total += J.n[j]; }
+  size_t want = (total / 4 + 255) / 256;
+  const int nb = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+  hipLaunchKernelGGL(lo_amax_partial_kernel, dim3(nb), dim3(256), 0, st, J, scratch + 4);
+  LO_LAUNCH_CHECK("amax_partial");
+  hipLaunchKernelGGL(lo_amax_finalize_kernel, dim3(1), dim3(256), 0, st, scratch + 4, nb, scratch);
+  LO_LAUNCH_CHECK("amax_finalize");
+  return LO_OK;
+}
+int lo_scale_copy_dev_run(const float* src, float* dst, size_t n, const float* scale_dev, hipStream_t st) {
+  hipLaunchKernelGGL(lo_scale_copy_dev_kernel, dim3(lo_stream_blocks(n)), dim3(256), 0, st, src, dst, n, scale_dev);
+  LO_LAUNCH_CHECK("scale_copy_dev");
+  return LO_OK;
+}
+int lo_scale_dev_run(float* x, size_t n, const float* scale_dev, const unsigned int* fail, hipStream_t st) {
+  hipLaunchKernelGGL(lo_scale_dev_kernel, dim3(lo_stream_blocks(n)), dim3(256), 0, st, x, n, scale_dev, fail);
+  LO_LAUNCH_CHECK("scale_dev");
   return LO_OK;
 }

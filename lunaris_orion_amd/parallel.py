@@ -52,6 +52,8 @@ class FlatGradSync:
         self.compress = compress_fp16
         self.wire_scale = float(wire_scale)      # overflow on the wire needs a gradient element > 64
         self.compress_min_elems = 4 << 20        # ranges below 16 MB (fp32) stay on the fp32 wire
+        self.direct_min_elems = 4 << 20          # ... and go through ONE all-reduce whatever `mode` says
+        self._mode_log, self._mode_last = [], []   # exchange form of every range of the current / the last finished step
         self.force = force                       # tests: issue the collectives even in a one-rank group
         if mode not in ("allreduce", "direct"):
             raise ValueError(f"unknown exchange mode {mode!r}")
@@ -106,8 +108,11 @@ class FlatGradSync:
         """The collectives of one range, issued on the CURRENT stream (sync-in-stream calls: the stream, not the host, waits)."""
         # gloo implements all_to_all / all_gather for CPU tensors only: the two-rank rehearsals on one GPU (gloo + GPU tensors) fall
         # back to the all-reduce form; RCCL and the CPU tests run what was asked for
-        direct = self.mode == "direct" and not (self.backend == "gloo" and buf.is_cuda)
+        # ... and ranges below `direct_min_elems` (the teacher's head gradients, the exposed last 7.7 MB of the encoder) are latency-
+        # bound: one all-reduce instead of all-to-all + share sum + all-gather + tail all-reduce (ADVICE r3)
+        direct = self.mode == "direct" and not (self.backend == "gloo" and buf.is_cuda) and buf.numel() >= self.direct_min_elems
         self.mode_used = "direct" if direct else "allreduce"
+        self._mode_log.append(self.mode_used)
         if direct:
             n, w = buf.numel(), self.world
             chunk = n // w
@@ -190,6 +195,7 @@ class FlatGradSync:
         if self._pending:
             self._finishes += 1
             self._phase_log, self._phase_bytes = self._phase_bytes, []
+            self._mode_last, self._mode_log = self._mode_log, []
         self._pending.clear()
 
     # ---- bench bookkeeping ----------------------------------------------------------------------------------
@@ -202,6 +208,10 @@ class FlatGradSync:
         if not self._events:
             return None
         return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
+
+    def modes_per_phase(self):
+        """Exchange form ("direct" / "allreduce") each range of the last step actually ran as, in hand-over order."""
+        return list(self._mode_last)
 
     def bytes_per_phase(self):
         """Bytes handed to the exchange (on the wire format) by each begin() of the last step, in hand-over order."""

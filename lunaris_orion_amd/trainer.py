@@ -83,6 +83,11 @@ class VAEStepper:
         self.accum = max(1, int(gradient_accumulation_steps))
         self.betas, self.eps = betas, eps
         self.grad_sync = grad_sync      # data parallel: averages the flat gradient buffer across ranks (RCCL)
+        # The weight gradients of the three Linear layers (82 % of the parameters) are rank-B matrices: the fused step keeps them as
+        # their factors -- norm from Gram matrices, gradient tiles formed inside the AdamW pass (csrc/lo_lowrank.hip) -- instead of
+        # writing and re-reading 201 MB.  Single process, batch <= 128; LO_LINEAR_FACTORED=0: the materialised path (A/B).
+        # `parameter_grads()` still returns all 72 gradients (the two matrices are written out on demand).
+        self.linear_factored = grad_sync is None and os.environ.get("LO_LINEAR_FACTORED", "1") != "0"
         self.dp_three_phase = True      # hand the encoder's last stage over before stages 3..1 run (False: one encoder range)
         flat = vae.flat_parameters()
         self.grads = torch.zeros_like(flat)
@@ -102,6 +107,7 @@ class VAEStepper:
         # same averaged gradients).
         self._skip_slots = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(self._DP_LAG + 1)]
         self._skip_inflight = []      # (event, pinned slot, optimizer-step index), oldest first
+        self._last_engine = None
         self._presummed_begin: Optional[int] = None   # set by a backward that left the early part of the gradient norm in the scratch
 
     @property
@@ -124,8 +130,6 @@ class VAEStepper:
             lr = self.lr
             self.opt_steps += 1
             self._clip_adamw(flat, lr, st, eng)
-            if not self.pipeline_optimizer:
-                vae.mark_weights_changed()
             self._observe_skipped_updates()
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
@@ -158,6 +162,7 @@ class VAEStepper:
         """Native backward of the fused loss into ``self.grads`` (+ the data-parallel exchange, overlapped with it)."""
         vae = self.vae
         flat = vae._flat
+        self._last_engine = eng
         bargs = (images.data_ptr(), flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(), images.data_ptr(), 1, None, None, None,
                  float(vae.loss_scale), self.grads.data_ptr(), st)
         if self.grad_sync is not None and hasattr(self.grad_sync, "begin"):
@@ -172,6 +177,8 @@ class VAEStepper:
             assert e4.value == b.value and e.value == self.grads.numel()
             # FlatGradSync runs the exchange on its own stream: the phases then hand their range over as an event for THAT stream
             # (lo_vae_set_async_handover) instead of holding this one up until the side stream's weight gradients have finished
+            if _lib.lib.lo_vae_linear_factored(eng.handle):
+                _lib.check(_lib.lib.lo_vae_set_linear_factored(eng.handle, 0), "lo_vae_set_linear_factored")
             hooks = getattr(self.grad_sync, "supports_then", False)
             _lib.check(_lib.lib.lo_vae_set_async_handover(eng.handle, 1 if hooks else 0), "lo_vae_set_async_handover")
             def wait_range():
@@ -198,7 +205,10 @@ class VAEStepper:
         else:
             # single process: the backward takes the sum of squares of everything from fc_mu.weight on as soon as it is final,
             # beside the encoder backward; _clip_adamw then reads only the encoder range for the norm
-            early = self.grad_sync is None and os.environ.get("LO_EARLY_NORM", "1") != "0"       # LO_EARLY_NORM=0: A/B knob
+            fac = self.linear_factored and eng.batch <= 128
+            if bool(_lib.lib.lo_vae_linear_factored(eng.handle)) != fac:
+                _lib.check(_lib.lib.lo_vae_set_linear_factored(eng.handle, 1 if fac else 0), "lo_vae_set_linear_factored")
+            early = self.grad_sync is None and (fac or os.environ.get("LO_EARLY_NORM", "1") != "0")       # LO_EARLY_NORM=0: A/B knob
             _lib.check(_lib.lib.lo_vae_set_gradnorm_scratch(eng.handle, self.scratch.data_ptr() if early else None),
                        "lo_vae_set_gradnorm_scratch")
             _lib.check(_lib.lib.lo_vae_backward(eng.handle, *bargs), "lo_vae_backward")
@@ -220,13 +230,17 @@ class VAEStepper:
         args = (float(self.max_grad_norm), float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                 float(self.weight_decay), self.opt_steps, self.scratch.data_ptr(), st)
         pre, self._presummed_begin = self._presummed_begin, None
-        if self.pipeline_optimizer and eng is not None:
+        if eng is not None:
+            # through the engine in both orders (LO_OPT_SERIAL = norm, AdamW, re-pack in order on this stream): its clip kernel reads the
+            # plan's rendezvous-failure word and skips the update on the device when a fused-GroupNorm wait of this step ran out
+            flags = (1 if pre is not None else 0) | (0 if self.pipeline_optimizer else 2)
             _lib.check(_lib.lib.lo_vae_optimizer_step(eng.handle, flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                       self.exp_avg_sq.data_ptr(), eng.ws.data_ptr(), *args[:7], self.scratch.data_ptr(),
-                                                      1 if pre is not None else 0, st), "lo_vae_optimizer_step")
+                                                      flags, st), "lo_vae_optimizer_step")
             self.vae.mark_weights_changed()
             eng.packed_version = self.vae._current_version()     # this engine's operand copies were refreshed by the call itself
-            self._pipelined_engine = eng
+            if self.pipeline_optimizer:
+                self._pipelined_engine = eng
             return
         if pre is not None:
             _lib.check(_lib.lib.lo_clip_adamw_step_presummed(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
@@ -268,11 +282,28 @@ class VAEStepper:
     @staticmethod
     def _check_sync(word: float) -> None:
         if word != 0:
-            raise _lib.LunarisHipError("a fused GroupNorm epilogue gave up waiting for the other workgroups of its sample (a launch of this "
-                                       "step did not complete): the step's results are invalid; LO_GN_FUSE=0 runs the separate passes")
+            raise _lib.LunarisHipError("a fused GroupNorm epilogue gave up waiting for the other workgroups of its sample (a launch of a "
+                                       "step did not complete).  No parameter update has been applied since: the optimizer's clip kernel "
+                                       "reads the same word and skips the update on the device.  LO_GNB_APPLY_FUSE=0 / LO_GN_FUSE=0 run "
+                                       "the separate passes")
+
+    def check_device_health(self) -> None:
+        """Host-synchronising look at the rendezvous-failure word (checkpoints call it before they write anything)."""
+        self._check_sync(float(self._sync_fail_word().item()))
+
+    def flat_grads(self) -> torch.Tensor:
+        """The flat gradient buffer with every gradient of the last step in it (in the factored mode the two Linear weight
+        gradients are written out first; `self.grads` alone does not hold them then)."""
+        self.parameter_grads()
+        return self.grads
 
     def parameter_grads(self):
-        """Views of the flat gradient buffer, one per parameter (state_dict order)."""
+        """Views of the flat gradient buffer, one per parameter (state_dict order).  In the factored mode the two Linear weight
+        gradients of the last step are written out first (`lo_vae_materialize_linear_grads`: the tiles the AdamW pass formed)."""
+        for eng in self.vae._engines.values():
+            if eng is self._last_engine and _lib.lib.lo_vae_linear_factored(eng.handle):
+                _lib.check(_lib.lib.lo_vae_materialize_linear_grads(eng.handle, eng.ws.data_ptr(), self.grads.data_ptr(), _lib.stream_ptr()),
+                           "lo_vae_materialize_linear_grads")
         return [self.grads[o:o + n].view(shape) for (o, n, shape) in self.vae._layout]
 
 
@@ -365,8 +396,6 @@ class HybridStepper(VAEStepper):
             t_lr = cosine_warm_restarts_lr(self.teacher_base_lr, self.min_lr, self.t0, 2, self.opt_steps)
             self.opt_steps += 1
             self._clip_adamw(flat, lr, st, eng)
-            if not self.pipeline_optimizer:
-                vae.mark_weights_changed()
             self._observe_skipped_updates()
             # teacher: gate + quality heads only (train_hybrid.py:891-904, 914, 922)
             b, e = self.t_range

@@ -197,26 +197,77 @@ class Decoder(_OwnedByVAE, nn.Module):
         return vae._native_decode(z, skips)[0]
 
 
+def _normalise_upstream(grads):
+    """Bring the upstream gradients of an autograd node into the range the fp16 backward is built for, whatever loss scale the
+    caller's loop has multiplied them by (train_hybrid.py:899-904: ``scaler.scale(vae_loss).backward()`` with GradScaler's 65 536):
+    ``r = 2**k`` with ``max|g| * r`` in [2, 4) is picked ON THE DEVICE (``lo_grad_scale_pick``; no host synchronisation), the
+    gradients are multiplied by it, and ``_denormalise`` multiplies what the backward produced by ``1 / r`` — both exact in fp32.
+    Returns (scratch, scaled gradients); scratch[0] = r, scratch[1] = 1 / r."""
+    live = [g for g in grads if g is not None]
+    dev = live[0].device
+    scr = torch.empty(264, dtype=torch.float32, device=dev)
+    st = _lib.stream_ptr()
+    args = []
+    for k in range(5):
+        g = grads[k] if k < len(grads) else None
+        args += [_lib.ptr(g), g.numel() if g is not None else 0]
+    _lib.check(_lib.lib.lo_grad_scale_pick(*args, scr.data_ptr(), st), "lo_grad_scale_pick")
+    out = []
+    for g in grads:
+        if g is None:
+            out.append(None)
+            continue
+        d = torch.empty_like(g)
+        _lib.check(_lib.lib.lo_scale_copy_dev(g.data_ptr(), d.data_ptr(), g.numel(), scr.data_ptr(), st), "lo_scale_copy_dev")
+        out.append(d)
+    return scr, out
+
+
+def _denormalise(t: Optional[torch.Tensor], scr: torch.Tensor, eng: "_Engine") -> None:
+    """t *= 1 / r (see ``_normalise_upstream``); a set rendezvous-failure word of the engine turns the result into NaN."""
+    if t is not None:
+        _lib.check(_lib.lib.lo_grad_unscale_dev(t.data_ptr(), t.numel(), scr.data_ptr() + 4, eng.sync_fail.data_ptr(), _lib.stream_ptr()),
+                   "lo_grad_unscale_dev")
+
+
+def _check_generation(eng: "_Engine", what: str, want) -> None:
+    """The activations of a forward live in the engine's ONE workspace.  The reference's modules allow two forwards before a backward
+    (or an eval forward of the same batch size inside a step); here the second forward overwrites what the first one's backward needs,
+    and that backward must say so instead of returning gradients of the wrong activations."""
+    have = (eng.gen_enc, eng.gen_dec)
+    bad = [n for n, h, w in zip(("encoder", "decoder"), have, want) if w is not None and h != w]
+    if bad:
+        raise _lib.LunarisHipError(
+            f"{what}: another forward of this module at the same batch size has overwritten the {' and '.join(bad)} activations this "
+            "backward needs (one workspace per batch size). Run backward() before the next forward of that batch size, or run the "
+            "other forward under a different batch size / on a copy of the module.")
+
+
 class _EncoderFunction(torch.autograd.Function):
     """Encoder.forward / its backward as one native call each."""
 
     @staticmethod
     def forward(ctx, vae, x, *params):
         mu, logvar, s0, s1, s2, eng = vae._native_encode(x)
-        ctx.vae, ctx.eng, ctx.nparam = vae, eng, len(params)
+        ctx.vae, ctx.eng, ctx.nparam, ctx.gen = vae, eng, len(params), (eng.gen_enc, None)
         ctx.save_for_backward(x)
         return mu, logvar, s0, s1, s2
 
     @staticmethod
     def backward(ctx, g_mu, g_lv, g0, g1, g2):
         vae, eng = ctx.vae, ctx.eng
+        _check_generation(eng, "Encoder backward", ctx.gen)
         (x,) = ctx.saved_tensors
         cont = lambda t: None if t is None else t.contiguous().float()
-        g_mu, g_lv, g0, g1, g2 = (cont(t) for t in (g_mu, g_lv, g0, g1, g2))
+        ups = [cont(t) for t in (g_mu, g_lv, g0, g1, g2)]
         flat_g = torch.zeros_like(vae._flat)
+        if all(t is None for t in ups):
+            return (None, None) + tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in vae._layout[:ctx.nparam])
+        scr, (g_mu, g_lv, g0, g1, g2) = _normalise_upstream(ups)
         _lib.check(_lib.lib.lo_vae_encoder_backward(eng.handle, x.data_ptr(), vae._flat.data_ptr(), eng.ws.data_ptr(), _lib.ptr(g_mu),
-                                                    _lib.ptr(g_lv), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(g2), float(vae.loss_scale),
+                                                    _lib.ptr(g_lv), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(g2), 1.0,
                                                     flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_encoder_backward")
+        _denormalise(flat_g, scr, eng)
         grads = tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in vae._layout[:ctx.nparam])
         return (None, None) + grads
 
@@ -228,22 +279,25 @@ class _DecoderFunction(torch.autograd.Function):
     def forward(ctx, vae, n_skips, z, *rest):
         skips, params = rest[:n_skips], rest[n_skips:]
         recon, eng = vae._native_decode(z, skips)
-        ctx.vae, ctx.eng, ctx.n_skips, ctx.nparam = vae, eng, n_skips, len(params)
+        ctx.vae, ctx.eng, ctx.n_skips, ctx.nparam, ctx.gen = vae, eng, n_skips, len(params), (None, eng.gen_dec)
         ctx.save_for_backward(recon)
         return recon
 
     @staticmethod
     def backward(ctx, g_recon):
         vae, eng, ns = ctx.vae, ctx.eng, ctx.n_skips
+        _check_generation(eng, "Decoder backward", ctx.gen)
         (recon,) = ctx.saved_tensors
-        g_recon = g_recon.contiguous().float()
+        scr, (g_recon,) = _normalise_upstream([g_recon.contiguous().float()])
         B, dev = recon.shape[0], recon.device
         flat_g = torch.zeros_like(vae._flat)
         dz = torch.empty(B, vae.latent_dim, dtype=torch.float32, device=dev)
         dsk = [torch.empty(B, 64 << k, 64 >> k, 64 >> k, dtype=torch.float32, device=dev) if k < ns else None for k in range(3)]
         _lib.check(_lib.lib.lo_vae_decoder_backward(eng.handle, vae._flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(), g_recon.data_ptr(),
-                                                    float(vae.loss_scale), dz.data_ptr(), _lib.ptr(dsk[0]), _lib.ptr(dsk[1]), _lib.ptr(dsk[2]),
+                                                    1.0, dz.data_ptr(), _lib.ptr(dsk[0]), _lib.ptr(dsk[1]), _lib.ptr(dsk[2]),
                                                     flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_decoder_backward")
+        for t in (flat_g, dz, *dsk):
+            _denormalise(t, scr, eng)
         first = len(vae._layout) - ctx.nparam                    # the decoder's parameters are the tail of the state_dict order
         grads = tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in vae._layout[first:])
         return (None, None, dz) + tuple(dsk[:ns]) + grads
@@ -258,6 +312,7 @@ class _Engine:
         self.batch, self.latent_dim, self.device = batch, latent_dim, device
         self.ws = torch.empty(_lib.lib.lo_vae_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
         self.packed_version = None      # (explicit version, sum of the parameters' version counters) of the last pack
+        self.gen_enc = self.gen_dec = 0 # bumped by every call that overwrites the encoder / decoder activations in the workspace
         off, nf = C.c_size_t(), C.c_int()
         _lib.check(_lib.lib.lo_vae_sync_fail_word(self.handle, C.byref(off), C.byref(nf)), "lo_vae_sync_fail_word")
         self.fused_gn_layers = nf.value
@@ -280,20 +335,27 @@ class _VAEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, eps, *params):
         recon, mu, logvar, eng = model._native_forward(x, eps, target=None)
-        ctx.model, ctx.eng = model, eng
+        ctx.model, ctx.eng, ctx.gen = model, eng, (eng.gen_enc, eng.gen_dec)
         ctx.save_for_backward(x, recon)
         return recon, mu, logvar
 
     @staticmethod
     def backward(ctx, g_recon, g_mu, g_logvar):
         model, eng = ctx.model, ctx.eng
+        _check_generation(eng, "LunarisCoreVAE backward", ctx.gen)
         x, recon = ctx.saved_tensors
         flat_g = torch.empty_like(model._flat)
         cont = lambda t: None if t is None else t.contiguous().float()
-        g_recon, g_mu, g_logvar = cont(g_recon), cont(g_mu), cont(g_logvar)
+        ups = [cont(g_recon), cont(g_mu), cont(g_logvar)]
+        if all(t is None for t in ups):
+            flat_g.zero_()
+            return (None, None, None) + tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in model._layout)
+        # the upstream gradients may carry a foreign loss scale (torch.amp.GradScaler): normalised on the device, see _normalise_upstream
+        scr, (g_recon, g_mu, g_logvar) = _normalise_upstream(ups)
         _lib.check(_lib.lib.lo_vae_backward(eng.handle, x.data_ptr(), model._flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
                                             None, 0, _lib.ptr(g_recon), _lib.ptr(g_mu), _lib.ptr(g_logvar),
-                                            float(model.loss_scale), flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_backward")
+                                            1.0, flat_g.data_ptr(), _lib.stream_ptr()), "lo_vae_backward")
+        _denormalise(flat_g, scr, eng)
         grads = tuple(flat_g[o:o + n].view(shape) for (o, n, shape) in model._layout)
         return (None, None, None) + grads
 
@@ -315,7 +377,10 @@ class LunarisCoreVAE(nn.Module):
         self.decoder = Decoder(latent_dim=latent_dim)
         for sub in (self.encoder, self.decoder):                 # not a registered attribute: no module cycle, nothing in state_dict
             object.__setattr__(sub, "_owner", weakref.ref(self))
-        self.loss_scale = 65536.0      # fp16 gradient range (the reference's GradScaler starts at 2**16 too)
+        #: loss scale of the FUSED step (trainer.VAEStepper, which also runs GradScaler's policy on it).  The autograd path does not
+        #: use it: there the upstream gradients are normalised on the device (`_normalise_upstream`), so a loop that brings its own
+        #: torch.amp.GradScaler (train_hybrid.py:289-297, 899-923) needs no setting here
+        self.loss_scale = 65536.0
         self._flat: Optional[torch.Tensor] = None
         self._layout: List[Tuple[int, int, torch.Size]] = []
         self._engines: Dict[Tuple[int, str], _Engine] = {}
@@ -445,6 +510,8 @@ class LunarisCoreVAE(nn.Module):
             self._seed = lcg_advance(self._seed, self.noise_calls)       # > 0 after a resume: this rank's stream, same position
         self._seed = (self._seed * _LCG_A + _LCG_C) & _M64
         self.noise_calls += 1
+        eng.gen_enc += 1
+        eng.gen_dec += 1
         _lib.check(_lib.lib.lo_vae_forward(eng.handle, x.data_ptr(), _lib.ptr(eps), self._seed, self._flat.data_ptr(),
                                            eng.ws.data_ptr(), recon.data_ptr(), mu.data_ptr(), logvar.data_ptr(),
                                            _lib.ptr(target), _lib.stream_ptr()), "lo_vae_forward")
@@ -461,6 +528,7 @@ class LunarisCoreVAE(nn.Module):
         mu = torch.empty(B, self.latent_dim, dtype=torch.float32, device=dev)
         logvar = torch.empty_like(mu)
         sk = [torch.empty(B, 64 << k, 64 >> k, 64 >> k, dtype=torch.float32, device=dev) for k in range(3)]
+        eng.gen_enc += 1
         _lib.check(_lib.lib.lo_vae_encode(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), mu.data_ptr(),
                                           logvar.data_ptr(), sk[0].data_ptr(), sk[1].data_ptr(), sk[2].data_ptr(), _lib.stream_ptr()),
                    "lo_vae_encode")
@@ -480,6 +548,7 @@ class LunarisCoreVAE(nn.Module):
         eng = self._engine(B)
         recon = torch.empty(B, 3, 128, 128, dtype=torch.float32, device=z.device)
         p = [_lib.ptr(sk[k]) if k < len(sk) else None for k in range(3)]
+        eng.gen_dec += 1
         _lib.check(_lib.lib.lo_vae_decode_skips(eng.handle, z.data_ptr(), len(sk), p[0], p[1], p[2], self._flat.data_ptr(), eng.ws.data_ptr(),
                                                 recon.data_ptr(), _lib.stream_ptr()), "lo_vae_decode_skips")
         return recon, eng
@@ -508,6 +577,7 @@ class LunarisCoreVAE(nn.Module):
             raise ValueError("z must have shape [B, latent_dim]")
         eng = self._engine(z.shape[0])
         recon = torch.empty(z.shape[0], 3, 128, 128, dtype=torch.float32, device=z.device)
+        eng.gen_dec += 1
         _lib.check(_lib.lib.lo_vae_decode(eng.handle, z.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), recon.data_ptr(),
                                           _lib.stream_ptr()), "lo_vae_decode")
         return recon

@@ -102,3 +102,42 @@ def test_fused_groupnorm_backward_apply_equals_the_separate_pass(tmp_path, B, L)
             bad.append((k, (a - b).abs().max().item(), 0.0))
     first_step = [t for t in bad if t[0].startswith(("grad0", "recon0", "mu0", "logvar0", "losses0"))]
     assert not bad, (first_step or bad)[:12]
+
+
+def test_a_failed_rendezvous_skips_the_update_on_the_device_and_poisons_the_autograd_path():
+    """VERDICT r3 item 1b / ADVICE r3: the word a fused-GroupNorm workgroup sets when its bounded wait runs out is read by the
+    optimizer's clip kernel (no host in between): the update of that step and of every later step is skipped on the device until the
+    host has looked, `metrics()` and `check_device_health()` (what a checkpoint calls first) raise, and the autograd path — which
+    has no optimizer kernel of this library behind it — returns NaN gradients, which a GradScaler / clip_grad_norm_ sees.  The word
+    is set by hand here: the wait itself never runs out (the bit-for-bit tests above would fail)."""
+    import torch.nn.functional as F
+    from oracle import vae_ref as R
+    from lunaris_orion_amd._lib import LunarisHipError
+    from lunaris_orion_amd.trainer import VAEStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    B, L = 2, 256
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    for pipelined in (False, True):
+        m = LunarisCoreVAE(L); m.load_state_dict(R.closed_form_params(L)); m = m.to("cuda")
+        st = VAEStepper(m, gradient_accumulation_steps=1, pipeline_optimizer=pipelined)
+        st.step(x, 0, R.closed_form_eps(B, L, salt=0).cuda())
+        st.synchronize_parameters(); torch.cuda.synchronize()
+        st.metrics()                                         # healthy
+        p1 = m.flat_parameters().clone()
+        eng = m._engine(B)
+        eng.sync_fail.fill_(1)                               # "a launch of this step was lost"
+        for s in (1, 2):
+            st.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
+        st.synchronize_parameters(); torch.cuda.synchronize()
+        assert torch.equal(m.flat_parameters(), p1), "an update was applied after the failure word was set"
+        with pytest.raises(LunarisHipError, match="gave up waiting"):
+            st.check_device_health()
+        with pytest.raises(LunarisHipError, match="gave up waiting"):
+            st.metrics()
+    # the autograd path: NaN gradients
+    m = LunarisCoreVAE(L); m.load_state_dict(R.closed_form_params(L)); m = m.to("cuda")
+    recon, mu, logvar = m(x, R.closed_form_eps(B, L, salt=0).cuda())
+    m._engine(B).sync_fail.fill_(1)
+    (F.mse_loss(recon, x) + 0.1 * mu.pow(2).mean()).backward()
+    torch.cuda.synchronize()
+    assert all(torch.isnan(p.grad).all() for p in m.parameters())

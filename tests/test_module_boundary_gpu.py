@@ -30,8 +30,10 @@ class _Loop:
     """The state a TrainingManager keeps around `_process_batch` (train_hybrid.py:283-286, 502-527) and one method with the
     statement order of train_hybrid.py:841-926 (its fp32 branch: no autocast, no GradScaler)."""
 
-    def __init__(self, vae, teacher, accum=1):
-        self.vae, self.teacher, self.accum = vae, teacher, accum
+    def __init__(self, vae, teacher, accum=1, amp=False):
+        self.vae, self.teacher, self.accum, self.amp = vae, teacher, accum, amp
+        # the reference's mixed-precision branch (train_hybrid.py:246-247, 289-297): fp16 autocast + torch.amp.GradScaler('cuda')
+        self.scaler = torch.amp.GradScaler("cuda") if amp else None
         self.vae_opt = torch.optim.AdamW(vae.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
         self.t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
         sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts
@@ -45,29 +47,43 @@ class _Loop:
         self.vae_opt.zero_grad(set_to_none=True)
         self.t_opt.zero_grad(set_to_none=True)
         images = images.detach().requires_grad_(True)
-        recon, mu, logvar = self.vae(images)
-        with torch.no_grad():
-            prompt = self.teacher(images)["prompt_embedding"]
-        recon_loss = F.mse_loss(recon, images, reduction="mean")
-        kl_loss = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
-        ev = self.teacher(recon.detach(), prompt)
-        q, sem = ev["quality_scores"], ev["semantic_score"]
-        quality_reward = q.mean(dim=1, keepdim=True)
-        total_reward = quality_reward + self.semantic_weight * sem
-        tr = total_reward.mean().item()
-        self.baseline = tr if self.baseline is None else self.momentum * self.baseline + (1 - self.momentum) * tr
-        advantage = (total_reward - self.baseline).detach() * self.reward_scale
-        pg_loss = -(advantage * recon_loss).mean()
-        vae_loss = (self.recon_weight * recon_loss + self.kl_weight * kl_loss + pg_loss) / self.accum
-        quality_loss = -torch.mean(q)
-        teacher_loss = self.quality_weight * quality_loss / self.accum
-        vae_loss.backward()
-        teacher_loss.backward()
+        from contextlib import nullcontext
+        with torch.autocast(device_type="cuda", dtype=torch.float16) if self.amp else nullcontext():      # train_hybrid.py:848-849
+            recon, mu, logvar = self.vae(images)
+            with torch.no_grad():
+                prompt = self.teacher(images)["prompt_embedding"]
+            recon_loss = F.mse_loss(recon, images, reduction="mean")
+            kl_loss = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+            ev = self.teacher(recon.detach(), prompt)
+            q, sem = ev["quality_scores"], ev["semantic_score"]
+            quality_reward = q.mean(dim=1, keepdim=True)
+            total_reward = quality_reward + self.semantic_weight * sem
+            tr = total_reward.mean().item()
+            self.baseline = tr if self.baseline is None else self.momentum * self.baseline + (1 - self.momentum) * tr
+            advantage = (total_reward - self.baseline).detach() * self.reward_scale
+            pg_loss = -(advantage * recon_loss).mean()
+            vae_loss = (self.recon_weight * recon_loss + self.kl_weight * kl_loss + pg_loss) / self.accum
+            quality_loss = -torch.mean(q)
+            teacher_loss = self.quality_weight * quality_loss / self.accum
+        if self.amp:                                                       # train_hybrid.py:899-904
+            self.scaler.scale(vae_loss).backward()
+            self.scaler.scale(teacher_loss).backward()
+        else:
+            vae_loss.backward()
+            teacher_loss.backward()
         if (batch_idx + 1) % self.accum == 0:
+            if self.amp:                                                   # :908-911
+                self.scaler.unscale_(self.vae_opt)
+                self.scaler.unscale_(self.t_opt)
             torch.nn.utils.clip_grad_norm_(self.vae.parameters(), self.max_grad_norm)
             torch.nn.utils.clip_grad_norm_(self.teacher.parameters(), self.max_grad_norm)
-            self.vae_opt.step()
-            self.t_opt.step()
+            if self.amp:                                                   # :916-919
+                self.scaler.step(self.vae_opt)
+                self.scaler.step(self.t_opt)
+                self.scaler.update()
+            else:
+                self.vae_opt.step()
+                self.t_opt.step()
             self.vae_sched.step()
             self.t_sched.step()
         return {"recon_loss": recon_loss.item(), "kl_loss": kl_loss.item(), "quality_loss": quality_loss.item(), "pg_loss": pg_loss.item(),
@@ -76,14 +92,19 @@ class _Loop:
                 "total_loss": vae_loss.item() + teacher_loss.item(), "quality_scores": q.mean().item()}
 
 
-def test_a_reference_shaped_step_with_torch_optimizers_matches_the_references_trace():
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32_branch", "amp_branch_autocast_gradscaler"])
+def test_a_reference_shaped_step_with_torch_optimizers_matches_the_references_trace(amp):
+    """amp=True is the branch every GPU recipe of the reference's README runs (`--mixed_precision`; train_hybrid.py:246-247, 289-297,
+    848-849, 899-923): torch.autocast(fp16) around the forward, GradScaler around backward / unscale_ / clip / step / update.  Nothing
+    of this build is configured for it (no `vae.loss_scale` assignment): the autograd node normalises the GradScaler-scaled upstream
+    gradients on the device.  No optimizer step may be skipped and the scaler must still stand at its initial 65 536 afterwards."""
     g = np.load(os.path.join(GOLD, "hybrid_loop_L256_B2.npz"))
     cols, trace, seeds = [str(c) for c in g["cols"]], g["trace"], [int(v) for v in g["call_seeds"]]
     L, B, steps = (int(v) for v in g["meta"])
     vae, t = _models(L)
     x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
     t.set_dropout_stream(seeds[0], exact_next=True)
-    loop = _Loop(vae, t)
+    loop = _Loop(vae, t, amp=amp)
     tol = {"recon_loss": ("rel", 2e-4), "kl_loss": ("rel", 2e-4), "vae_loss": ("rel", 1e-3), "pg_loss": ("abs", 5e-4), "advantage": ("abs", 5e-4)}
     for s in range(steps):
         vae.next_eps = R.closed_form_eps(B, L, salt=s).cuda()       # what the fixture injected through randn_like
@@ -98,6 +119,57 @@ def test_a_reference_shaped_step_with_torch_optimizers_matches_the_references_tr
     np.testing.assert_allclose(t.gate[2].weight.detach().cpu().numpy()[:4, :8], g["gate_w_after"], atol=2e-4)
     np.testing.assert_allclose(vae.encoder.fc_mu.bias.detach().cpu().numpy()[:16], g["vae_fc_mu_b_after"], atol=2e-4)
     assert abs(loop.vae_opt.param_groups[0]["lr"] - float(g["lr_after"])) <= 1e-12
+    if amp:
+        # zero skipped steps: GradScaler found no inf / NaN in either optimizer's gradients (a skipped step halves the scale and
+        # leaves the optimizer's per-parameter step count behind)
+        assert loop.scaler.get_scale() == 65536.0
+        assert int(loop.vae_opt.state[vae.encoder.fc_mu.bias]["step"].item()) == steps
+        assert int(loop.t_opt.state[t.gate[2].weight]["step"].item()) == steps
+
+
+def test_gradscaler_scaled_upstream_gradients_give_the_scaled_parameter_gradients():
+    """The autograd node under a foreign loss scale: backward of S * loss must give S * (backward of loss) for all 72 parameters,
+    for S = 2**16 (GradScaler's start), 2**24 (after growth) and 2**-8 — the node normalises the upstream gradients to a fixed
+    fp16 range on the device, so only fp32 rounding of the power-of-two scaling separates the results (none: bitwise equal)."""
+    L, B = 256, 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+
+    def grads(scale):
+        vae, _ = _models(L)
+        recon, mu, logvar = vae(x, eps)
+        loss = F.mse_loss(recon, x) + 0.1 * (-0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp()))
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in vae.named_parameters()}
+
+    base = grads(1.0)
+    for sc in (65536.0, 2.0 ** 24, 2.0 ** -8):
+        other = grads(sc)
+        for k in base:
+            assert torch.isfinite(other[k]).all(), (sc, k)
+            assert torch.equal(other[k], base[k] * sc), (sc, k)
+
+
+def test_a_second_forward_before_backward_is_reported_not_silently_wrong():
+    """One workspace per batch size: a forward of the same batch size between a forward and its backward overwrites the activations;
+    the backward raises instead of returning gradients of the wrong activations.  Another batch size is fine."""
+    from lunaris_orion_amd._lib import LunarisHipError
+    L, B = 256, 2
+    vae, _ = _models(L)
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    recon, mu, _ = vae(x, eps)
+    with torch.no_grad():
+        vae(torch.flip(x, dims=[0]), eps)                  # same batch size: overwrites
+    with pytest.raises(LunarisHipError, match="overwritten"):
+        (F.mse_loss(recon, x) + mu.mean()).backward()
+    vae.zero_grad(set_to_none=True)
+    recon, mu, _ = vae(x, eps)
+    with torch.no_grad():
+        vae(x[:1], eps[:1])                                # another batch size: its own engine
+    (F.mse_loss(recon, x) + mu.mean()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in vae.parameters())
 
 
 def test_teacher_outputs_carry_a_graph_over_gate_and_quality_heads():

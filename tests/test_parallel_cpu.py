@@ -41,9 +41,15 @@ def _worker(rank, world, port, q):
     sync = FlatGradSync()
     sync(flat)
     direct = FlatGradSync(mode="direct")
+    direct.direct_min_elems = 0              # the product sends ranges below 4 M elements through one all-reduce (latency-bound)
     direct.begin(flat_direct)
     direct.finish()
-    assert direct.bytes_per_phase() == [4 * flat_direct.numel()]
+    assert direct.bytes_per_phase() == [4 * flat_direct.numel()] and direct.modes_per_phase() == ["direct"]
+    small = FlatGradSync(mode="direct")      # ... which is what this one does: same numbers, reported as what it ran as
+    fs = flat.clone()
+    fs.copy_(torch.cat([g.flatten() for g in R.OracleTrainer(P).step(xs, es, 0.0, do_update=False)["grads"].values()]))
+    small.begin(fs[:1000]); small.finish()
+    assert small.modes_per_phase() == ["allreduce"] and torch.equal(fs[:1000], flat[:1000])
     # the product's hand-over pattern: three ranges handed over one after the other (tail of the buffer first, like the phased
     # backward does), fp16 wire, then one finish(); every range complete and equal to the all-reduce average to fp16 rounding
     o2 = R.OracleTrainer(P).step(xs, es, 0.0, do_update=False)
@@ -51,12 +57,13 @@ def _worker(rank, world, port, q):
     n = flat16.numel()
     b1, b2 = (n // 10) * 3 + 1, (n // 10) * 1 + 3                # odd boundaries: remainder paths in every range
     d16 = FlatGradSync(mode="direct", compress_fp16=True)
-    d16.compress_min_elems = 0               # the fp16 wire on every range (the product keeps ranges below 16 MB on the fp32 wire)
+    d16.compress_min_elems = d16.direct_min_elems = 0   # the fp16 wire / direct form on every range (the product keeps ranges below 16 MB on the fp32 wire and on one all-reduce)
     d16.begin(flat16[b1:]); d16.begin(flat16[b2:b1]); d16.begin(flat16[:b2])
     d16.finish()
     assert d16.bytes_per_phase() == [2 * (n - b1), 2 * (b1 - b2), 2 * b2]
     # the product's rule: a range below `compress_min_elems` stays on the fp32 wire (the last, exposed range of a step)
     mixed = FlatGradSync(mode="direct", compress_fp16=True)
+    mixed.direct_min_elems = 0
     mixed.compress_min_elems = b1 - b2 + 1
     fm = torch.cat([g.flatten() for g in R.OracleTrainer(P).step(xs, es, 0.0, do_update=False)["grads"].values()])
     mixed.begin(fm[b1:]); mixed.begin(fm[b2:b1]); mixed.begin(fm[:b2])

@@ -111,9 +111,10 @@ def main(argv=None):
         # nccl = RCCL over xGMI; LO_DIST_BACKEND=gloo rehearses the multi-rank control flow with several ranks on one GPU
         dist.init_process_group(os.environ.get("LO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
         from lunaris_orion_amd.parallel import FlatGradSync
-        # the xGMI-shaped exchange (all-to-all reduce-scatter + all-gather, fp16 wire) behind the backward; LO_DP_EXCHANGE=allreduce:
-        # one RCCL all-reduce per hand-over range on the fp32 wire (DP == single process to fp32 rounding)
-        dp_mode = os.environ.get("LO_DP_EXCHANGE", "direct")
+        # default: one RCCL all-reduce per hand-over range on the fp32 wire (DP == single process to fp32 rounding, the documented
+        # contract).  LO_DP_EXCHANGE=direct opts into the xGMI-shaped exchange (all-to-all reduce-scatter + all-gather, fp16 wire):
+        # it stays opt-in until an N > 1 RCCL run has checked its parity and timing on hardware
+        dp_mode = os.environ.get("LO_DP_EXCHANGE", "allreduce")
         grad_sync = FlatGradSync(mode=dp_mode, compress_fp16=dp_mode == "direct")
 
     out_dir = Path(args.output_dir)
@@ -164,6 +165,7 @@ def main(argv=None):
             return
         stepper.synchronize_parameters()          # the pipelined optimizer step may still be updating the decoder's parameters
         torch.cuda.synchronize()
+        stepper.check_device_health()             # raises instead of writing a checkpoint after a lost launch (rendezvous-failure word)
         torch.save(hostside.checkpoint_dict(stepper, vae, teacher, global_step, best_loss, vars(args)), out_dir / "checkpoints" / f"{tag}.pt")
         log.info(f"Checkpoint saved at step {global_step}")
 
