@@ -821,9 +821,12 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
     LO_TRY(lo_pack_f8_all(jobs8 + h->n_packjobs8_enc, h->n_packjobs8_s4 - h->n_packjobs8_enc, h->pack_blocks8_s4 - h->pack_blocks8_enc, sd, h->pack_blocks8_enc));
   LO_TRY(vae_side_record(h, 2, sd));
   // level 3: fc_mu / fc_logvar (weights + biases are adjacent: [bh, bd)) and their fp16 copy
+  const LoLowrankMat lrm[2] = {{P + bh, M + bh, V + bh, WSP(f16, h->o_wp_head), WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768},
+                               {P + bd, M + bd, V + bd, WSP(f16, h->o_wp_dfc), WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L}};
   if (h->lin_factored) {
-    LO_TRY(lo_adamw_lowrank(P + bh, M + bh, V + bh, WSP(f16, h->o_wp_head), WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768, h->B,
-                            h->fac_scale, norm, lr, b1, b2, eps, wd, step, sd));
+    // both factored matrices (fc_mu | fc_logvar and decoder.fc: 82 % of the parameters) in one launch: the forward needs neither
+    // before the end of the encoder, ~1 ms away, and one launch has one ramp and one tail
+    LO_TRY(lo_adamw_lowrank(lrm, 2, h->B, h->fac_scale, norm, lr, b1, b2, eps, wd, step, sd));
     LO_TRY(adam(bh + nh, bd));
   } else if (fuse_cast) {
     LO_TRY(adam(bh, bh + nh, WSP(f16, h->o_wp_head)));
@@ -835,9 +838,7 @@ static int vae_flush_deferred(LoVae* h, hipStream_t after_main) {
   LO_TRY(vae_side_record(h, 3, sd));
   // level 4: decoder.fc, the decoder and final convs
   if (h->lin_factored) {
-    LO_TRY(lo_adamw_lowrank(P + bd, M + bd, V + bd, WSP(f16, h->o_wp_dfc), WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L, h->B,
-                            h->fac_scale, norm, lr, b1, b2, eps, wd, step, sd));
-    LO_TRY(adam(bd + nd, n));
+    LO_TRY(adam(bd + nd, n));          // decoder.fc.weight went with the encoder heads (one launch for both factored matrices)
   } else if (fuse_cast) {
     LO_TRY(adam(bd, bd + nd, WSP(f16, h->o_wp_dfc)));
     LO_TRY(adam(bd + nd, n));
@@ -940,12 +941,11 @@ extern "C" int lo_vae_optimizer_step(LoVae* h, float* P, const float* G, float* 
     if (h->lin_factored) {
       const int L = h->L;
       const size_t bh = h->p_off[h->idx_fc_mu_w], nh = (size_t)2 * L * 32768, bd = h->p_off[h->idx_dfc_w], nd = (size_t)32768 * L;
+      const LoLowrankMat lrm[2] = {{P + bh, M + bh, V + bh, nullptr, WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768},
+                                   {P + bd, M + bd, V + bd, nullptr, WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L}};
       LO_TRY(lo_adamw(P, G, M, V, bh, norm, lr, beta1, beta2, eps, weight_decay, step, st));
-      LO_TRY(lo_adamw_lowrank(P + bh, M + bh, V + bh, nullptr, WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_dmlT), 2 * L, 32768, h->B, h->fac_scale, norm,
-                              lr, beta1, beta2, eps, weight_decay, step, st));
+      LO_TRY(lo_adamw_lowrank(lrm, 2, h->B, h->fac_scale, norm, lr, beta1, beta2, eps, weight_decay, step, st));
       LO_TRY(lo_adamw(P + bh + nh, G + bh + nh, M + bh + nh, V + bh + nh, bd - (bh + nh), norm, lr, beta1, beta2, eps, weight_decay, step, st));
-      LO_TRY(lo_adamw_lowrank(P + bd, M + bd, V + bd, nullptr, WSP(f16, h->o_fac_zT), WSP(f16, h->o_fac_gfcT), 32768, L, h->B, h->fac_scale, norm,
-                              lr, beta1, beta2, eps, weight_decay, step, st));
       LO_TRY(lo_adamw(P + bd + nd, G + bd + nd, M + bd + nd, V + bd + nd, n - (bd + nd), norm, lr, beta1, beta2, eps, weight_decay, step, st));
     } else {
       LO_TRY(lo_adamw(P, G, M, V, n, norm, lr, beta1, beta2, eps, weight_decay, step, st));
@@ -1472,11 +1472,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     if (ovl) LO_HIP(hipStreamWaitEvent(h->side, e, 0));
   }
   LO_TRY(lo_colsum_f16(Gfc, GRD(h->idx_dfc_b), B, 32768, inv, gs));
-  if (fac) {
-    // dW = Gfc^T z is never formed: its factors, transposed and batch-padded, are what the optimizer's AdamW pass multiplies
-    LO_TRY(lo_transpose_pad_f16(Gfc, WSP(f16, h->o_fac_gfcT), B, 32768, h->Bp, gs));
-    LO_TRY(lo_transpose_pad_f16(WSP(f16, h->o_z), WSP(f16, h->o_fac_zT), B, L, h->Bp, gs));
-  } else {
+  if (!fac) {      // factored mode: dW = Gfc^T z is never formed (its factors are transposed below, with the encoder heads')
     LO_TRY(lo_wgrad_run(h->g_dfc, WSP(f16, h->o_z), Gfc, WSP(float, h->o_wslab_lin), GRD(h->idx_dfc_w), inv, gs));
   }
   LO_TRY(lo_conv_run(h->g_dfc_d, Gfc, WSP(f16, h->o_wp_dfc_t), nullptr, nullptr, nullptr, nullptr, WSP(float, h->o_slab_dz),
@@ -1507,8 +1503,11 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   // ---- encoder heads (bias + weight gradient beside the chain, see decoder.fc above)
   LO_TRY(lo_colsum_f16(WSP(f16, h->o_dml), GRD(h->idx_fc_mu_b), B, 2 * L, inv, gs));
   if (fac) {
-    LO_TRY(lo_transpose_pad_f16(WSP(f16, h->o_dml), WSP(f16, h->o_fac_dmlT), B, 2 * L, h->Bp, gs));
-    LO_TRY(lo_transpose_pad_f16(WSP(f16, h->o_xflat), WSP(f16, h->o_fac_xT), B, 32768, h->Bp, gs));
+    // the four factors, transposed and batch-padded, are what the optimizer's AdamW pass multiplies: one launch
+    const f16* src[4] = {WSP(f16, h->o_dml), WSP(f16, h->o_xflat), Gfc, WSP(f16, h->o_z)};
+    f16* dst[4] = {WSP(f16, h->o_fac_dmlT), WSP(f16, h->o_fac_xT), WSP(f16, h->o_fac_gfcT), WSP(f16, h->o_fac_zT)};
+    const int Cs[4] = {2 * L, 32768, 32768, L};
+    LO_TRY(lo_transpose_pad_f16_multi(src, dst, Cs, 4, B, h->Bp, gs));
   } else {
     LO_TRY(lo_wgrad_run(h->g_head, WSP(f16, h->o_xflat), WSP(f16, h->o_dml), WSP(float, h->o_wslab_lin), GRD(h->idx_fc_mu_w), inv, gs));
   }
@@ -1556,8 +1555,9 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
       float* sc = h->norm_scratch;
       LO_TRY(lo_sumsq_blocks(G + bd + nd, h->flat_elems - (bd + nd), sc + 512, 255, ns));
       LO_TRY(lo_sumsq_blocks(G + bh + nh, bd - (bh + nh), sc + 767, 1, ns));
-      LO_TRY(lo_lowrank_sumsq(WSP(f16, h->o_dml), 2 * L, WSP(f16, h->o_xflat), 32768, B, inv, WSP(float, h->o_gram), sc + 768, 128, ns));
-      LO_TRY(lo_lowrank_sumsq(WSP(f16, h->o_z), L, WSP(f16, h->o_gfc), 32768, B, inv, WSP(float, h->o_gram) + 128 * 128, sc + 896, 128, ns));
+      const LoLowrankNorm nl[2] = {{WSP(f16, h->o_dml), 2 * L, WSP(f16, h->o_xflat), 32768, WSP(float, h->o_gram), sc + 768, 128},
+                                   {WSP(f16, h->o_z), L, WSP(f16, h->o_gfc), 32768, WSP(float, h->o_gram) + 128 * 128, sc + 896, 128}};
+      LO_TRY(lo_lowrank_sumsq(nl, 2, B, inv, ns));
       h->fac_scale = inv;
       h->fac_ready = true;
     } else {

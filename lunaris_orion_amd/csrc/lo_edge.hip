@@ -236,8 +236,18 @@ __global__ __launch_bounds__(256) void lo_colsum_kernel(const float* __restrict_
   const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
   float t = 0.f;
-  if (j < ncol)
-    for (int k = r; k < nrow; k += 16) t += partial[(size_t)k * stride + j];
+  if (j < ncol) {
+    // eight loads in flight per lane, added in row order (the one-load-at-a-time loop chained nrow / 16 round trips: 13 us for 1.7 MB)
+    int k = r;
+    for (; k + 7 * 16 < nrow; k += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + 16 * u) * stride + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; k < nrow; k += 16) t += partial[(size_t)k * stride + j];
+  }
   red[r][c] = t;
   __syncthreads();
   if (r == 0 && j < ncol) {
@@ -257,22 +267,10 @@ __global__ __launch_bounds__(256) void lo_colsum_kernel(const float* __restrict_
 #define LC_CI 32
 #define LC_PITCH 80   // bytes per staged pixel (64 B of channels + 16 B pad)
 
-__device__ __forceinline__ void lc_stage_a4(const f16* __restrict__ a4, unsigned char* tile, int n, int ty, int tx, int tid) {
-  // tile[(y*18 + x)] = a4[n][ty*16 - 1 + y][tx*16 - 1 + x][0..31], zero outside
-  for (int i = tid; i < LC_TP * LC_TP * 4; i += 256) {
-    int ch = i & 3, p = i >> 2;
-    int y = p / LC_TP, xx = p % LC_TP;
-    int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if ((unsigned)iy < 128u && (unsigned)ix < 128u)
-      v = *reinterpret_cast<const u32x4*>(a4 + (((size_t)n * 128 + iy) * 128 + ix) * LC_CI + ch * 8);
-    *reinterpret_cast<u32x4*>(tile + p * LC_PITCH + ch * 16) = v;
-  }
-}
 __device__ __forceinline__ void lc_stage_a4_wide(const f16* __restrict__ a4, unsigned char* tile, int n, int ty, int tx, int tid) {
   // tile[(y*18 + x)] = a4[n][ty*16 - 1 + y][tx*16 - 1 + x][0..31], zero outside.  All six loads of a thread are issued before the
-  // first LDS store (the rolled loop below serialises six global latencies; in the backward kernel the 24 extra registers cost more
-  // than that: 83 -> 131 us, so it keeps the rolled form)
+  // first LDS store (a rolled loop serialises six global latencies).  The backward kernel has no registers for this form (83 -> 131 us
+  // when it was tried there): it stages its patches by LDS-DMA instead
   constexpr int NCH = LC_TP * LC_TP * 4, NIT = (NCH + 255) / 256;
   u32x4 v[NIT];
 #pragma unroll
@@ -390,18 +388,70 @@ struct LcBwdArgs {
 //                   v_mfma_f32_16x16x32_f16 (ci 0..15, 16..31); A gathered from dpre with per-lane byte offsets
 //   weight gradient D[co][ci] += sum_px dpre[px][co] a4[px + tap][ci] per tap: K = 32 pixels (two tile rows), A = dpre^T
 //                   (3 of 16 rows used), B by transposed LDS reads of the a4 tile; 18 accumulators kept across the 8 tiles
-template <int TPW>   // tiles per workgroup: 8 = a whole row of tiles; fewer = more workgroups (the partial buffer holds 64 rows per sample)
-__global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
+// ---------------------------------------------------------------------------------------------
+// Global latencies are kept out of the per-tile chain (round 4).  The first form paid, per tile and one after the other, six
+// global-load round trips of a rolled a4 staging loop, two more for recon / target, the MFMA phases and the store: ~8 us per tile,
+// 63 us per launch (rocprofv3) for 160 MB of traffic; this form takes 45 us.  Here the NEXT tile's a4 patch is already on its way while this tile
+// computes: LDS-DMA (global_load_lds_dwordx4, no registers) into the other of two patch buffers, and the next tile's recon / target
+// (or upstream gradient) values into 12 registers.  The DMA writes pixels at 64-byte pitch (no pad possible: 64 lanes x 16 B land
+// lane-linear).  Out-of-image pixels (and the tail of the last 1-KiB instruction) are fetched from a zero page.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) unsigned int lo_zero_page_e[64];
+#define LC_PATCH_BYTES (21 * 1024)     // 324 pixels x 64 B = 20.25 KiB, in whole 1-KiB DMA instructions
+__device__ __forceinline__ void lc_dma_a4(const f16* __restrict__ a4, unsigned int lds_base, int n, int ty, int tx, int wave, int lane) {
+  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page_e);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {                             // 21 instructions per patch: 6 / 5 / 5 / 5 per wave
+    const int k = wave + 4 * i;                             // wave-uniform (readfirstlane by the caller)
+    if (k >= 21) break;
+    const int q = k * 64 + lane, p = q >> 2, slot = q & 3;
+    const int y = p / LC_TP, xx = p - y * LC_TP;
+    const int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
+    const void* src = zpage + lane * 4;
+    if (p < LC_TP * LC_TP && (unsigned)iy < 128u && (unsigned)ix < 128u) src = a4 + (((size_t)n * 128 + iy) * 128 + ix) * LC_CI + slot * 8;
+    lo_dma16(src, __builtin_amdgcn_readfirstlane(lds_base + k * 1024));
+  }
+}
+__device__ __forceinline__ void lo_dma4(const void* gptr, unsigned int lds_off) {     // 64 lanes x 4 B -> 256 B at lds_off, lane-linear
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_off) : "memory");
+}
+// recon and target (or the upstream gradient) of the 18 x 18 patch as fp32 [2 tensors][3 channels][384] in LDS.  Wave w fetches the
+// pixel blocks 64 w .. 64 w + 63 and 256 + 64 w .. -- exactly the pixels its own threads convert (p = tid, tid + 256), so the
+// readers need this wave's vmcnt(0) only, no barrier.
+__device__ __forceinline__ void lc_dma_rt(const float* __restrict__ recon, const float* __restrict__ gsrc, unsigned int lds_base, int n,
+                                          int ty, int tx, int wave, int lane) {
+  const unsigned char* zpage = reinterpret_cast<const unsigned char*>(lo_zero_page_e);
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int j = wave + 4 * jb;
+    if (j * 64 >= LC_TP * LC_TP) break;
+    const int p = j * 64 + lane;
+    const int y = p / LC_TP, xx = p - y * LC_TP;
+    const int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
+    const bool in = p < LC_TP * LC_TP && (unsigned)iy < 128u && (unsigned)ix < 128u;
+    const size_t o = ((size_t)n * 3 * 128 + iy) * 128 + ix;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lo_dma4(in ? (const void*)(recon + o + c * 16384) : (const void*)(zpage + lane * 4), __builtin_amdgcn_readfirstlane(lds_base + ((0 * 3 + c) * 384 + j * 64) * 4));
+      lo_dma4(in ? (const void*)(gsrc + o + c * 16384) : (const void*)(zpage + lane * 4), __builtin_amdgcn_readfirstlane(lds_base + ((1 * 3 + c) * 384 + j * 64) * 4));
+    }
+  }
+}
+template <int TPW>
+__global__ __launch_bounds__(256, 2) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
   constexpr int SP = 80;                                          // staging pitch of the output tile (bytes per pixel)
-  __shared__ __attribute__((aligned(16))) unsigned char tile[LC_TP * LC_TP * LC_PITCH];  // reused as reduction buffer
+  __shared__ __attribute__((aligned(1024))) unsigned char tile[2][LC_PATCH_BYTES];   // two a4 patches (64-byte pixels); [0] reused as reduction buffer
   __shared__ __attribute__((aligned(16))) f16 dp[LC_TP * LC_TP][8];   // dpre as fp16 hi [0..2] + lo [4..6] (hi + lo ~ 22 bits)
   __shared__ __attribute__((aligned(16))) unsigned char so[256 * SP];
+  __shared__ __attribute__((aligned(256))) float rt[2][3][384];    // recon, target / upstream gradient of the patch (fp32, by DMA)
   __shared__ float bred[4][3];
-  constexpr int WPR = 8 / TPW;                                                       // workgroups per row of tiles
+  constexpr int WPR = 8 / TPW;
   const int tid = threadIdx.x, lane = tid & 63, ty = blockIdx.x / WPR, tx0 = (blockIdx.x % WPR) * TPW, n = blockIdx.y;
-  const int wave = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
   const float cf = a.drecon ? a.gscale : *a.coef;
-  // ---- data-gradient constants: k = 8g + jj -> (tap, co); A byte offset relative to pixel (py, m) of the tile; B = weights
+  const unsigned int tile_lds = (unsigned int)(size_t)(&tile[0][0]);      // LDS byte address (the low 32 bits of a shared pointer)
+  const unsigned int rt_lds = (unsigned int)(size_t)(&rt[0][0][0]);
+  const float* gsrc = a.drecon ? a.drecon : a.target;
   int aoff[8];
   f16x8 wd[2];
 #pragma unroll
@@ -410,37 +460,54 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
     const int tap = kidx / 3, co = kidx - tap * 3, r = tap / 3, sx = tap - r * 3;
     aoff[jj] = kidx < 27 ? (((2 - r) * LC_TP + (2 - sx)) * 8 + co) * 2 : -1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) wd[t][jj] = kidx < 27 ? (f16)a.w[(co * LC_CI + t * 16 + m) * 9 + tap] : (f16)0.f;
+    for (int t = 0; t < 2; ++t) {
+      // unconditional load from a clamped index, then a select: a branch around each load made the 16 loads 16 dependent round trips
+      const float wv = a.w[kidx < 27 ? (co * LC_CI + t * 16 + m) * 9 + tap : 0];
+      wd[t][jj] = kidx < 27 ? (f16)wv : (f16)0.f;
+    }
   }
   f32x4 wacc[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t) { wacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wacc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float bacc0 = 0.f, bacc1 = 0.f, bacc2 = 0.f;
-  const int tq = m >> 2, tsub = (m & 3) * 8;                      // transposed-read lane roles
-  for (int tx = tx0; tx < tx0 + TPW; ++tx) {
-    __syncthreads();                     // previous tile fully consumed
-    lc_stage_a4(a.a4, tile, n, ty, tx, tid);
-    for (int p = tid; p < LC_TP * LC_TP; p += 256) {
-      int y = p / LC_TP, xx = p % LC_TP;
-      int iy = ty * LC_T - 1 + y, ix = tx * LC_T - 1 + xx;
-      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-      if ((unsigned)iy < 128u && (unsigned)ix < 128u) {
-        size_t o = ((size_t)n * 3 * 128 + iy) * 128 + ix;
-        float r0 = a.recon[o], r1 = a.recon[o + 16384], r2 = a.recon[o + 32768];
-        float g0, g1, g2;
-        if (a.drecon) { g0 = a.drecon[o]; g1 = a.drecon[o + 16384]; g2 = a.drecon[o + 32768]; }
-        else { g0 = r0 - a.target[o]; g1 = r1 - a.target[o + 16384]; g2 = r2 - a.target[o + 32768]; }
-        d0 = cf * g0 * (1.f - r0 * r0);
-        d1 = cf * g1 * (1.f - r1 * r1);
-        d2 = cf * g2 * (1.f - r2 * r2);
+  const int tq = m >> 2, tsub = (m & 3) * 8;
+  lc_dma_a4(a.a4, tile_lds, n, ty, tx0, wave, lane);
+  lc_dma_rt(a.recon, gsrc, rt_lds, n, ty, tx0, wave, lane);
+  for (int it = 0; it < TPW; ++it) {
+    const int tx = tx0 + it, cur = it & 1;
+    // ---- dpre of this tile from the values this wave's DMA has staged (zero outside the image: the zero page)
+    // this wave's DMA of THIS tile (patch share + recon / target) has landed.  vmcnt counts loads, stores and LDS-DMA together in
+    // issue order: the four da4 stores of the previous tile are younger than that DMA and may stay in flight
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = tid + h * 256;
+      if (p < LC_TP * LC_TP) {
+        const int y = p / LC_TP, xx = p - y * LC_TP;
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float r0 = rt[0][c][p];
+          const float g0 = a.drecon ? rt[1][c][p] : r0 - rt[1][c][p];
+          d[c] = cf * g0 * (1.f - r0 * r0);
+        }
+        if (y >= 1 && y <= LC_T && xx >= 1 && xx <= LC_T) { bacc0 += d[0]; bacc1 += d[1]; bacc2 += d[2]; }
+        const f16 h0 = (f16)d[0], h1 = (f16)d[1], h2 = (f16)d[2];
+        dp[p][0] = h0; dp[p][1] = h1; dp[p][2] = h2; dp[p][3] = (f16)0.f;
+        dp[p][4] = (f16)(d[0] - (float)h0); dp[p][5] = (f16)(d[1] - (float)h1); dp[p][6] = (f16)(d[2] - (float)h2); dp[p][7] = (f16)0.f;
       }
-      if (y >= 1 && y <= LC_T && xx >= 1 && xx <= LC_T) { bacc0 += d0; bacc1 += d1; bacc2 += d2; }   // bias: the tile's own pixels
-      const f16 h0 = (f16)d0, h1 = (f16)d1, h2 = (f16)d2;
-      dp[p][0] = h0; dp[p][1] = h1; dp[p][2] = h2; dp[p][3] = (f16)0.f;
-      dp[p][4] = (f16)(d0 - (float)h0); dp[p][5] = (f16)(d1 - (float)h1); dp[p][6] = (f16)(d2 - (float)h2); dp[p][7] = (f16)0.f;
     }
-    __syncthreads();
+    // raw barriers inside the loop: __syncthreads() would drain the LDS-DMA that is in flight across it (it is a pending LDS write
+    // on the VM counter); the LDS traffic of the ordinary ds instructions is ordered by the explicit lgkmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // everybody's patch share has landed; dp is complete; the other patch buffer and rt are free
+    if (it + 1 < TPW) {
+      lc_dma_a4(a.a4, tile_lds + (cur ^ 1) * LC_PATCH_BYTES, n, ty, tx + 1, wave, lane);
+      lc_dma_rt(a.recon, gsrc, rt_lds, n, ty, tx + 1, wave, lane);
+    }
     const unsigned char* dpb = reinterpret_cast<const unsigned char*>(&dp[0][0]);
+    const unsigned char* tb = &tile[cur][0];
     // ---- data gradient: wave w owns tile rows 4w .. 4w+3
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -452,7 +519,6 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, wd[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        // D: column = ci (lane & 15), rows = pixels 4g + reg of this tile row
 #pragma unroll
         for (int e = 0; e < 4; ++e) *reinterpret_cast<f16*>(so + (py * 16 + 4 * g + e) * SP + (t * 16 + m) * 2) = (f16)d[e];
       }
@@ -461,8 +527,6 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int c = wave * 2 + cc;
-      // A = dpre^T: row = co (m < 3), k = pixels {row 2c: 4g..4g+3, row 2c+1: 4g..4g+3}; hi and lo halves: the weight
-      // gradient keeps the precision of an fp32 dpre (the MFMAs are not what this kernel waits for)
       f16x8 af, al;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -475,28 +539,33 @@ __global__ __launch_bounds__(256) void lo_final_conv_bwd_kernel(LcBwdArgs a) {
         const int r = t9 / 3, sx = t9 - r * 3;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const unsigned char* p0 = tile + ((2 * c + r) * LC_TP + 4 * g + tq + sx) * LC_PITCH + t * 32 + tsub;
+          // (64-byte pixels: the two groups of four pixels a 32-lane half touches share banks, a 2-way conflict on a read path that
+          // is 5x under the MFMA time; a swizzle would make every tap's address a register of its own -- 36 of them -- in a
+          // kernel that has none to spare)
+          const unsigned char* p0 = tb + ((2 * c + r) * LC_TP + 4 * g + tq + sx) * 64 + t * 32 + tsub;
           h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)p0);
-          h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(p0 + LC_TP * LC_PITCH));
+          h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((h16x4 __attribute__((address_space(3)))*)(p0 + LC_TP * 64));
           f16x8 bf = (f16x8){(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
           wacc[t9][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, wacc[t9][t], 0, 0, 0);
           wacc[t9][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bf, wacc[t9][t], 0, 0, 0);
         }
       }
     }
-    __syncthreads();
-    // ---- staged data gradient -> global (16-byte chunks; a tile row is 1 KiB contiguous in NHWC)
-    for (int i = tid; i < 256 * 4; i += 256) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- staged data gradient -> global (16-byte chunks; a tile row is 1 KiB contiguous in NHWC): exactly four stores per thread
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
       const int px = i >> 2, ch = i & 3;
       const int oy = ty * LC_T + (px >> 4), ox = tx * LC_T + (px & 15);
       *reinterpret_cast<u32x4*>(a.da4 + (((size_t)n * 128 + oy) * 128 + ox) * LC_CI + ch * 8) =
           *reinterpret_cast<const u32x4*>(so + px * SP + ch * 16);
     }
   }
-  __syncthreads();                       // everyone is done with the a4 tile: reuse it for the reduction
-  float* red = reinterpret_cast<float*>(tile);   // [4 waves][27][32] floats = 13824 B
-  static_assert(LC_TP * LC_TP * LC_PITCH >= 4 * 27 * 32 * 4, "reduction buffer");
-  // D of the weight gradient: column = ci (lane & 15), rows = co 4g + reg: lanes 0..15 (g = 0), reg 0..2
+  __syncthreads();                       // everyone is done with the patches: reuse the first for the reduction
+  float* red = reinterpret_cast<float*>(&tile[0][0]);   // [4 waves][27][32] floats = 13824 B
+  static_assert(LC_PATCH_BYTES >= 4 * 27 * 32 * 4, "reduction buffer");
   if (g == 0) {
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9)

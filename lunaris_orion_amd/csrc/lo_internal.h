@@ -151,10 +151,11 @@ int lo_decode_sprites(const uint8_t* u8, float* out, int B, hipStream_t st);
 // lo_lowrank.hip: rank-B Linear-layer weight gradients as factors (Gram-matrix norm, AdamW that forms the gradient tiles itself)
 int lo_lowrank_bp(int B);                          // batch rounded up to the MFMA K step (32)
 bool lo_lowrank_applies(int B, int N, int K);
-int lo_transpose_pad_f16(const f16* src, f16* dst, int R, int C, int Rp, hipStream_t st);
-int lo_lowrank_sumsq(const f16* fshort, int n_short, const f16* flong, int n_long, int B, float scale, float* gram, float* partial,
-                     int nslots, hipStream_t st);
-int lo_adamw_lowrank(float* p, float* m, float* v, f16* cast, const f16* xt, const f16* yt, int N, int K, int B, float gscale,
-                     const float* norm, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t st);
+int lo_transpose_pad_f16_multi(const f16* const* src, f16* const* dst, const int* C, int njobs, int R, int Rp, hipStream_t st);
+struct LoLowrankNorm { const f16* fshort; int n_short; const f16* flong; int n_long; float* gram; float* partial; int nslots; };
+int lo_lowrank_sumsq(const LoLowrankNorm* layers, int nlayers, int B, float scale, hipStream_t st);
+struct LoLowrankMat { float* p; float* m; float* v; f16* cast; const f16* xt; const f16* yt; int N, K; };   // W [N][K]; xt [K][Bp], yt [N][Bp]
+int lo_adamw_lowrank(const LoLowrankMat* mats, int nmat, int B, float gscale, const float* norm, float lr, float beta1, float beta2,
+                     float eps, float wd, int step, hipStream_t st);
 int lo_lowrank_materialize(float* gout, const f16* xt, const f16* yt, int N, int K, int B, float gscale, hipStream_t st);
 int lo_sumsq_blocks(const float* g, size_t n, float* partial, int nblocks, hipStream_t st);   // lo_train.hip: partial[0 .. nblocks)
