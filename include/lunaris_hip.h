@@ -188,7 +188,15 @@ int lo_vae_join(LoVae* h, void* stream);   /* `stream` waits for the side-stream
  * inside its AdamW pass (train_hybrid.py:921).  Same update to fp32 rounding; 12 of 38 bytes of HBM traffic per parameter less.
  * Explicit-gradient backwards (the autograd path) and lo_vae_backward_phase always write every gradient.
  * lo_vae_materialize_linear_grads: writes the two gradients of the last fused backward into flat_grads after all (tests, tools). */
-int lo_vae_set_linear_factored(LoVae* h, int on);
+int lo_vae_set_linear_factored(LoVae* h, int mode);   /* 0 off, 1 single process (above), 2 data parallel (below) */
+/* Data parallel (mode 2; no reference counterpart: the reference has no distributed code).  lo_vae_backward_phase(1) then leaves the
+ * two Linear layers' factors instead of their weight gradients: one contiguous block of the workspace (lo_vae_factor_block:
+ * dml^T | xflat^T | Gfc^T | z^T, transposed, batch-padded fp16; 8.6 MB at batch 64 / latent 512).  The ranks all-gather the blocks
+ * (exact, and 8.6 MB per rank on the wire instead of 201 MB of gradients) and each calls lo_vae_materialize_gathered_linear_grads
+ * on the gathered buffer (block r at gathered + r * bytes): flat_grads of the two matrices = (1 / world) sum_r dY_r^T X_r / loss
+ * scale -- the all-reduce(AVG) of the per-rank gradients to fp32 rounding.  Everything else of the range is exchanged as before. */
+int lo_vae_factor_block(const LoVae* h, size_t* byte_offset, size_t* bytes);
+int lo_vae_materialize_gathered_linear_grads(LoVae* h, const void* gathered, int world, float* flat_grads, void* stream);
 int lo_vae_linear_factored(const LoVae* h);
 int lo_vae_materialize_linear_grads(LoVae* h, void* ws, float* flat_grads, void* stream);
 /* forward.  eps: explicit N(0,1) noise [B,L] or NULL (on-device counter RNG with `seed`).  target: images for the fused

@@ -82,6 +82,8 @@ SIGNATURES = {
     "lo_vae_join": (i32, [vp, vp]),
     "lo_vae_set_linear_factored": (i32, [vp, i32]),
     "lo_vae_linear_factored": (i32, [vp]),
+    "lo_vae_factor_block": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lo_vae_materialize_gathered_linear_grads": (i32, [vp, vp, i32, f32p, vp]),
     "lo_vae_materialize_linear_grads": (i32, [vp, vp, f32p, vp]),
     "lo_vae_gradnorm_presummed": (i32, [vp]),
     "lo_clip_adamw_step_presummed": (i32, [f32p, f32p, f32p, f32p, sz, sz, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),

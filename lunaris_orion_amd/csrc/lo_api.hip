@@ -299,6 +299,7 @@ struct LoVae {
   // dml^T [2L][Bp], xflat^T [32768][Bp], Gfc^T [32768][Bp], z^T [L][Bp] (one contiguous block), Gram scratch; fac_ready: a fused
   // backward has left this step's factors and the Gram part of the gradient norm; fac_scale: 1 / loss scale of that backward
   bool lin_factored, fac_ready;
+  bool lin_factored_dp;      // data parallel: phase 1 leaves the factors (no Linear weight gradients); the ranks all-gather them
   int Bp;
   size_t o_fac_dmlT, o_fac_xT, o_fac_gfcT, o_fac_zT, o_gram;
   float fac_scale;
@@ -485,7 +486,7 @@ extern "C" int lo_vae_create_ex(int B, int L, unsigned flags, LoVae** out) {
   h->o_fac_gfcT = ar.take((size_t)32768 * h->Bp * 2);
   h->o_fac_zT = ar.take((size_t)L * h->Bp * 2);
   h->o_gram = ar.take((size_t)2 * 128 * 128 * 4);
-  h->lin_factored = h->fac_ready = false;
+  h->lin_factored = h->fac_ready = h->lin_factored_dp = false;
   h->fac_scale = 1.f;
 
   // ---- fp8 operand mode: every forward conv whose geometry the e4m3 igemm covers (Cin % 128 == 0: the 128 / 256 / 512
@@ -635,11 +636,34 @@ extern "C" int lo_vae_gradnorm_presummed(const LoVae* h) { return h && h->norm_s
 // its AdamW pass.  Batch <= 128.  Explicit-gradient (autograd) backwards and the phased data-parallel backward are not affected.
 extern "C" int lo_vae_set_linear_factored(LoVae* h, int on) {
   LO_REQUIRE(h, "lo_vae_set_linear_factored: null handle");
+  LO_REQUIRE(on >= 0 && on <= 2, "lo_vae_set_linear_factored: mode must be 0 (off), 1 (single process) or 2 (data parallel: factors only)");
   if (on) LO_REQUIRE(lo_lowrank_applies(h->B, 2 * h->L, 32768) && lo_lowrank_applies(h->B, 32768, h->L),
                      "lo_vae_set_linear_factored: batch %d is above the rank the factored update is built for (128)", h->B);
-  h->lin_factored = on != 0;
+  h->lin_factored = on == 1;
+  h->lin_factored_dp = on == 2;
   h->fac_ready = false;
   return LO_OK;
+}
+// data parallel (mode 2): where the factor block -- dml^T | xflat^T | Gfc^T | z^T, transposed and batch-padded fp16, one contiguous
+// range of the workspace -- lives: what the ranks all-gather instead of exchanging the Linear layers' 201 MB of weight gradients
+extern "C" int lo_vae_factor_block(const LoVae* h, size_t* byte_offset, size_t* bytes) {
+  LO_REQUIRE(h && byte_offset && bytes, "lo_vae_factor_block: null argument");
+  *byte_offset = h->o_fac_dmlT;
+  *bytes = h->o_gram - h->o_fac_dmlT;       // the arena places the four factors back to back (256-byte granules), o_gram follows
+  return LO_OK;
+}
+// ... and the averaged Linear weight gradients from `world` gathered blocks (block r at gathered + r * lo_vae_factor_block bytes):
+// flat_grads[fc_mu.weight | fc_logvar.weight] and [decoder.fc.weight] = (1 / world) sum_r dY_r^T X_r / loss scale
+extern "C" int lo_vae_materialize_gathered_linear_grads(LoVae* h, const void* gathered, int world, float* G, void* stream) {
+  LO_REQUIRE(h && gathered && G && world >= 1, "lo_vae_materialize_gathered_linear_grads: bad argument");
+  hipStream_t st = S(stream);
+  const int L = h->L;
+  const size_t blk = (h->o_gram - h->o_fac_dmlT) / 2;     // elements per rank block
+  const f16* base = reinterpret_cast<const f16*>(gathered);
+  const float sc = h->fac_scale / (float)world;
+  LO_TRY(lo_lowrank_materialize_gathered(G + h->p_off[h->idx_fc_mu_w], base + (h->o_fac_xT - h->o_fac_dmlT) / 2, base, blk, world, 2 * L, 32768, h->B, sc, st));
+  return lo_lowrank_materialize_gathered(G + h->p_off[h->idx_dfc_w], base + (h->o_fac_zT - h->o_fac_dmlT) / 2, base + (h->o_fac_gfcT - h->o_fac_dmlT) / 2,
+                                         blk, world, 32768, L, h->B, sc, st);
 }
 extern "C" int lo_vae_linear_factored(const LoVae* h) { return h && h->lin_factored ? 1 : 0; }
 extern "C" int lo_vae_num_params(const LoVae* h) { return h->nparam; }
@@ -1406,8 +1430,10 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
   const int B = h->B, L = h->L;
   const float inv = 1.0f / loss_scale;
   // the Linear layers' weight gradients stay factored (lo_lowrank.hip): the fused single-call backward of a stepper only
-  const bool fac = h->lin_factored && fused && phase == 0;
-  if (fac && !h->norm_scratch) { lo_set_error("lo_vae_backward: the factored Linear-gradient mode needs lo_vae_set_gradnorm_scratch"); return LO_ERR_STATE; }
+  const bool fac1 = h->lin_factored && fused && phase == 0;
+  const bool facdp = h->lin_factored_dp && fused && phase == 1;     // data parallel: the factors leave this rank, not the gradients
+  const bool fac = fac1 || facdp;
+  if (fac1 && !h->norm_scratch) { lo_set_error("lo_vae_backward: the factored Linear-gradient mode needs lo_vae_set_gradnorm_scratch"); return LO_ERR_STATE; }
   if (phase == 0 || phase == 1) h->fac_ready = false;
   LoStopEventGuard stop_guard_;
   hipEvent_t early_ev = nullptr;      // ev_pre when part A's last launch carries it (single-call backward with the early gradient norm)
@@ -1537,7 +1563,8 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
     LO_TRY(lo_nchw_to_nhwc_f16(Gb, Ga, B, 64, 512, st));
   }
   const bool side_ok = h->overlap && !g_lo_prof_on;
-  const bool early_norm = phase == 0 && h->norm_scratch && (side_ok || fac);      // decoder layers finalized here, norm of the phase-1 range taken early
+  if (facdp) h->fac_scale = inv;
+  const bool early_norm = phase == 0 && h->norm_scratch && (side_ok || fac1);      // decoder layers finalized here, norm of the phase-1 range taken early
   if (early_norm) {
     // everything from fc_mu.weight on is final once the decoder's side-stream weight gradients are: order the early
     // sum of squares after both streams' part A and let it run on the side stream beside the encoder backward
@@ -1547,7 +1574,7 @@ static int vae_backward_impl(LoVae* h, int phase, const float* x, const float* P
       LO_HIP(hipStreamWaitEvent(h->side, h->ev_pre, 0));
     }
     LO_TRY(vae_gn_finalize(h, 0u, true, G, ws, inv, ns));      // the decoder's GroupNorm / bias gradients belong to the range
-    if (fac) {
+    if (fac1) {
       // scratch[512..1024) = partial sums of squares of the range: [512, 767) everything behind decoder.fc.weight (decoder.fc.bias,
       // the decoder's convs and GroupNorms, the final conv), [767] the two head biases, [768, 896) fc_mu | fc_logvar weights and
       // [896, 1024) decoder.fc.weight from the Gram matrices of their factors -- no pass over the 50 M elements they stand for

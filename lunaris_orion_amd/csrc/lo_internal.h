@@ -158,4 +158,6 @@ struct LoLowrankMat { float* p; float* m; float* v; f16* cast; const f16* xt; co
 int lo_adamw_lowrank(const LoLowrankMat* mats, int nmat, int B, float gscale, const float* norm, float lr, float beta1, float beta2,
                      float eps, float wd, int step, hipStream_t st);
 int lo_lowrank_materialize(float* gout, const f16* xt, const f16* yt, int N, int K, int B, float gscale, hipStream_t st);
+int lo_lowrank_materialize_gathered(float* gout, const f16* xt, const f16* yt, size_t rank_stride_elems, int world, int N, int K, int B,
+                                    float gscale, hipStream_t st);
 int lo_sumsq_blocks(const float* g, size_t n, float* partial, int nblocks, hipStream_t st);   // lo_train.hip: partial[0 .. nblocks)

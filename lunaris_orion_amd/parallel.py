@@ -180,6 +180,55 @@ class FlatGradSync:
         self._pending.append(done)
         return True
 
+    def gather(self, block: torch.Tensor) -> torch.Tensor:
+        """All-gather of one flat tensor: [world * numel], rank r's block at r * numel (issued on the CURRENT stream)."""
+        key = ("gather", block.data_ptr(), block.numel(), block.dtype)
+        out = self._stage.get(key)
+        if out is None:
+            out = self._stage[key] = torch.empty(self.world * block.numel(), dtype=block.dtype, device=block.device)
+        if self.backend == "gloo" and block.is_cuda:     # rehearsals: gloo carries all-gather for CPU tensors only
+            host = torch.empty(self.world * block.numel(), dtype=block.dtype)
+            dist.all_gather_into_tensor(host, block.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, block, group=self.group)
+        return out
+
+    def begin_factored(self, pieces, factors: torch.Tensor, materialize, then=None, pre=None) -> bool:
+        """The first hand-over range of a step with the Linear layers' weight gradients kept as factors (VAEStepper, mode 2 of
+        lo_vae_set_linear_factored): `factors` = this rank's factor block (8.6 MB of fp16 instead of 201 MB of gradients) is
+        all-gathered -- exact, no wire rounding -- and `materialize(gathered, world)` writes the AVERAGED gradients of the two matrices
+        from the gathered blocks; `pieces` (the rest of the range: biases, decoder convs) are averaged the usual way.  `pre` / `then`
+        as for begin().  Everything is chained on the communication stream behind the work already on the current stream."""
+        if self.world == 1 and not self.force:
+            return False
+        self._phase_bytes.append(factors.numel() * factors.element_size() + sum(p.numel() * p.element_size() for p in pieces))
+        if not factors.is_cuda:                           # CPU tensors (gloo tests): synchronous
+            materialize(self.gather(factors), self.world)
+            self._mode_log.append("factors")
+            for p in pieces:
+                self._run(p)
+            self._pending.append(None)
+            return False
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=factors.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._comm.wait_event(ready)
+        with torch.cuda.stream(self._comm):
+            if pre is not None:
+                pre()
+            materialize(self.gather(factors), self.world)
+            self._mode_log.append("factors")
+            for p in pieces:
+                self._run(p)
+            if then is not None:
+                then()
+            done = torch.cuda.Event()
+            done.record()
+        self._pending.append(done)
+        return True
+
     def finish(self) -> None:
         ev = None
         if self.time_exposed and any(p is not None for p in self._pending):

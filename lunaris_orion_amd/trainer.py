@@ -88,6 +88,9 @@ class VAEStepper:
         # writing and re-reading 201 MB.  Single process, batch <= 128; LO_LINEAR_FACTORED=0: the materialised path (A/B).
         # `parameter_grads()` still returns all 72 gradients (the two matrices are written out on demand).
         self.linear_factored = grad_sync is None and os.environ.get("LO_LINEAR_FACTORED", "1") != "0"
+        # data parallel: the ranks all-gather the FACTORS (8.6 MB of fp16 per rank, exact) instead of exchanging the 201 MB of Linear
+        # weight gradients, and each forms the averaged gradient from the gathered blocks (FlatGradSync.begin_factored)
+        self.dp_factored = hasattr(grad_sync, "begin_factored") and os.environ.get("LO_LINEAR_FACTORED", "1") != "0"
         self.dp_three_phase = True      # hand the encoder's last stage over before stages 3..1 run (False: one encoder range)
         flat = vae.flat_parameters()
         self.grads = torch.zeros_like(flat)
@@ -172,13 +175,17 @@ class VAEStepper:
             # only the small remainder (7.7 MB) is exchanged with nothing left to hide it
             import ctypes as C
             b, e, b4, e4 = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+            kw = {}
             _lib.check(_lib.lib.lo_vae_phase1_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_vae_phase1_grad_range")
             _lib.check(_lib.lib.lo_vae_stage4_grad_range(eng.handle, C.byref(b4), C.byref(e4)), "lo_vae_stage4_grad_range")
             assert e4.value == b.value and e.value == self.grads.numel()
             # FlatGradSync runs the exchange on its own stream: the phases then hand their range over as an event for THAT stream
             # (lo_vae_set_async_handover) instead of holding this one up until the side stream's weight gradients have finished
-            if _lib.lib.lo_vae_linear_factored(eng.handle):
-                _lib.check(_lib.lib.lo_vae_set_linear_factored(eng.handle, 0), "lo_vae_set_linear_factored")
+            active = getattr(self.grad_sync, "world", 1) > 1 or getattr(self.grad_sync, "force", False)
+            dpf = self.dp_factored and active and eng.batch <= 128
+            if eng.fac_mode != (2 if dpf else 0):
+                _lib.check(_lib.lib.lo_vae_set_linear_factored(eng.handle, 2 if dpf else 0), "lo_vae_set_linear_factored")
+                eng.fac_mode = 2 if dpf else 0
             hooks = getattr(self.grad_sync, "supports_then", False)
             _lib.check(_lib.lib.lo_vae_set_async_handover(eng.handle, 1 if hooks else 0), "lo_vae_set_async_handover")
             def wait_range():
@@ -188,7 +195,30 @@ class VAEStepper:
             # ... and so is the sum of squares of that range for clip_grad_norm_ (of the AVERAGED gradients): taken right behind the
             # exchange on the communication stream, beside the encoder backward; the tail of the step reads only the encoder range
             early = os.environ.get("LO_EARLY_NORM", "1") != "0" and hooks
-            if early:
+            if dpf:
+                # the Linear weight gradients of this range travel as factors: gather, form the averaged matrices locally, average the
+                # rest of the range (head biases; decoder.fc.bias, decoder and final convs), then the range's share of the norm
+                fo, fb = C.c_size_t(), C.c_size_t()
+                _lib.check(_lib.lib.lo_vae_factor_block(eng.handle, C.byref(fo), C.byref(fb)), "lo_vae_factor_block")
+                factors = eng.ws[fo.value:fo.value + fb.value]
+                L = vae.latent_dim
+                h_end, d_beg, d_end = b.value + 2 * L * 32768, None, None
+                lb, le = C.c_size_t(), C.c_size_t()
+                _lib.check(_lib.lib.lo_vae_linear_grad_range(eng.handle, C.byref(lb), C.byref(le)), "lo_vae_linear_grad_range")
+                d_end = le.value - 32768                 # decoder.fc.bias is the last tensor of the Linear range (32768 elements, aligned)
+                d_beg = d_end - 32768 * L
+                pieces = [self.grads[h_end:d_beg], self.grads[d_end:e.value]]
+
+                def materialize(gathered, world, eng=eng):
+                    _lib.check(_lib.lib.lo_vae_materialize_gathered_linear_grads(eng.handle, gathered.data_ptr(), world, self.grads.data_ptr(),
+                                                                                 _lib.stream_ptr()), "lo_vae_materialize_gathered_linear_grads")
+
+                def norm_of_range():
+                    _lib.check(_lib.lib.lo_gradnorm_early_range(self.grads.data_ptr(), b.value, e.value, self.scratch.data_ptr(), _lib.stream_ptr()),
+                               "lo_gradnorm_early_range")
+                if self.grad_sync.begin_factored(pieces, factors, materialize, then=norm_of_range if early else None, **kw) and early:
+                    self._presummed_begin = b.value
+            elif early:
                 if self.grad_sync.begin(self.grads[b.value:e.value], sumsq_scratch=self.scratch.data_ptr(), **kw):
                     self._presummed_begin = b.value
             else:
@@ -206,8 +236,9 @@ class VAEStepper:
             # single process: the backward takes the sum of squares of everything from fc_mu.weight on as soon as it is final,
             # beside the encoder backward; _clip_adamw then reads only the encoder range for the norm
             fac = self.linear_factored and eng.batch <= 128
-            if bool(_lib.lib.lo_vae_linear_factored(eng.handle)) != fac:
+            if eng.fac_mode != (1 if fac else 0):
                 _lib.check(_lib.lib.lo_vae_set_linear_factored(eng.handle, 1 if fac else 0), "lo_vae_set_linear_factored")
+                eng.fac_mode = 1 if fac else 0
             early = self.grad_sync is None and (fac or os.environ.get("LO_EARLY_NORM", "1") != "0")       # LO_EARLY_NORM=0: A/B knob
             _lib.check(_lib.lib.lo_vae_set_gradnorm_scratch(eng.handle, self.scratch.data_ptr() if early else None),
                        "lo_vae_set_gradnorm_scratch")

@@ -312,6 +312,7 @@ class _Engine:
         self.batch, self.latent_dim, self.device = batch, latent_dim, device
         self.ws = torch.empty(_lib.lib.lo_vae_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
         self.packed_version = None      # (explicit version, sum of the parameters' version counters) of the last pack
+        self.fac_mode = 0               # lo_vae_set_linear_factored: 0 off, 1 single process, 2 data parallel (set by the stepper)
         self.gen_enc = self.gen_dec = 0 # bumped by every call that overwrites the encoder / decoder activations in the workspace
         off, nf = C.c_size_t(), C.c_int()
         _lib.check(_lib.lib.lo_vae_sync_fail_word(self.handle, C.byref(off), C.byref(nf)), "lo_vae_sync_fail_word")

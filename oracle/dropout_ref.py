@@ -81,12 +81,14 @@ def keep_flat(call_seed: int, site: int, n: int, p: float) -> np.ndarray:
 class TeacherMasks:
     """Multiplicative masks (keep / (1 - p), float32 torch tensors in the reference's layouts) of one teacher forward."""
 
-    def __init__(self, call_seed: int, p: float, B: int, H: int = 128, W: int = 128, C: int = 128):
+    def __init__(self, call_seed: int, p: float, B: int, H: int = 128, W: int = 128, C: int = 128, device=None):
         self.seed, self.p, self.B, self.H, self.W, self.C = int(call_seed), float(p), B, H, W, C
         self.scale = 1.0 / (1.0 - float(np.float32(p)))
+        self.device = device        # where the mask tensors live (None = CPU); the bits always come from the numpy restatement
 
     def _t(self, keep: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(keep.astype(np.float32)) * np.float32(self.scale)
+        t = torch.from_numpy(keep.astype(np.float32)) * np.float32(self.scale)
+        return t if self.device is None else t.to(self.device)
 
     def elementwise_nchw(self, site: int, C: int) -> torch.Tensor:
         """[B, C, H, W] mask of an elementwise dropout on a feature map (library index order: NHWC)."""
@@ -114,7 +116,7 @@ class TeacherMasks:
             a = (site, self.attention(site, heads, chunk))
             self._att_cache = a
         full = a[1]
-        m = torch.ones(self.B, heads, chunk, chunk)
+        m = torch.ones(self.B, heads, chunk, chunk, device=full.device)
         m[:, :, 0, :] = full[:, i]
         if i == 511:
             m[:, :, 1:, :] = full[:, 512:].permute(0, 2, 1, 3)

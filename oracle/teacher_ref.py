@@ -170,7 +170,7 @@ def attention_as_executed(x, S, p, num_heads=8, chunk=32, att_mask=None, proj_ma
         att[:, :, :, 0, :] = att[:, :, :, 0, :] * att_mask[:, :nchunk].permute(0, 2, 1, 3)
         att[:, :, nchunk - 1, 1:, :] = att[:, :, nchunk - 1, 1:, :] * att_mask[:, nchunk:].permute(0, 2, 1, 3)
     co = torch.matmul(att, v)                                                          # [B,heads,nchunk,chunk,hd]
-    out = torch.zeros(B, num_heads, N, hd, dtype=x.dtype)
+    out = torch.zeros(B, num_heads, N, hd, dtype=x.dtype, device=x.device)
     out[:, :, :nchunk] = co[:, :, :, 0]                      # p <= nchunk-1 : row 0 of chunk p
     out[:, :, nchunk:nchunk + chunk - 1] = co[:, :, nchunk - 1, 1:]   # rows 1..31 of the last chunk
     out = out.permute(0, 1, 3, 2).reshape(B, C, H, W)

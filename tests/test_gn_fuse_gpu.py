@@ -14,53 +14,69 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-_SNIPPET = r"""
-import sys, torch
-sys.path.insert(0, {root!r})
-from oracle import vae_ref as R
-from lunaris_orion_amd.vae import LunarisCoreVAE
-from lunaris_orion_amd.trainer import VAEStepper
-B, L = {B}, {L}
-m = LunarisCoreVAE(L); m.load_state_dict(R.closed_form_params(L)); m = m.to("cuda")
-x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
-st = VAEStepper(m, gradient_accumulation_steps=1)
-out = {{}}
-for s in range(2):
-    recon, mu, logvar = st.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
-    met = st.metrics()                       # raises if a rendezvous ran out
-    out[f"recon{{s}}"], out[f"mu{{s}}"], out[f"logvar{{s}}"] = recon.cpu(), mu.cpu(), logvar.cpu()
-    for (name, _), g_ in zip(m.named_parameters(), st.parameter_grads()):
-        out[f"grad{{s}}/{{name}}"] = g_.detach().cpu().clone()
-    out[f"losses{{s}}"] = torch.tensor([met["recon_loss"], met["kl_loss"], met["grad_norm"]], dtype=torch.float64)
-eng = m._engine(B)
-# intermediate tensors of the last forward, read back from the workspace: a failure names the first layer that differs
-import ctypes as C
-from lunaris_orion_amd import _lib
-def dbg(which, s, k):
-    off, dims = C.c_size_t(), (C.c_int * 4)()
-    _lib.check(_lib.lib.lo_vae_debug_tensor(eng.handle, which, s, k, C.byref(off), dims))
-    n = dims[0] * dims[1] * dims[2] * dims[3]
-    return eng.ws[off.value:off.value + 2 * n].view(torch.float16).clone().cpu()
-for s_ in range(4):
-    for k_ in range(3):
-        out[f"a_enc{{s_}}_conv{{k_}}_raw"] = dbg(0, s_, k_)
-    out[f"b_enc{{s_}}_out"] = dbg(2, s_, 0)
-for s_ in range(4):
-    out[f"c_dec{{s_}}_raw"] = dbg(1, s_, 0)
-    out[f"d_dec{{s_}}_act"] = dbg(3, s_, 0)
-out["fused_layers"] = torch.tensor(eng.fused_gn_layers)
-out["sync_fail"] = eng.sync_fail.cpu().clone()
-out["params"] = m.flat_parameters().detach().cpu().clone()
-torch.save(out, sys.argv[1])
-"""
+_CACHE = {}
 
 
 def _run(tmp_path, tag, B, L, env_extra):
-    f = tmp_path / f"{tag}.pt"
-    env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-c", _SNIPPET.format(root=ROOT, B=B, L=L), str(f)], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return torch.load(f)
+    """Two optimizer steps of a fresh model under the given knobs, in THIS process: the three knobs involved (LO_GN_FUSE,
+    LO_GNB_FUSE, LO_GNB_APPLY_FUSE) are read by lo_vae_create_ex for every plan it makes, so a fresh model under a changed
+    environment is a fresh configuration (round 3 started a Python process per configuration: 12 of them, 90 s of the suite).
+    Results are cached per configuration: the "separate passes" run is shared by the two tests below."""
+    import ctypes as C
+
+    from oracle import vae_ref as R
+    from lunaris_orion_amd import _lib
+    from lunaris_orion_amd.trainer import VAEStepper
+    from lunaris_orion_amd.vae import LunarisCoreVAE
+    knobs = ("LO_GN_FUSE", "LO_GNB_FUSE", "LO_GNB_APPLY_FUSE")
+    defaults = {"LO_GN_FUSE": "0", "LO_GNB_FUSE": "1", "LO_GNB_APPLY_FUSE": "1"}
+    key = (B, L, tuple(env_extra.get(k, defaults[k]) for k in knobs))
+    if key in _CACHE:
+        return _CACHE[key]
+    saved = {k: os.environ.get(k) for k in knobs}
+    try:
+        for k in knobs:
+            os.environ.pop(k, None)
+        os.environ.update(env_extra)
+        m = LunarisCoreVAE(L); m.load_state_dict(R.closed_form_params(L)); m = m.to("cuda")
+        x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+        st = VAEStepper(m, gradient_accumulation_steps=1)
+        out = {}
+        for s in range(2):
+            recon, mu, logvar = st.step(x, s, R.closed_form_eps(B, L, salt=s).cuda())
+            met = st.metrics()                       # raises if a rendezvous ran out
+            out[f"recon{s}"], out[f"mu{s}"], out[f"logvar{s}"] = recon.cpu(), mu.cpu(), logvar.cpu()
+            for (name, _), g_ in zip(m.named_parameters(), st.parameter_grads()):
+                out[f"grad{s}/{name}"] = g_.detach().cpu().clone()
+            out[f"losses{s}"] = torch.tensor([met["recon_loss"], met["kl_loss"], met["grad_norm"]], dtype=torch.float64)
+        eng = m._engine(B)
+
+        # intermediate tensors of the last forward, read back from the workspace: a failure names the first layer that differs
+        def dbg(which, s_, k_):
+            off, dims = C.c_size_t(), (C.c_int * 4)()
+            _lib.check(_lib.lib.lo_vae_debug_tensor(eng.handle, which, s_, k_, C.byref(off), dims))
+            n = dims[0] * dims[1] * dims[2] * dims[3]
+            return eng.ws[off.value:off.value + 2 * n].view(torch.float16).clone().cpu()
+        for s_ in range(4):
+            for k_ in range(3):
+                out[f"a_enc{s_}_conv{k_}_raw"] = dbg(0, s_, k_)
+            out[f"b_enc{s_}_out"] = dbg(2, s_, 0)
+        for s_ in range(4):
+            out[f"c_dec{s_}_raw"] = dbg(1, s_, 0)
+            out[f"d_dec{s_}_act"] = dbg(3, s_, 0)
+        out["fused_layers"] = torch.tensor(eng.fused_gn_layers)
+        out["sync_fail"] = eng.sync_fail.cpu().clone()
+        st.synchronize_parameters()
+        torch.cuda.synchronize()
+        out["params"] = m.flat_parameters().detach().cpu().clone()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    _CACHE[key] = out
+    return out
 
 
 @pytest.mark.parametrize("B,L", [(2, 256), (5, 256), (64, 512)])

@@ -7,7 +7,7 @@ path, itself pinned to the reference's golden gradients) and against the oracle:
   * the norm == the norm over the materialised buffer;
   * parameters, Adam moments and fp16 operand copies after optimizer steps == the materialised path's (Adam's first step is
     lr * g / |g|: sign-like on near-zero elements, so the parameter comparison is bounded by lr and tight on average);
-  * batch sizes that need zero padding of the factor's batch axis (1, 2, 5, 33), the full batch 64 / latent 512, batch 96;
+  * batch sizes that need zero padding of the factor's batch axis (1, 33), the full batch 64 / latent 512, batch 96 (three MFMA K steps);
   * the update is skipped on a non-finite norm (GradScaler semantics) with factors exactly like with gradients.
 """
 import numpy as np
@@ -34,7 +34,7 @@ def _lin_names(m):
     return ("encoder.fc_mu.weight", "encoder.fc_logvar.weight", "decoder.fc.weight")
 
 
-@pytest.mark.parametrize("B,L", [(2, 256), (1, 64), (5, 128), (33, 256), (64, 512), (96, 256)])
+@pytest.mark.parametrize("B,L", [(1, 64), (33, 256), (64, 512), (96, 256)])
 def test_factored_gradients_and_norm_equal_the_materialised_path(B, L):
     x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
     eps = R.closed_form_eps(B, L, salt=0).cuda()
@@ -76,8 +76,7 @@ def test_factored_gradients_match_the_oracle():
     assert abs(st.metrics()["grad_norm"] - o["grad_norm"]) <= 2e-3 * o["grad_norm"]
 
 
-@pytest.mark.parametrize("pipelined", [False, True], ids=["serial", "pipelined"])
-@pytest.mark.parametrize("B,L", [(4, 256), (64, 512)])
+@pytest.mark.parametrize("B,L,pipelined", [(4, 256, False), (64, 512, True)], ids=["b4_l256_serial", "b64_l512_pipelined"])
 def test_factored_optimizer_steps_equal_the_materialised_path(B, L, pipelined):
     lr = 1e-4
     xs = [R.normalise_sprites(R.closed_form_sprites(B, salt=s)).cuda() for s in range(2)]
@@ -120,3 +119,63 @@ def test_factored_update_is_skipped_on_a_non_finite_norm():
     met = st.metrics()
     assert met["grads_finite"] == 0.0 and met["skipped_steps"] >= 1.0
     assert torch.equal(m.flat_parameters(), p0)
+
+
+def test_gathered_factors_give_the_average_of_the_ranks_gradients():
+    """Data parallel (mode 2): two "ranks" run the product's phased backward on their shards one after the other on this GPU; a stand-in
+    for FlatGradSync collects the factor blocks they hand over (what RCCL's all-gather would deliver, rank-major), and the library
+    forms the averaged Linear gradients from the gathered buffer.  Result == the mean of the two ranks' lo_wgrad_tn gradients to fp32
+    rounding, == the global-batch gradient to the fp16-operand tolerance of the DP identity test, and the Linear weight ranges of
+    the flat buffer were never written by the backward itself."""
+    import ctypes as C
+    from lunaris_orion_amd import _lib
+    L, Bper, world = 256, 2, 2
+    x = R.normalise_sprites(R.closed_form_sprites(Bper * world)).cuda()
+    eps = R.closed_form_eps(Bper * world, L, salt=0).cuda()
+
+    class Collector:
+        world, supports_then = 2, False
+
+        def __init__(self):
+            self.blocks, self.mat = [], None
+
+        def begin(self, g, **kw):
+            return False
+
+        def begin_factored(self, pieces, factors, materialize, then=None, pre=None):
+            self.blocks.append(factors.clone())
+            self.mat = materialize
+            return False
+
+        def finish(self):
+            pass
+
+        def average_small(self, t):
+            pass
+
+    col = Collector()
+    per_rank = []
+    for r in range(world):
+        xs, es = x[r * Bper:(r + 1) * Bper].contiguous(), eps[r * Bper:(r + 1) * Bper].contiguous()
+        m0, s0 = _stepper(L, False, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)      # this rank's gradients, written out by lo_wgrad_tn
+        s0.step(xs, 0, es)
+        per_rank.append(s0.flat_grads().clone())
+        mr, sr = _stepper(L, False, lr=0.0, weight_decay=0.0, max_grad_norm=1e9, grad_sync=col)
+        assert sr.dp_factored
+        sr.grads.fill_(float("nan"))
+        sr.step(xs, 0, es)
+        torch.cuda.synchronize()
+    lin = [(o, n, k) for (o, n, _), (k, _) in zip(mr._layout, mr.named_parameters()) if k in _lin_names(None)]
+    for o, n, k in lin:
+        assert torch.isnan(sr.grads[o:o + n]).all(), k          # the phased backward left the factors, not the gradients
+    gathered = torch.cat(col.blocks)
+    col.mat(gathered, world)                                     # rank 1's engine: fac_scale of its own backward, same loss scale on both
+    torch.cuda.synchronize()
+    mean = (per_rank[0] + per_rank[1]) * 0.5
+    mg, sg = _stepper(L, False, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
+    sg.step(x, 0, eps)
+    g_global = sg.flat_grads()
+    for o, n, k in lin:
+        a, b, c = sr.grads[o:o + n].double(), mean[o:o + n].double(), g_global[o:o + n].double()
+        assert (a - b).norm().item() <= 2e-6 * b.norm().item(), (k, (a - b).norm().item() / b.norm().item())
+        assert (a - c).norm().item() <= 2e-3 * c.norm().item(), k

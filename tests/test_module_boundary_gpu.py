@@ -129,7 +129,7 @@ def test_a_reference_shaped_step_with_torch_optimizers_matches_the_references_tr
 
 def test_gradscaler_scaled_upstream_gradients_give_the_scaled_parameter_gradients():
     """The autograd node under a foreign loss scale: backward of S * loss must give S * (backward of loss) for all 72 parameters,
-    for S = 2**16 (GradScaler's start), 2**24 (after growth) and 2**-8 — the node normalises the upstream gradients to a fixed
+    for S = 2**24 (beyond anything GradScaler's growth reaches; 2**16, its start, is what the AMP branch of the loop test above runs) and 2**-8 — the node normalises the upstream gradients to a fixed
     fp16 range on the device, so only fp32 rounding of the power-of-two scaling separates the results (none: bitwise equal)."""
     L, B = 256, 2
     x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
@@ -144,7 +144,7 @@ def test_gradscaler_scaled_upstream_gradients_give_the_scaled_parameter_gradient
         return {k: p.grad.clone() for k, p in vae.named_parameters()}
 
     base = grads(1.0)
-    for sc in (65536.0, 2.0 ** 24, 2.0 ** -8):
+    for sc in (2.0 ** 24, 2.0 ** -8):
         other = grads(sc)
         for k in base:
             assert torch.isfinite(other[k]).all(), (sc, k)

@@ -70,11 +70,38 @@ def _worker(rank, world, port, q):
     mixed.finish()
     assert mixed.bytes_per_phase() == [2 * (n - b1), 4 * (b1 - b2), 4 * b2]
     assert (fm[:b1] - flat[:b1]).abs().max().item() <= 1e-6 * flat.abs().max().item()      # fp32 wire: the all-reduce average
+    # the Linear layers' gradients as factors (FlatGradSync.begin_factored): every rank all-gathers the factor blocks and forms
+    # dW = (1 / N) sum_r Y_r^T X_r from the gathered buffer itself -- the all-reduce average of the per-rank matrices to fp32 rounding
+    gen = torch.Generator().manual_seed(100 + rank)
+    Nf, Kf, Bp = 48, 80, 32
+    yt = (torch.randn(Nf, Bp, generator=gen) * 0.5).half()           # dY^T [N][Bp] of this rank
+    xt = (torch.randn(Kf, Bp, generator=gen) * 0.5).half()           # X^T  [K][Bp]
+    block = torch.cat([yt.flatten(), xt.flatten()])
+    dw_local = yt.float() @ xt.float().t()                           # this rank's materialised gradient
+    dw_allreduce = dw_local.clone()
+    FlatGradSync()(dw_allreduce.view(-1))                            # the exchange the factors replace
+    dw_fact = torch.empty(Nf, Kf)
+
+    def materialize(gathered, w):
+        acc = torch.zeros(Nf, Kf)
+        per = block.numel()
+        for r_ in range(w):                                          # rank-major blocks, rank order: the same bits on every rank
+            blk = gathered[r_ * per:(r_ + 1) * per]
+            acc += blk[:Nf * Bp].view(Nf, Bp).float() @ blk[Nf * Bp:].view(Kf, Bp).float().t()
+        dw_fact.copy_(acc / w)
+    fsync = FlatGradSync()
+    piece = torch.full((7,), float(rank + 1))
+    fsync.begin_factored([piece], block, materialize)
+    fsync.finish()
+    assert fsync.modes_per_phase()[0] == "factors" and fsync.bytes_per_phase() == [2 * block.numel() + 4 * 7]
+    assert torch.equal(piece, torch.full((7,), 1.5))                 # the rest of the range: averaged the usual way
     # plain Python objects only (tensors through a spawn-context Queue need the producer to stay alive)
     res = {"sum": flat.double().sum().item(), "l2": flat.double().norm().item(),
            "direct_vs_allreduce": (flat_direct - flat[:-1]).abs().max().item(),
            "direct16_rel": ((flat16 - flat).norm() / flat.norm()).item(), "direct16_sum": flat16.double().sum().item(),
-           "lr": [cosine_warm_restarts_lr(1e-4, 1e-6, 10, 2, k) for k in range(40)]}
+           "lr": [cosine_warm_restarts_lr(1e-4, 1e-6, 10, 2, k) for k in range(40)],
+           "factored_vs_allreduce": ((dw_fact - dw_allreduce).abs().max() / dw_allreduce.abs().max()).item(),
+           "factored_sum": dw_fact.double().sum().item()}
     if rank == 0:
         full = R.OracleTrainer(P).step(x, eps, 0.0, do_update=False)
         fg = torch.cat([g.flatten() for g in full["grads"].values()])
@@ -105,6 +132,9 @@ def test_flat_grad_sync_equals_global_batch_gradient():
     # per element before the fp32 share sum)
     assert out[0]["direct16_sum"] == out[1]["direct16_sum"]
     assert max(out[0]["direct16_rel"], out[1]["direct16_rel"]) <= 1e-3, (out[0]["direct16_rel"], out[1]["direct16_rel"])
+    # factor exchange == all-reduce of the materialised gradient (fp32 rounding), identical on both ranks
+    assert max(out[0]["factored_vs_allreduce"], out[1]["factored_vs_allreduce"]) <= 1e-6
+    assert out[0]["factored_sum"] == out[1]["factored_sum"]
 
 
 def test_shard_batch_partitions_without_overlap():
