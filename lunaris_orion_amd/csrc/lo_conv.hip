@@ -740,7 +740,15 @@ __global__ void lo_splitk_reduce_kernel(const float* __restrict__ slab, const fl
   if (i >= M * N) return;
   int n = i % N;
   float v = bias ? bias[n] : 0.f;
-  for (int s = 0; s < nsplit; ++s) v += slab[(size_t)s * M * N + i];
+  int s = 0;
+  for (; s + 8 <= nsplit; s += 8) {              // eight loads in flight, added in split order
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slab[(size_t)(s + u) * M * N + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; s < nsplit; ++s) v += slab[(size_t)s * M * N + i];
   if (out32) out32[i] = v;
   if (out16) out16[i] = (f16)v;
 }
@@ -982,6 +990,61 @@ __device__ __forceinline__ void lo_wgrad_reduce_block(const float* __restrict__ 
 __global__ __launch_bounds__(256) void lo_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
                                                               int total, int nsplit, float scale) {
   lo_wgrad_reduce_block(slab, grad, g, total, nsplit, scale, (int)blockIdx.x);
+}
+// The same reduction for the 3x3 convolutions (one phase, nine taps, canonical weight W[co][ci][3][3]: sc == 9) with COALESCED
+// stores.  The kernel above walks the packed layout [n][tap][c] and scatters every value to n*sn + c*9 + rs: 4-byte stores 36 bytes
+// apart, neighbouring lanes 144 bytes apart -- for the 512 x 512 layers (2.4 M elements from two slabs) that was 39 us per launch,
+// against 6 us for the small layers whose time is the slab reads (rocprofv3, round 4: 176 us per step over the 15 launches).  Here a
+// workgroup owns (output channel n, 64 input channels): its nine tap segments are summed over the splits (thread = (16-byte column,
+// tap, split group)), staged in LDS, and leave as ONE contiguous run of 64 x 9 floats in 16-byte stores.  Same split-group order
+// as above: the same bits.
+__global__ __launch_bounds__(576) void lo_wgrad_reduce_rows_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
+                                                                   int total, int nsplit, float scale) {
+  __shared__ float part[4][9][64];
+  __shared__ int tap_of_rs[9];
+  const int x = threadIdx.x, t = threadIdx.y, sg = threadIdx.z, G = blockDim.z;
+  const int cblocks = g.Cin >> 6;
+  const int n = blockIdx.x / cblocks, c0 = (blockIdx.x - n * cblocks) << 6;
+  if (sg == 0 && x == 0) tap_of_rs[g.rs[0][t]] = t;
+  const size_t i = (size_t)n * 9 * g.Cin + (size_t)t * g.Cin + c0 + 4 * x;
+  const float* src = slab + i;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int s = sg;
+  for (; s + 3 * G < nsplit; s += 4 * G) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (size_t)s * total);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + G) * total);
+    f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2 * G) * total);
+    f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3 * G) * total);
+    v += a0; v += a1; v += a2; v += a3;
+  }
+  for (; s < nsplit; s += G) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * total);
+  *reinterpret_cast<f32x4*>(&part[sg][t][4 * x]) = v;
+  __syncthreads();
+  const int w = x + 16 * (t + 9 * sg);
+  if (w >= 144) return;
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int f = 4 * w + e, cc = f / 9, rs = f - cc * 9, tt = tap_of_rs[rs];
+    float acc = part[0][tt][cc];
+    for (int q = 1; q < G; ++q) acc += part[q][tt][cc];
+    o[e] = acc * scale;
+  }
+  *reinterpret_cast<f32x4*>(grad + (size_t)n * g.sn + (size_t)c0 * 9 + 4 * w) = o;
+}
+static bool lo_wgrad_reduce_rows_applies(const LoGeom& g) {
+  return g.n_phase == 1 && g.T[0] == 9 && g.sc == 9 && g.sn == 9 * g.Cin && g.wofs[0] == 0 && g.Cin % 64 == 0;
+}
+// slab [nsplit][packed] -> canonical fp32 gradient (scaled): the coalescing form where the geometry allows it
+static int lo_wgrad_reduce_launch(const float* slab, float* grad, const LoGeom& g, int total, int nsplit, float scale, hipStream_t st) {
+  if (lo_wgrad_reduce_rows_applies(g)) {
+    const int G = nsplit >= 4 ? 4 : (nsplit < 1 ? 1 : nsplit);
+    hipLaunchKernelGGL(lo_wgrad_reduce_rows_kernel, dim3(g.Cout * (g.Cin / 64)), dim3(16, 9, G), 0, st, slab, grad, g, total, nsplit, scale);
+  } else {
+    hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
+  }
+  LO_LAUNCH_CHECK("wgrad_reduce");
+  return LO_OK;
 }
 // ---------------------------------------------------------------------------------------------
 // host launchers
@@ -1402,9 +1465,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
       if (r != LO_OK) return r;
     }
     LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);
-    hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
-    LO_LAUNCH_CHECK("wgrad_reduce");
-    return LO_OK;
+    return lo_wgrad_reduce_launch(slab, grad, g, total, nsplit, scale, st);
   }
   if (lo_wgrad_s2_enabled() && lo_wgrad2_nsplit(g) > 0) {
     int nsplit = 0;
@@ -1415,9 +1476,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
       if (r != LO_OK) return r;
     }
     LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (nsplit + 1), st);
-    hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
-    LO_LAUNCH_CHECK("wgrad_reduce");
-    return LO_OK;
+    return lo_wgrad_reduce_launch(slab, grad, g, total, nsplit, scale, st);
   }
   WgradArgs a;
   a.x = x; a.dy = dy; a.slab = slab; a.g = g; a.grad = grad; a.scale = scale;
@@ -1455,9 +1514,7 @@ int lo_wgrad_run(const LoGeom& g, const f16* x, const f16* dy, float* slab, floa
   if (a.direct) return LO_OK;
   int total = a.packed_elems;
   LoProfScope _p2(lo_prof_geom_name("lo_wgrad_reduce", g), 0, 4.0 * total * (a.nsplit + 1), st);
-  hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, a.nsplit, scale);
-  LO_LAUNCH_CHECK("wgrad_reduce");
-  return LO_OK;
+  return lo_wgrad_reduce_launch(slab, grad, g, total, a.nsplit, scale, st);
 }
 
 size_t lo_wgrad_slab_bytes(const LoGeom& g) { return (size_t)lo_wgrad_nsplit(g) * geom_packed_elems(g) * sizeof(float); }
