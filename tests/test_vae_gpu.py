@@ -358,8 +358,10 @@ assert abs(out[0]["recon_loss"] - out[3]["recon_loss"]) <= 1e-5 and abs(out[0]["
 # on the communication stream)
 assert abs(out[0]["recon_loss"] - out[4]["recon_loss"]) < 1e-4 and abs(out[0]["grad_norm"] - out[4]["grad_norm"]) <= 2e-3 * out[0]["grad_norm"], out
 nb = sync.bytes_per_phase(); nf = m.flat_parameters().numel()
-# ranges of 4 Mi elements and more travel as fp16, smaller ones (the last, exposed range) as fp32
-assert sync.exposed_ms_per_step() is not None and len(nb) == 3 and 2 * nf <= sum(nb) < 2.3 * nf, (nb, nf)
+# the first range travels as the Linear layers' factors (all-gather of the fp16 factor block) + its small fp32 remainder, the other two
+# as gradients: a fraction of the 4 * nf bytes of the buffer in all (round 3: 2.0 - 2.3 * nf on the fp16 wire)
+assert sync.exposed_ms_per_step() is not None and len(nb) == 3 and sum(nb) < 1.2 * nf, (nb, nf)
+assert sync.modes_per_phase()[0] == "factors", sync.modes_per_phase()
 # the hybrid step under data parallelism: gradient ranges of both models + the 5-float reward-mean exchange
 from oracle import teacher_ref as T
 from lunaris_orion_amd.teacher import LunarMoETeacher
@@ -576,6 +578,8 @@ def test_golden_parity_with_the_fused_tap_kernel_forced_on(gn_fuse):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LO_HALO="3", LO_GN_FUSE=gn_fuse, LO_GNB_APPLY_FUSE=gn_fuse)
     sel = "test_forward_matches_oracle_and_golden or test_gradients_match_the_golden_samples or test_fused_steps_match_golden_trace or test_run_to_run_bitwise_determinism"
+    if gn_fuse == "0":       # the separate-pass variant: the latent-256 cases only (latent 512 runs in the fused variant; 23 s per variant before)
+        sel = "(" + sel + ") and not 512"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_vae_gpu.py"), "-x", "-q", "-m", "gpu", "-k", sel],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
