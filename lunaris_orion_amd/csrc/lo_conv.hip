@@ -1032,6 +1032,43 @@ __global__ __launch_bounds__(576) void lo_wgrad_reduce_rows_kernel(const float* 
   }
   *reinterpret_cast<f32x4*>(grad + (size_t)n * g.sn + (size_t)c0 * 9 + 4 * w) = o;
 }
+// ... and for the 4x4 stride-2 transposed convolutions (four phases of four taps, canonical weight W[ci][co][4][4]: sn == 16,
+// sc == Cout * 16, so the contiguous runs of the gradient are (co, rs) for a fixed ci).  A workgroup owns 16 reduced channels c
+// (one 64-byte run of every packed segment) x 4 output channels n: thread = (16-byte column, n, phase, tap) sums its column over the
+// splits in split order, the 16 x (4 x 16) block is staged in LDS and leaves as sixteen 256-byte runs in 16-byte stores (the
+// scattering kernel needed 15 - 35 us for these four layers).
+__global__ __launch_bounds__(256) void lo_wgrad_reduce_convt_kernel(const float* __restrict__ slab, float* __restrict__ grad, LoGeom g,
+                                                                    int total, int nsplit, float scale) {
+  __shared__ float outb[16][4][16];
+  const int tid = threadIdx.x, x = tid & 3, seg = tid >> 2, nl = seg >> 4, p = (seg >> 2) & 3, t = seg & 3;
+  const int cblocks = g.Cin >> 4;
+  const int nb = blockIdx.x / cblocks, c0 = (blockIdx.x - nb * cblocks) << 4, n0 = nb << 2;
+  const size_t i = (size_t)g.wofs[p] + (size_t)(n0 + nl) * 4 * g.Cin + (size_t)t * g.Cin + c0 + 4 * x;
+  const float* src = slab + i;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (size_t)s * total);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 1) * total);
+    f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2) * total);
+    f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3) * total);
+    v += a0; v += a1; v += a2; v += a3;
+  }
+  for (; s < nsplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * total);
+  const int rs = g.rs[p][t];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) outb[4 * x + e][nl][rs] = v[e] * scale;
+  __syncthreads();
+  const int cc = tid >> 4, q = tid & 15;
+  *reinterpret_cast<f32x4*>(grad + (size_t)(c0 + cc) * g.sc + (size_t)n0 * 16 + 4 * q) =
+      *reinterpret_cast<const f32x4*>(&outb[cc][q >> 2][(q & 3) * 4]);
+}
+static bool lo_wgrad_reduce_convt_applies(const LoGeom& g) {
+  if (g.n_phase != 4 || g.sn != 16 || g.sc != g.Cout * 16 || g.Cin % 16 != 0 || g.Cout % 4 != 0) return false;
+  for (int p = 0; p < 4; ++p)
+    if (g.T[p] != 4 || g.wofs[p] != p * 4 * g.Cin * g.Cout) return false;
+  return true;
+}
 static bool lo_wgrad_reduce_rows_applies(const LoGeom& g) {
   return g.n_phase == 1 && g.T[0] == 9 && g.sc == 9 && g.sn == 9 * g.Cin && g.wofs[0] == 0 && g.Cin % 64 == 0;
 }
@@ -1040,6 +1077,8 @@ static int lo_wgrad_reduce_launch(const float* slab, float* grad, const LoGeom& 
   if (lo_wgrad_reduce_rows_applies(g)) {
     const int G = nsplit >= 4 ? 4 : (nsplit < 1 ? 1 : nsplit);
     hipLaunchKernelGGL(lo_wgrad_reduce_rows_kernel, dim3(g.Cout * (g.Cin / 64)), dim3(16, 9, G), 0, st, slab, grad, g, total, nsplit, scale);
+  } else if (lo_wgrad_reduce_convt_applies(g)) {
+    hipLaunchKernelGGL(lo_wgrad_reduce_convt_kernel, dim3((g.Cout / 4) * (g.Cin / 16)), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
   } else {
     hipLaunchKernelGGL(lo_wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, st, slab, grad, g, total, nsplit, scale);
   }
