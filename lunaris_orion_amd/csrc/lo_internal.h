@@ -154,7 +154,7 @@ bool lo_lowrank_applies(int B, int N, int K);
 int lo_transpose_pad_f16_multi(const f16* const* src, f16* const* dst, const int* C, int njobs, int R, int Rp, hipStream_t st);
 struct LoLowrankNorm { const f16* fshort; int n_short; const f16* flong; int n_long; float* gram; float* partial; int nslots; };
 int lo_lowrank_sumsq(const LoLowrankNorm* layers, int nlayers, int B, float scale, hipStream_t st);
-struct LoLowrankMat { float* p; float* m; float* v; f16* cast; const f16* xt; const f16* yt; int N, K; };   // W [N][K]; xt [K][Bp], yt [N][Bp]
+struct LoLowrankMat { float* p; float* m; float* v; f16* cast; f16* cast_t; const f16* xt; const f16* yt; int N, K; };   // W [N][K] (cast_t [K][N]); xt [K][Bp], yt [N][Bp]
 int lo_adamw_lowrank(const LoLowrankMat* mats, int nmat, int B, float gscale, const float* norm, float lr, float beta1, float beta2,
                      float eps, float wd, int step, hipStream_t st);
 int lo_lowrank_materialize(float* gout, const f16* xt, const f16* yt, int N, int K, int B, float gscale, hipStream_t st);

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) void lo_gram_dot_kernel(LoGramJobs J) {
 struct LoLowrankArgs {
   float* p; float* m; float* v;   // [N][K] fp32 (parameter, Adam moments)
   f16* cast;                      // [N][K] fp16 operand copy of the updated parameter (may be null)
+  f16* cast_t;                    // [K][N] the same, transposed (operand of the layer's data gradient; may be null)
   float* gout;                    // materialising variant: the gradient [N][K]
   const f16* xt;                  // X^T  [K][Bp]
   const f16* yt;                  // dY^T [N][Bp]
@@ -213,8 +214,14 @@ __device__ __forceinline__ void lo_adamw_elem_lr(float& p, float g, float& m, fl
 // Neighbouring waves own neighbouring bands: the 256-byte row segments of the waves of a workgroup are contiguous in memory.
 // (The first version -- one wave per 64 x 64 block, nothing in flight across blocks -- ran at 4.8 TB/s against lo_adamw's 6.2.)
 struct LoLowrankPair { LoLowrankArgs l[2]; int nwg0; };      // workgroups [0, nwg0) update matrix 0, the rest matrix 1
+// cast_t: the transposed fp16 copy leaves through LDS -- a wave's 64 x 64 block of updated parameters is collected [k][n] in the
+// wave's own 9 KB of LDS (2-byte writes as the groups complete) and stored as 64 rows of 128 contiguous bytes once the block's four
+// groups are done: 2 more bytes per parameter on this pass instead of a separate transpose pass over both fp16 copies (4 bytes per
+// parameter, 45 us per step for the two matrices).
+#define LR_TP 72     // LDS pitch of a transposed block in halves (64 + 8: rows 144 bytes apart)
 template <int KB, bool MAT>
 __global__ __launch_bounds__(256) void lo_adamw_lowrank_kernel(LoLowrankPair A) {
+  __shared__ __attribute__((aligned(16))) f16 tbuf[MAT ? 1 : 4][MAT ? 8 : 64 * LR_TP];
   const bool second = (int)blockIdx.x >= A.nwg0;
   const LoLowrankArgs& a = second ? A.l[1] : A.l[0];
   const int bid = second ? (int)blockIdx.x - A.nwg0 : (int)blockIdx.x, nbl = second ? (int)gridDim.x - A.nwg0 : A.nwg0;
@@ -276,7 +283,25 @@ __global__ __launch_bounds__(256) void lo_adamw_lowrank_kernel(LoLowrankPair A) 
           *reinterpret_cast<f32x4*>(a.m + base + 16 * ik) = me;
           *reinterpret_cast<f32x4*>(a.v + base + 16 * ik) = ve;
           if (a.cast) *reinterpret_cast<f16x4*>(a.cast + base + 16 * ik) = (f16x4){(f16)pe[0], (f16)pe[1], (f16)pe[2], (f16)pe[3]};
+          if (a.cast_t) {
+            f16* tb = &tbuf[threadIdx.x >> 6][0];
+            const int nloc = 16 * (g & 3) + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[(16 * ik + 4 * lq + r) * LR_TP + nloc] = (f16)pe[r];
+          }
         }
+      }
+      if (!MAT && a.cast_t && (g & 3) == 3) {
+        // the block's four groups are in: 64 rows (k) x 64 columns (n); instruction j stores rows 8 j .. 8 j + 7, 128 bytes each
+        __builtin_amdgcn_wave_barrier();
+        const f16* tb = &tbuf[threadIdx.x >> 6][0];
+        const size_t n_first = (size_t)(sub + (g >> 2) * wpb) * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = 8 * j + (lane >> 3), ch = lane & 7;
+          *reinterpret_cast<f16x8*>(a.cast_t + (size_t)(k0 + kk) * a.N + n_first + 8 * ch) = *reinterpret_cast<const f16x8*>(tb + kk * LR_TP + 8 * ch);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     };
     load_group(0, 0);
@@ -426,12 +451,12 @@ int lo_adamw_lowrank(const LoLowrankMat* mats, int nmat, int B, float gscale, co
     const LoLowrankMat& mt = mats[i];
     LO_REQUIRE(lo_lowrank_applies(B, mt.N, mt.K), "lo_adamw_lowrank: shape B=%d N=%d K=%d not supported", B, mt.N, mt.K);
     LoLowrankArgs& a = A.l[i];
-    a.p = mt.p; a.m = mt.m; a.v = mt.v; a.cast = mt.cast; a.gout = nullptr; a.xt = mt.xt; a.yt = mt.yt; a.N = mt.N; a.K = mt.K; a.Bp = lo_lowrank_bp(B);
+    a.p = mt.p; a.m = mt.m; a.v = mt.v; a.cast = mt.cast; a.cast_t = mt.cast_t; a.gout = nullptr; a.xt = mt.xt; a.yt = mt.yt; a.N = mt.N; a.K = mt.K; a.Bp = lo_lowrank_bp(B);
     a.gscale = gscale; a.norm = norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     elems[i] = (double)mt.N * mt.K;
-    bytes += (mt.cast ? 26.0 : 24.0) * elems[i];
+    bytes += (24.0 + (mt.cast ? 2.0 : 0.0) + (mt.cast_t ? 2.0 : 0.0)) * elems[i];
   }
   // workgroups of the larger matrix.  Two are resident per CU (208 registers); a longer grid measured better on the step, where the
   // kernel runs beside the next forward: 512 / 1024 / 2048 / 4096 / 8192 -> 23 310 / 23 590 / 23 790 / 23 230 / 23 190 sprites/s
