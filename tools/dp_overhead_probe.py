@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """What does the data-parallel PATH cost before any byte crosses a link?  One rank, RCCL group of one: the step (a) as bench.py runs it
-at N = 1 and (b) with FlatGradSync(force=True) in the N > 1 default (three-range phased backward, direct exchange, fp16 wire, early
-norm behind the first range): the phase joins, the wire pack / share sum / unpack kernels, the two collectives per range (self-copies
+at N = 1 and (b) with FlatGradSync(force=True) in the bench's N > 1 default (three-range phased backward; the first range travels as the
+Linear layers' factors -- all-gather + local contraction --, the others by direct exchange / all-reduce; early norm behind the first
+range): the phase joins, the wire pack / share sum / unpack kernels, the two collectives per range (self-copies
 here) and the events.  T(a) / T(b) is an upper bound of the weak-scaling efficiency the path can reach at any N."""
 import os, sys, time
 import torch
@@ -54,5 +55,5 @@ for rep in range(2):
     s = FlatGradSync(force=True, mode="direct", compress_fp16=True, time_exposed=True)
     b = run(s)
     print(f"single-process step {a[0]:8.0f} sprites/s {a[1]:.3f} ms | data-parallel path, one rank {b[0]:8.0f} sprites/s {b[1]:.3f} ms "
-          f"(exposed in finish(): {s.exposed_ms_per_step():.3f} ms, mode {s.mode_used}, bytes per range {s.bytes_per_phase()}) | ratio {a[1] / b[1]:.3f}")
+          f"(exposed in finish(): {s.exposed_ms_per_step():.3f} ms, ranges ran as {s.modes_per_phase()}, bytes per range {s.bytes_per_phase()}) | ratio {a[1] / b[1]:.3f}")
 dist.destroy_process_group()

@@ -8,6 +8,8 @@ O=gpurun_out/prof_refresh
 rm -rf $O && mkdir -p $O
 python3 bench.py --steps 50 --warmup 10 --breakdown > $O/bench.json 2> $O/bench_breakdown.txt
 LO_PROF_LAYERS=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --hybrid-steps 0 --fp8-steps 0 --config2-steps 0 --highend-steps 0 --breakdown > /dev/null 2> $O/bench_per_layer.txt
+python3 tools/vendor_ceiling.py --mine $O/bench_per_layer.txt > $O/vendor_ceiling.txt 2> $O/vendor_ceiling.err
+python3 tools/dp_overhead_probe.py > $O/dp_path_probe.txt 2>&1
 python3 tools/hybrid_probe.py > $O/hybrid_breakdown.txt 2>&1
 python3 tools/gnb_det.py 8 > $O/gnb_det.log 2>&1
 python3 tools/host_enqueue_probe.py > $O/host_enqueue.txt 2>&1
