@@ -1,11 +1,12 @@
 // SelfAttention2d (lunar_generate.py:56-78): out = gamma * (V softmax(Q^T K)^T) + x on a [B, C, H, W] map.
 // The reference defines this module but never instantiates it, so it is built as a standalone op with its
 // own parity test, not as part of the VAE graph.  Forward, default path (MFMA):
-//   lo_attn_project_mfma : q, k (C/8 channels) and v (C channels) = 1x1 convs of x, channel-major [B][c][N], on the exact
+//   lo_attn_project_qkv  : q, k (C/8 channels) and v (C channels) = 1x1 convs of x, channel-major [B][c][N], ONE launch, on the exact
 //                          fp32 matrix instruction (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, same numerics as the VALU
 //                          form; q / k / v are saved in fp32 for the backward)
-//   lo_attn_mfma         : one wave per 16 queries, all value channels of the workgroup's group in its accumulators.  Per 32
-//                          keys: S^T = K^T Q and O += V P^T on v_mfma_f32_16x16x32_f16 (fp16 operands, fp32 accumulate), the
+//   lo_attn_mfma         : one wave per 16 queries, 128 value channels per workgroup in its accumulators; the four waves of a
+//                          workgroup share every 64-key block of K and V through LDS (fp16, staged while the previous block is
+//                          multiplied).  Per 32 keys: S^T = K^T Q and O += V P^T on v_mfma_f32_16x16x32_f16 (fp32 accumulate), the
 //                          softmax online in ONE pass over the keys (running max / sum per query, wave-wide by two shuffles
 //                          across the four 16-lane groups); the score accumulators ARE the P operand of the second product
 //                          (its k slots are ordered the way the accumulator rows come out, and V is loaded in that order),
@@ -99,55 +100,38 @@ __global__ __launch_bounds__(256) void lo_attn_fused_kernel(const float* __restr
 }
 
 // ---- MFMA forward -------------------------------------------------------------------------------------------------
-// y[bi][co][n] = b[co] + sum_ci w[co][ci] x[bi][ci][n].  Workgroup = 64 output channels x 64 positions, wave = 16 x 64.
+// Projections: y[bi][co][n] = b[co] + sum_ci w[co][ci] x[bi][ci][n].  Workgroup = 64 output channels x 64 positions, wave = 16 x 64.
 // v_mfma_f32_16x16x4_f32: lane l holds A[row l&15][k = l>>4], B[k = l>>4][col l&15]; D: col = l&15, row = 4*(l>>4) + reg.
-__global__ __launch_bounds__(256) void lo_attn_project_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                   const float* __restrict__ b, float* __restrict__ y, int C, int Co, int N) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 64, co0 = blockIdx.y * 64 + wave * 16, bi = blockIdx.z;
-  if (co0 >= Co) return;                                   // wave-uniform
-  const int row = co0 + fr;
-  const bool valid = row < Co;
-  const float* wr = w + (size_t)(valid ? row : 0) * C + g;
-  const float* xb = x + ((size_t)bi * C + g) * N + n0 + fr;
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int ci0 = 0; ci0 < C; ci0 += 4) {
-    const float a = valid ? wr[ci0] : 0.f;
-    const float* xp = xb + (size_t)ci0 * N;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xp[16 * t], acc[t], 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = co0 + 4 * g + r;
-    if (co < Co) {
-      const float bv = b[co];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) y[((size_t)bi * Co + co) * N + n0 + 16 * t + fr] = acc[t][r] + bv;
-    }
-  }
-}
-
+// (lo_attn_project_qkv_kernel below: the three projections of the module in one launch.)
 // Fused attention.  q, k: [B][D][N] fp32, v / x / out: [B][C][N] fp32.  Workgroup = 64 queries (4 waves x 16) x 16*NT value
-// channels; grid = (N/64, C/(16*NT), B).  Per wave and 32-key step:
+// channels; grid = (N/64, C/(16*NT), B).  Keys are walked in blocks of 64 that the four waves SHARE: the block's K rows and V rows
+// are fetched with 16-byte loads (fp32, key-contiguous as they lie in memory), converted to fp16 and staged in LDS -- K
+// transposed to [key][d] so that a lane's A fragment is one 16-byte read, V as [channel][key] -- while the previous block is
+// being multiplied (registers hold the next block's loads across the compute phase; two LDS stages, one barrier per block).
+// The round-2 form let every lane fetch its own operands from global memory with 4-byte loads inside the key loop (16 + 8 NT
+// dependent loads per 32 keys, no sharing between the waves): 582 us at B = 8 / C = 64 / N = 4096.
+// Per wave and 32-key step:
 //   S^T tiles a (keys j0..j0+15) and b (j0+16..j0+31):  D[j][i] = sum_d K[d][j] Q[d][i]      (A = K^T rows, B = Q columns)
 //     -> lane (i = lane&15, g = lane>>4) holds S[i][j0 + 4g + r] (a) and S[i][j0 + 16 + 4g + r] (b), r = 0..3
 //   online softmax of query i over those 32 keys: in-lane over 8 values, then across the four groups g (shuffle xor 16, 32)
 //   O^T += V P^T:  D[c][i] = sum_s V[c][key(s)] P[i][key(s)] with the k slot s = 8g + t  <->  key(s) = j0 + 4g + t (t < 4) or
-//     j0 + 16 + 4g + (t - 4): exactly the eight probabilities the lane already holds; V is loaded in that order (two 16-byte
-//     loads per lane and channel tile).  The accumulators' column is the query, so the running rescale is lane-local.
+//     j0 + 16 + 4g + (t - 4): exactly the eight probabilities the lane already holds; V is read in that order (two 8-byte LDS
+//     reads per lane and channel tile).  The accumulators' column is the query, so the running rescale is lane-local.
+#define AF_KP 72      // LDS pitch of a K row [key][d] and of a V row [channel][key], in halves (64 + 8)
 template <int NT>
 __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, const float* __restrict__ x,
                                                            const float* __restrict__ gamma, float* __restrict__ out, int C, int D, int N) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64 + wave * 16, c0 = blockIdx.y * 16 * NT, bi = blockIdx.z;
+  constexpr int CV = 16 * NT, VP = CV / 16;                   // value channels of the workgroup; V staging passes (16 rows each)
+  __shared__ __attribute__((aligned(16))) f16 sK[2][64 * AF_KP];
+  __shared__ __attribute__((aligned(16))) f16 sV[2][CV * AF_KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64 + wave * 16, c0 = blockIdx.y * CV, bi = blockIdx.z;
   const float* qb = q + (size_t)bi * D * N;
   const float* kb = k + (size_t)bi * D * N;
-  const float* vb = v + ((size_t)bi * C + c0 + fr) * N + 4 * g;
+  const float* vb = v + ((size_t)bi * C + c0) * N;
   const int KD = (D + 31) >> 5;                              // 32-wide k steps of the score product (D = C/8 <= 64)
+  const int DR = (D + 15) >> 4;                              // K staging passes (16 rows of d each)
   f16x8 qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -156,52 +140,87 @@ __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restri
       const int d = ks * 32 + 8 * g + t;
       qf[ks][t] = (ks < KD && d < D) ? (f16)qb[(size_t)d * N + q0 + fr] : (f16)0.f;
     }
+  // zero the d-padding of both K stages once (rows are [key][d], d < 32 KD read; only d < D is ever written below)
+  for (int e = tid; e < 2 * 64 * AF_KP; e += 256) (&sK[0][0])[e] = (f16)0.f;
+  // staging roles: thread -> (row = tid >> 4, four consecutive keys 4 (tid & 15) .. + 3) of a 16-row pass
+  const int srow = tid >> 4, skey = (tid & 15) * 4;
+  f32x4 kreg[4], vreg[VP];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (p < DR) {
+        const int d = p * 16 + srow;
+        kreg[p] = d < D ? *reinterpret_cast<const f32x4*>(kb + (size_t)d * N + j0 + skey) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int p = 0; p < VP; ++p) vreg[p] = *reinterpret_cast<const f32x4*>(vb + (size_t)(p * 16 + srow) * N + j0 + skey);
+  };
+  auto stage = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (p < DR) {
+        const int d = p * 16 + srow;
+        if (d < D) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sK[st][(skey + e) * AF_KP + d] = (f16)kreg[p][e];
+        }
+      }
+#pragma unroll
+    for (int p = 0; p < VP; ++p)
+      *reinterpret_cast<f16x4*>(&sV[st][(p * 16 + srow) * AF_KP + skey]) = (f16x4){(f16)vreg[p][0], (f16)vreg[p][1], (f16)vreg[p][2], (f16)vreg[p][3]};
+  };
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  for (int j0 = 0; j0 < N; j0 += 32) {
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  __syncthreads();                                           // the zero fill is complete before the first K rows are written
+  stage(0);
+  const int nblk = N / 64;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int st = blk & 1;
+    __syncthreads();                                         // stage `st` is complete; everybody has finished reading stage st ^ 1
+    if (blk + 1 < nblk) fetch((blk + 1) * 64);               // in flight across this block's MFMAs
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks < KD) {
-        f16x8 ka, kc;
+    for (int sub = 0; sub < 2; ++sub) {
+      const int j0 = 32 * sub;
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int d = ks * 32 + 8 * g + t;
-          const bool ok = d < D;
-          ka[t] = ok ? (f16)kb[(size_t)d * N + j0 + fr] : (f16)0.f;
-          kc[t] = ok ? (f16)kb[(size_t)d * N + j0 + 16 + fr] : (f16)0.f;
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks < KD) {
+          const f16x8 ka = *reinterpret_cast<const f16x8*>(&sK[st][(j0 + fr) * AF_KP + ks * 32 + 8 * g]);
+          const f16x8 kc = *reinterpret_cast<const f16x8*>(&sK[st][(j0 + 16 + fr) * AF_KP + ks * 32 + 8 * g]);
+          sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], sa, 0, 0, 0);
+          sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc, qf[ks], sb, 0, 0, 0);
         }
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], sa, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc, qf[ks], sb, 0, 0, 0);
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])), fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);             // 0 on the first step (m_run = -inf)
+      float p[8], ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = __expf(sa[r] - m_new); p[4 + r] = __expf(sb[r] - m_new); }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ls += p[r];
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+      f16x8 pf;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) pf[r] = (f16)p[r];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f16* vp = &sV[st][(16 * nt + fr) * AF_KP + j0 + 4 * g];
+        const f16x4 va = *reinterpret_cast<const f16x4*>(vp), vc = *reinterpret_cast<const f16x4*>(vp + 16);
+        const f16x8 vf = {va[0], va[1], va[2], va[3], vc[0], vc[1], vc[2], vc[3]};
+        acc[nt] = acc[nt] * alpha;
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, acc[nt], 0, 0, 0);
       }
     }
-    float mx = fmaxf(fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])), fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);               // 0 on the first step (m_run = -inf)
-    float p[8], ls = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { p[r] = __expf(sa[r] - m_new); p[4 + r] = __expf(sb[r] - m_new); }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ls += p[r];
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
-    f16x8 pf;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) pf[r] = (f16)p[r];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float* vp = vb + (size_t)(16 * nt) * N + j0;
-      const f32x4 va = *reinterpret_cast<const f32x4*>(vp), vc = *reinterpret_cast<const f32x4*>(vp + 16);
-      const f16x8 vf = {(f16)va[0], (f16)va[1], (f16)va[2], (f16)va[3], (f16)vc[0], (f16)vc[1], (f16)vc[2], (f16)vc[3]};
-      acc[nt] = acc[nt] * alpha;
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, acc[nt], 0, 0, 0);
-    }
+    if (blk + 1 < nblk) stage(st ^ 1);                       // stage st ^ 1 was last read in block blk - 1: free since this block's barrier
   }
   const float inv = 1.f / l_run, gm = gamma[0];
 #pragma unroll
@@ -213,6 +232,54 @@ __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restri
     }
 }
 
+// q, k and v projections in ONE launch: blockIdx.y walks the 64-row tiles of [Wq; Wk; Wv]
+__global__ __launch_bounds__(256) void lo_attn_project_qkv_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                                  const float* __restrict__ bq, const float* __restrict__ wk,
+                                                                  const float* __restrict__ bk, const float* __restrict__ wv,
+                                                                  const float* __restrict__ bv, float* __restrict__ q, float* __restrict__ k,
+                                                                  float* __restrict__ v, int C, int D, int N) {
+  const int tq = (D + 63) / 64;                              // 64-row tiles of q (and of k)
+  const int ty = blockIdx.y;
+  const float* w = ty < tq ? wq : (ty < 2 * tq ? wk : wv);
+  const float* b = ty < tq ? bq : (ty < 2 * tq ? bk : bv);
+  float* y = ty < tq ? q : (ty < 2 * tq ? k : v);
+  const int Co = ty < 2 * tq ? D : C;
+  const int tile = ty < tq ? ty : (ty < 2 * tq ? ty - tq : ty - 2 * tq);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64, co0 = tile * 64 + wave * 16, bi = blockIdx.z;
+  if (co0 >= Co) return;                                   // wave-uniform
+  const int row = co0 + fr;
+  const bool valid = row < Co;
+  const float* wr = w + (size_t)(valid ? row : 0) * C + g;
+  const float* xb = x + ((size_t)bi * C + g) * N + n0 + fr;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ci0 = 0; ci0 < C; ci0 += 16) {                  // four k steps per iteration: their 20 loads are issued together
+    float av[4], xv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = valid ? wr[ci0 + 4 * u] : 0.f;
+      const float* xp = xb + (size_t)(ci0 + 4 * u) * N;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xv[u][t] = xp[16 * t];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], xv[u][t], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = co0 + 4 * g + r;
+    if (co < Co) {
+      const float bvv = b[co];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[((size_t)bi * Co + co) * N + n0 + 16 * t + fr] = acc[t][r] + bvv;
+    }
+  }
+}
+
 int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                       const float* bv, const float* gamma, float* q, float* k, float* v, float* out, int B, int C, int N,
                       hipStream_t st) {
@@ -221,18 +288,17 @@ int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const fl
   LO_REQUIRE(D <= 64, "lo_selfattn2d_fwd: C/8 = %d > 64 is not supported", D);
   static const bool fp32_path = getenv("LO_ATTN_FP32") && atoi(getenv("LO_ATTN_FP32")) != 0;
   if (!fp32_path) {
-    hipLaunchKernelGGL(lo_attn_project_mfma_kernel, dim3(N / 64, (D + 63) / 64, B), dim3(256), 0, st, x, wq, bq, q, C, D, N);
-    hipLaunchKernelGGL(lo_attn_project_mfma_kernel, dim3(N / 64, (D + 63) / 64, B), dim3(256), 0, st, x, wk, bk, k, C, D, N);
-    hipLaunchKernelGGL(lo_attn_project_mfma_kernel, dim3(N / 64, (C + 63) / 64, B), dim3(256), 0, st, x, wv, bv, v, C, C, N);
-    LO_LAUNCH_CHECK("attn_project_mfma");
-    // value channels per workgroup: all of them up to 512 (32 accumulator tiles = 128 VGPRs per lane), so the scores are
-    // computed once per query block; wider maps are split into 512-channel groups
-    const int CV = C % 512 == 0 ? 512 : (C % 256 == 0 ? 256 : (C % 128 == 0 ? 128 : 64));
+    // C is a multiple of 64, so the k loop of the projection runs in whole 16-channel iterations
+    hipLaunchKernelGGL(lo_attn_project_qkv_kernel, dim3(N / 64, 2 * ((D + 63) / 64) + C / 64, B), dim3(256), 0, st, x, wq, bq, wk, bk, wv, bv, q, k, v,
+                       C, D, N);
+    LO_LAUNCH_CHECK("attn_project_qkv");
+    // value channels per workgroup: 128 (64 for a 64-channel map): the scores are recomputed per channel group (D = C/8 against 128
+    // channels of P V: a third of the group's work) and in exchange the grid reaches every CU at the module's shapes -- B = 64 / C =
+    // 512 / N = 64: 256 workgroups; B = 8 / C = 64 / N = 4096: 512
+    const int CV = C % 128 == 0 ? 128 : 64;
     LoProfScope _p("lo_attn_mfma", 2.0 * B * N * (double)N * (D * (double)(C / CV) + C), 4.0 * B * N * (2.0 * D + 3.0 * C), st);
     const dim3 grid(N / 64, C / CV, B);
-    if (CV == 512) hipLaunchKernelGGL((lo_attn_mfma_kernel<32>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
-    else if (CV == 256) hipLaunchKernelGGL((lo_attn_mfma_kernel<16>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
-    else if (CV == 128) hipLaunchKernelGGL((lo_attn_mfma_kernel<8>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
+    if (CV == 128) hipLaunchKernelGGL((lo_attn_mfma_kernel<8>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
     else hipLaunchKernelGGL((lo_attn_mfma_kernel<4>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
     LO_LAUNCH_CHECK("attn_mfma");
     return LO_OK;
