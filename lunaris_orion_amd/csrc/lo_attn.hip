@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void lo_attn_fused_kernel(const float* __restr
 //     j0 + 16 + 4g + (t - 4): exactly the eight probabilities the lane already holds; V is read in that order (two 8-byte LDS
 //     reads per lane and channel tile).  The accumulators' column is the query, so the running rescale is lane-local.
 #define AF_KP 72      // LDS pitch of a K row [key][d] and of a V row [channel][key], in halves (64 + 8)
-template <int NT>
+template <int NT, int PF>      // PF = key blocks fetched ahead (register sets): 2 where the registers allow it (NT = 4)
 __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, const float* __restrict__ x,
                                                            const float* __restrict__ gamma, float* __restrict__ out, int C, int D, int N) {
@@ -138,49 +138,58 @@ __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int d = ks * 32 + 8 * g + t;
-      qf[ks][t] = (ks < KD && d < D) ? (f16)qb[(size_t)d * N + q0 + fr] : (f16)0.f;
+      // log2(e) rides on q: the scores come out of the MFMA in the base-2 domain and every exponential below is the hardware's
+      // own v_exp_f32 (2^x) without the multiply that __expf puts in front of it (softmax is invariant: the same factor sits in the
+      // running maximum)
+      qf[ks][t] = (ks < KD && d < D) ? (f16)(qb[(size_t)d * N + q0 + fr] * 1.44269504088896341f) : (f16)0.f;
     }
   // zero the d-padding of both K stages once (rows are [key][d], d < 32 KD read; only d < D is ever written below)
   for (int e = tid; e < 2 * 64 * AF_KP; e += 256) (&sK[0][0])[e] = (f16)0.f;
   // staging roles: thread -> (row = tid >> 4, four consecutive keys 4 (tid & 15) .. + 3) of a 16-row pass
   const int srow = tid >> 4, skey = (tid & 15) * 4;
-  f32x4 kreg[4], vreg[VP];
-  auto fetch = [&](int j0) {
+  f32x4 kreg[PF][4], vreg[PF][VP];
+  auto fetch = [&](int set, int j0) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       if (p < DR) {
         const int d = p * 16 + srow;
-        kreg[p] = d < D ? *reinterpret_cast<const f32x4*>(kb + (size_t)d * N + j0 + skey) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        kreg[set][p] = d < D ? *reinterpret_cast<const f32x4*>(kb + (size_t)d * N + j0 + skey) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-    for (int p = 0; p < VP; ++p) vreg[p] = *reinterpret_cast<const f32x4*>(vb + (size_t)(p * 16 + srow) * N + j0 + skey);
+    for (int p = 0; p < VP; ++p) vreg[set][p] = *reinterpret_cast<const f32x4*>(vb + (size_t)(p * 16 + srow) * N + j0 + skey);
   };
-  auto stage = [&](int st) {
+  auto stage = [&](int set, int st) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       if (p < DR) {
         const int d = p * 16 + srow;
         if (d < D) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) sK[st][(skey + e) * AF_KP + d] = (f16)kreg[p][e];
+          for (int e = 0; e < 4; ++e) sK[st][(skey + e) * AF_KP + d] = (f16)kreg[set][p][e];
         }
       }
 #pragma unroll
     for (int p = 0; p < VP; ++p)
-      *reinterpret_cast<f16x4*>(&sV[st][(p * 16 + srow) * AF_KP + skey]) = (f16x4){(f16)vreg[p][0], (f16)vreg[p][1], (f16)vreg[p][2], (f16)vreg[p][3]};
+      *reinterpret_cast<f16x4*>(&sV[st][(p * 16 + srow) * AF_KP + skey]) =
+          (f16x4){(f16)vreg[set][p][0], (f16)vreg[set][p][1], (f16)vreg[set][p][2], (f16)vreg[set][p][3]};
   };
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  fetch(0);
-  __syncthreads();                                           // the zero fill is complete before the first K rows are written
-  stage(0);
   const int nblk = N / 64;
-  for (int blk = 0; blk < nblk; ++blk) {
-    const int st = blk & 1;
+  fetch(0, 0);
+  if (PF == 2 && nblk > 1) fetch(1, 64);
+  __syncthreads();                                           // the zero fill is complete before the first K rows are written
+  stage(0, 0);
+  // block `blk` is multiplied from LDS stage blk & 1 while block blk + PF travels into register set blk % PF (free: its previous
+  // content, block blk, was staged before this block's barrier) and block blk + 1 -- fetched PF - 1 blocks ago -- is staged at the
+  // end.  With one block ahead (PF = 1) a block's two 32-key steps (~0.4 us) did not cover an L2 round trip: at B = 8 / C = 64 /
+  // N = 4096 the kernel stalled on every one of its 64 blocks.
+  auto body = [&](int blk, int par) __attribute__((always_inline)) {
+    const int st = par;
     __syncthreads();                                         // stage `st` is complete; everybody has finished reading stage st ^ 1
-    if (blk + 1 < nblk) fetch((blk + 1) * 64);               // in flight across this block's MFMAs
+    if (blk + PF < nblk) fetch(PF == 2 ? par : 0, (blk + PF) * 64);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int j0 = 32 * sub;
@@ -198,10 +207,10 @@ __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restri
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);             // 0 on the first step (m_run = -inf)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 0 on the first step (m_run = -inf)
       float p[8], ls = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { p[r] = __expf(sa[r] - m_new); p[4 + r] = __expf(sb[r] - m_new); }
+      for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sa[r] - m_new); p[4 + r] = __builtin_amdgcn_exp2f(sb[r] - m_new); }
 #pragma unroll
       for (int r = 0; r < 8; ++r) ls += p[r];
       ls += __shfl_xor(ls, 16, 64);
@@ -211,16 +220,25 @@ __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restri
       f16x8 pf;
 #pragma unroll
       for (int r = 0; r < 8; ++r) pf[r] = (f16)p[r];
+      // the running maximum settles after the first blocks: the rescale of the NT accumulator tiles is skipped (wave-uniformly)
+      // whenever no query of the wave has moved its maximum -- alpha is exactly 1 then
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = acc[nt] * alpha;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const f16* vp = &sV[st][(16 * nt + fr) * AF_KP + j0 + 4 * g];
         const f16x4 va = *reinterpret_cast<const f16x4*>(vp), vc = *reinterpret_cast<const f16x4*>(vp + 16);
         const f16x8 vf = {va[0], va[1], va[2], va[3], vc[0], vc[1], vc[2], vc[3]};
-        acc[nt] = acc[nt] * alpha;
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, acc[nt], 0, 0, 0);
       }
     }
-    if (blk + 1 < nblk) stage(st ^ 1);                       // stage st ^ 1 was last read in block blk - 1: free since this block's barrier
+    if (blk + 1 < nblk) stage(PF == 2 ? par ^ 1 : 0, st ^ 1);   // stage st ^ 1 was last read in block blk - 1: free since this block's barrier
+  };
+  for (int blk = 0; blk < nblk; blk += 2) {
+    body(blk, 0);
+    if (blk + 1 < nblk) body(blk + 1, 1);
   }
   const float inv = 1.f / l_run, gm = gamma[0];
 #pragma unroll
@@ -232,12 +250,30 @@ __global__ __launch_bounds__(256) void lo_attn_mfma_kernel(const float* __restri
     }
 }
 
-// q, k and v projections in ONE launch: blockIdx.y walks the 64-row tiles of [Wq; Wk; Wv]
+// q, k and v projections in ONE launch: blockIdx.y walks the 64-row tiles of [Wq; Wk; Wv].
+// y[bi][co][n] = b[co] + sum_ci w[co][ci] x[bi][ci][n] on v_mfma_f32_16x16x32_f16 with BOTH operands split into fp16 halves,
+// a = hi + lo (hi = fp16(a), lo = fp16(a - hi): 22 significant bits), three products per tile and k step -- hi hi, hi lo, lo hi; the
+// dropped lo lo term is 2^-22 of the product -- accumulated in fp32: the accuracy of an fp32 product chain (q / k / v are saved in fp32
+// for the backward) at 16/3 of the fp32 matrix instruction's rate.  The first form ran on v_mfma_f32_16x16x4_f32 with 4-byte operand
+// loads in the k loop: 67 us of the module's 79 at B = 64 / C = 512 / N = 64 (rocprofv3).
+// Workgroup = 64 output rows x 64 positions; per 32-channel k step the x tile [32][64] is fetched with 16-byte loads, split, and
+// staged TRANSPOSED in LDS ([n][ci], hi and lo planes) so that a lane's B fragment -- eight consecutive channels of one position --
+// is one 16-byte read shared by the four waves; the A fragments (eight consecutive channels of one weight row) come straight from
+// global memory, two 16-byte loads.  Next step's loads are issued before this step's products; two LDS stages.
+#define PJ_P 40       // LDS pitch of a staged x row [n][32 ci] in halves (32 + 8)
+__device__ __forceinline__ void lo_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (f16)a[e]; lo[e] = (f16)(a[e] - (float)hi[e]);
+    hi[4 + e] = (f16)b[e]; lo[4 + e] = (f16)(b[e] - (float)hi[4 + e]);
+  }
+}
 __global__ __launch_bounds__(256) void lo_attn_project_qkv_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                                   const float* __restrict__ bq, const float* __restrict__ wk,
                                                                   const float* __restrict__ bk, const float* __restrict__ wv,
                                                                   const float* __restrict__ bv, float* __restrict__ q, float* __restrict__ k,
                                                                   float* __restrict__ v, int C, int D, int N) {
+  __shared__ __attribute__((aligned(16))) f16 sX[2][2][64 * PJ_P];      // [stage][hi / lo][n][ci]
   const int tq = (D + 63) / 64;                              // 64-row tiles of q (and of k)
   const int ty = blockIdx.y;
   const float* w = ty < tq ? wq : (ty < 2 * tq ? wk : wv);
@@ -245,30 +281,62 @@ __global__ __launch_bounds__(256) void lo_attn_project_qkv_kernel(const float* _
   float* y = ty < tq ? q : (ty < 2 * tq ? k : v);
   const int Co = ty < 2 * tq ? D : C;
   const int tile = ty < tq ? ty : (ty < 2 * tq ? ty - tq : ty - 2 * tq);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64, co0 = tile * 64 + wave * 16, bi = blockIdx.z;
-  if (co0 >= Co) return;                                   // wave-uniform
+  const bool wave_on = co0 < Co;                             // wave-uniform; idle waves still help staging
   const int row = co0 + fr;
-  const bool valid = row < Co;
-  const float* wr = w + (size_t)(valid ? row : 0) * C + g;
-  const float* xb = x + ((size_t)bi * C + g) * N + n0 + fr;
+  const bool valid = wave_on && row < Co;
+  const float* wr = w + (size_t)(valid ? row : 0) * C + 8 * g;
+  // staging role: channel ci = tid & 31, positions 8 (tid >> 5) .. + 7.  Consecutive lanes take consecutive channels so that the
+  // transposing 2-byte LDS writes of a wave land on 32 different banks (with the positions along the lanes the eight rows a wave
+  // writes are 160 dwords apart: two banks for 64 lanes -- half of the first form's 36 us at B = 64 / C = 512 / N = 64)
+  const int sci = tid & 31, sn = (tid >> 5) * 8;
+  const float* xs = x + ((size_t)bi * C + sci) * N + n0 + sn;
+  f32x4 xr[2], wa, wb;
+  auto fetch = [&](int ci0) {
+    xr[0] = *reinterpret_cast<const f32x4*>(xs + (size_t)ci0 * N);
+    xr[1] = *reinterpret_cast<const f32x4*>(xs + (size_t)ci0 * N + 4);
+    wa = valid ? *reinterpret_cast<const f32x4*>(wr + ci0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    wb = valid ? *reinterpret_cast<const f32x4*>(wr + ci0 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto stage = [&](int st) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xv = e < 4 ? xr[0][e] : xr[1][e - 4];
+      const f16 h = (f16)xv;
+      sX[st][0][(sn + e) * PJ_P + sci] = h;
+      sX[st][1][(sn + e) * PJ_P + sci] = (f16)(xv - (float)h);
+    }
+  };
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int ci0 = 0; ci0 < C; ci0 += 16) {                  // four k steps per iteration: their 20 loads are issued together
-    float av[4], xv[4][4];
+  fetch(0);
+  f16x8 whi, wlo;
+  lo_split8(wa, wb, whi, wlo);
+  stage(0);
+  const int nk = C / 32;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int st = ks & 1;
+    __syncthreads();                                         // stage st is complete; stage st ^ 1 has been read by everybody
+    f16x8 ahi = whi, alo = wlo;
+    if (ks + 1 < nk) fetch((ks + 1) * 32);
+    if (wave_on) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      av[u] = valid ? wr[ci0 + 4 * u] : 0.f;
-      const float* xp = xb + (size_t)(ci0 + 4 * u) * N;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xv[u][t] = xp[16 * t];
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(&sX[st][0][(16 * t + fr) * PJ_P + 8 * g]);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(&sX[st][1][(16 * t + fr) * PJ_P + 8 * g]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bh, acc[t], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], xv[u][t], acc[t], 0, 0, 0);
+    if (ks + 1 < nk) {
+      lo_split8(wa, wb, whi, wlo);
+      stage(st ^ 1);
+    }
   }
+  if (!wave_on) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = co0 + 4 * g + r;
@@ -298,8 +366,8 @@ int lo_selfattn2d_fwd(const float* x, const float* wq, const float* bq, const fl
     const int CV = C % 128 == 0 ? 128 : 64;
     LoProfScope _p("lo_attn_mfma", 2.0 * B * N * (double)N * (D * (double)(C / CV) + C), 4.0 * B * N * (2.0 * D + 3.0 * C), st);
     const dim3 grid(N / 64, C / CV, B);
-    if (CV == 128) hipLaunchKernelGGL((lo_attn_mfma_kernel<8>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
-    else hipLaunchKernelGGL((lo_attn_mfma_kernel<4>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
+    if (CV == 128) hipLaunchKernelGGL((lo_attn_mfma_kernel<8, 1>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
+    else hipLaunchKernelGGL((lo_attn_mfma_kernel<4, 2>), grid, dim3(256), 0, st, q, k, v, x, gamma, out, C, D, N);
     LO_LAUNCH_CHECK("attn_mfma");
     return LO_OK;
   }

@@ -55,7 +55,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         byts = 4.0 * B * N * (2.0 * D + 3.0 * Cc)
-        print(f"attn B={B} C={Cc} N={N}: {ms * 1e3:.1f} us/call (3 projections + fused attention)  {(fl_core + fl_proj) / ms / 1e9:.2f} TFLOP/s "
+        print(f"attn B={B} C={Cc} N={N}: {ms * 1e3:.1f} us/call (one q|k|v projection launch + fused attention)  {(fl_core + fl_proj) / ms / 1e9:.2f} TFLOP/s "
               f"= {(fl_core + fl_proj) / ms / 1e9 / 2500.0:.4f} of the dense fp16 MFMA peak;  {byts / ms / 1e6:.1f} GB/s of q/k/v/x/out traffic = {byts / ms / 1e6 / 8000.0:.4f} of HBM peak")
         return
     x = (torch.randn(B, H, H, Cin, device="cuda") * 0.5).half()
