@@ -366,7 +366,12 @@ def main():
                                    "gradient_accumulation_steps 1, " + ("fp16 MFMA operands" if args.precision == "fp16" else
                                    "e4m3 MFMA operands in the forward convs with Cin % 128 == 0, fp16 elsewhere") + " / fp32 accumulate, fp32 master weights",
                        "global_batch": world * B, "latent_dim": args.latent,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       # how the three Linear layers' weight gradients (82 % of the parameters) exist in this run: never written
+                       # (Gram-matrix norm + AdamW forming the tiles, csrc/lo_lowrank.hip), exchanged as factors, or written out
+                       "linear_weight_gradients": ("factored (never materialised)" if getattr(st, "linear_factored", False) and world == 1
+                                                   else ("factors all-gathered, averaged matrices formed per rank" if getattr(st, "dp_factored", False) and world > 1
+                                                         else "materialised"))},
             "roofline": roof,
             "host_enqueue_ms": 1e3 * host_enqueue_s / args.steps,     # host time per step inside the timed region (includes queue back-pressure)
             "host_enqueue_ms_idle_queue": 1e3 * host_idle_s,          # the host's own cost: 5 steps enqueued into an empty queue (launch-bound only when THIS nears ms_per_step)
