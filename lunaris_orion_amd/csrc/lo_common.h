@@ -137,10 +137,18 @@ __device__ __forceinline__ void lo_gn_group_stats(const float* partial, int MT, 
   if (tid < 64) {
     int grp = tid >> 3, part = tid & 7;
     double s = 0.0, q = 0.0;
-    for (int mt = part; mt < MT; mt += 8) {
-      const float* p = partial + (((size_t)n * MT + mt) * 8 + grp) * 2;
-      s += (double)p[0];
-      q += (double)p[1];
+    // rows part, part + 8, ...: eight rows' loads are issued together and added in row order (the rolled loop chained MT / 8
+    // round trips in front of every GroupNorm pass of the forward: every workgroup of the pass waits for this prologue)
+    for (int mt0 = part; mt0 < MT; mt0 += 64) {
+      f32x2 pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int mt = mt0 + 8 * i;
+        pv[i] = mt < MT ? *reinterpret_cast<const f32x2*>(partial + (((size_t)n * MT + mt) * 8 + grp) * 2) : (f32x2){0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (mt0 + 8 * i < MT) { s += (double)pv[i][0]; q += (double)pv[i][1]; }
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {

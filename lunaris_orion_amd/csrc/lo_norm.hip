@@ -238,7 +238,15 @@ __global__ __launch_bounds__(256) void lo_gn_bwd_apply_kernel(GnBwdArgs a) {
   // per-channel totals over chunks, then gamma-weighted group sums
   for (int c = tid; c < C; c += 256) {
     float t1 = 0.f, t2 = 0.f;
-    for (int k = 0; k < a.np1; ++k) {
+    int k = 0;
+    for (; k + 8 <= a.np1; k += 8) {        // eight rows' loads in flight, added in row order (the order the fused epilogues reproduce)
+      f32x2 pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const f32x2*>(a.P1 + (((size_t)n * a.np1 + k + u) * C + c) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { t1 += pv[u][0]; t2 += pv[u][1]; }
+    }
+    for (; k < a.np1; ++k) {
       const float* p = a.P1 + (((size_t)n * a.np1 + k) * C + c) * 2;
       t1 += p[0];
       t2 += p[1];

@@ -236,3 +236,73 @@ def test_config2_shape_batch32_latent256():
     for g, a, b, k in zip(full, h0, h1, names):
         ref = 0.5 * (a + b)
         assert (g - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-9, k
+
+
+def test_hybrid_step_batch64_latent512_composition_against_the_oracle():
+    """BASELINE config 3 as `bench.py` times it (batch 64, latent 512, embedding 256, teacher with the reference's default dropout),
+    checked as a COMPOSITION (the full hybrid step at this size only ran under a finite-loss assertion):
+      * the VAE half of the step is the VAE-only step bit for bit (same weights, same noise): recon / KL losses, reconstruction;
+      * the teacher call that is evaluated (train_hybrid.py:865, `teacher(recon.detach())`) against the oracle's functions on the
+        same input and the same dropout masks (the call's seed is read back from the module), all 64 samples;
+      * reward / baseline / advantage / losses follow train_hybrid.py:867-892 from those outputs, first step (baseline = batch mean,
+        advantage exactly 0) and second step (EMA baseline with momentum 0.9, advantage scaled by reward_scale 0.1);
+      * the second step is finite, nothing was skipped, and only the gate / quality heads of the teacher moved."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.trainer import HybridStepper, VAEStepper
+    from tests.hip_helpers import oracle_teacher_on_device
+    B, L = B_FULL, L_FULL
+    x, eps = _inputs(B)
+    S = T.closed_form_teacher_state(embedding_dim=256)
+    vae = _vae()
+    t = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256)
+    t.load_state_dict(S)
+    t = t.to("cuda").train()
+    t.set_dropout_stream(0xC0FFEE64, exact_next=True)
+    conv_before = t.experts[2][1].conv2[0].weight.detach().clone()
+    gate_before = t.gate[2].weight.detach().clone()
+    hs = HybridStepper(vae, t, gradient_accumulation_steps=1, pipeline_optimizer=True)
+    recon, mu, logvar = hs.step(x, 0, eps)
+    m0 = hs.metrics()
+    seed_eval = t.last_drop_seed                      # the evaluated call is the step's second teacher call
+    out = {k: v.detach().cpu() for k, v in hs.last_teacher_out.items() if torch.is_tensor(v)}
+    assert t.last_path(B) == 2
+    # ---- VAE half == the VAE-only step
+    vs = VAEStepper(_vae(), gradient_accumulation_steps=1, pipeline_optimizer=True)
+    r2, _, _ = vs.step(x, 0, eps)
+    v0 = vs.metrics()
+    assert m0["recon_loss"] == v0["recon_loss"] and m0["kl_loss"] == v0["kl_loss"] and torch.equal(recon, r2)
+    # ---- the evaluated teacher call against the oracle's functions (BatchNorm statistics as the first, statistics-only call left them)
+    t_ref = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=256)
+    t_ref.load_state_dict(S)
+    t_ref = t_ref.to("cuda").train()
+    t_ref.set_dropout_stream(0xC0FFEE64, exact_next=True)
+    t_ref.update_statistics_only(x)                   # train_hybrid.py:853-855: running statistics move, batch statistics are used
+    S1 = {k: v.detach().cpu() for k, v in t_ref.state_dict().items()}
+    ref, _ = oracle_teacher_on_device(recon.detach().cpu(), S1, True, seed_eval, 0.1)
+    for k, tol in (("quality_scores", 2e-3), ("semantic_score", 2e-3), ("expert_weights", 2e-3)):
+        d = (out[k] - ref[k]).abs().max().item()
+        print("hybrid B=64 teacher", k, d)
+        assert d <= tol, (k, d)
+    # ---- reward bookkeeping, first step
+    q, sem = out["quality_scores"].double(), out["semantic_score"].double()
+    quality_reward = q.mean(dim=1, keepdim=True)
+    total = quality_reward + 0.5 * sem
+    base0 = total.mean().item()
+    assert abs(m0["quality_reward"] - quality_reward.mean().item()) <= 1e-5 and abs(m0["semantic_reward"] - sem.mean().item()) <= 1e-5
+    assert abs(m0["baseline"] - base0) <= 1e-5 and m0["advantage"] == 0.0 and m0["pg_loss"] == 0.0
+    assert abs(m0["quality_loss"] + q.mean().item()) <= 1e-5 and abs(m0["teacher_loss"] - 0.5 * m0["quality_loss"]) <= 1e-6
+    assert abs(m0["vae_loss"] - (m0["recon_loss"] + 0.1 * m0["kl_loss"])) <= 1e-6
+    # ---- second step
+    hs.step(x, 1, R.closed_form_eps(B, L, salt=1).cuda())
+    m1 = hs.metrics()
+    o1 = {k: v.detach().cpu().double() for k, v in hs.last_teacher_out.items() if torch.is_tensor(v)}
+    tr1 = (o1["quality_scores"].mean(dim=1, keepdim=True) + 0.5 * o1["semantic_score"]).mean().item()
+    base1 = 0.9 * base0 + 0.1 * tr1
+    adv1 = (tr1 - base1) * 0.1
+    assert abs(m1["baseline"] - base1) <= 1e-5 and abs(m1["advantage"] - adv1) <= 1e-6
+    assert abs(m1["pg_loss"] + adv1 * m1["recon_loss"]) <= 1e-6
+    assert abs(m1["vae_loss"] - (m1["recon_loss"] + 0.1 * m1["kl_loss"] + m1["pg_loss"])) <= 1e-6
+    assert all(torch.isfinite(torch.tensor(float(v))) for v in m1.values()) and m1["grads_finite"] == 1.0 and m1["skipped_steps"] == 0.0
+    hs.synchronize_parameters()
+    torch.cuda.synchronize()
+    assert not torch.equal(t.gate[2].weight, gate_before) and torch.equal(t.experts[2][1].conv2[0].weight, conv_before)
