@@ -129,7 +129,9 @@ def main():
     ap.add_argument("--latent", type=int, default=512)
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the main CPU-baseline leg (0 = the GPU leg's batch)")
-    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of each CPU-baseline leg (after 3 warm-up steps; median)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of each CPU-baseline leg (after --cpu-warmup warm-up steps; median)")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="warm-up steps of the VAE-only CPU-baseline legs")
+    ap.add_argument("--cpu-hybrid-steps", type=int, default=2, help="timed steps of the CPU baseline of the full hybrid step (batch 4; 0 = skip that leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-warmup", type=int, default=MIN_WARMUP_STEPS, help="warm-up steps are topped up to this count (tests pass 0)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -514,12 +516,12 @@ def main():
                 if "roofline" in he:
                     he["roofline"]["kernel"] = "lo_conv3x3_pp / lo_igemm_nt (teacher 3x3 convs 128->512 and 512->512 at 128x128)"
                 out["readme_high_end_feature_dim512"] = he
-            if not args.no_cpu_baseline:
-                out["config3_full_hybrid"]["cpu_baseline"] = cpu_baseline_hybrid(args.latent)
+            if not args.no_cpu_baseline and args.cpu_hybrid_steps > 0:
+                out["config3_full_hybrid"]["cpu_baseline"] = cpu_baseline_hybrid(args.latent, steps=args.cpu_hybrid_steps)
         if world == 1 and not args.no_cpu_baseline:
             # the oracle at this leg's shape and at config 1's shape (batch 8, latent 256); 3 warm-up + N timed, median
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch or B, args.latent, args.cpu_steps)
-            out["cpu_baseline_config1"] = cpu_baseline(8, 256, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch or B, args.latent, args.cpu_steps, warm=args.cpu_warmup)
+            out["cpu_baseline_config1"] = cpu_baseline(8, 256, args.cpu_steps, warm=args.cpu_warmup)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
