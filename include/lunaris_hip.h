@@ -319,6 +319,21 @@ int lo_teacher_heads_saved(const LoTeacher* h, size_t* byte_offsets3, size_t* el
 int lo_teacher_heads_backward_ex(LoTeacher* h, const float* flat_state, const float* pooled_f, const float* pooled_e,
                                  const float* raw_q, const float* expert_weights, const float* d_quality, const float* d_weights,
                                  float dropout_p, uint64_t drop_seed, float* rows, float* flat_grads, void* stream);
+/* SURVEY §8 row F2, second half: the teacher trained "as documented" -- gradients for EVERY parameter on the path of the teacher
+ * loss, experts and feature extractor included, i.e. what teacher_loss.backward() (train_hybrid.py:891-904) produces when the three
+ * torch.utils.checkpoint.checkpoint calls of the model (lunar_evaluator.py:194-197, 266-275, 411-414) are non-reentrant.  Like the
+ * reference under checkpointing, the trunk is recomputed block by block (BatchNorm with the batch statistics, running statistics
+ * untouched) and then differentiated: 24 3x3 convs + BatchNorm(train) + Dropout2d, the chunk attention as executed (543 live rows,
+ * attn_drop / proj_drop replayed from the call's seed), layer_scale, the shortcut conv of feature_dim != 128, the feature extractor's
+ * depthwise / pointwise branches.  Must follow lo_teacher_forward(training = 1) on the same images (the heads' inputs and the
+ * dropout stream of that call are used); coef = quality_weight / accum; gscale = power of two applied to the fp16 activation
+ * gradients (parameter gradients come out unscaled; 64 * B * 16384 is a good value); bws = lo_teacher_full_backward_bytes(h) bytes
+ * of scratch; rows as for lo_teacher_heads_backward; flat_grads = the whole state-table layout (lo_teacher_flat_elems floats):
+ * every parameter on the loss path is written, everything else (the three heads the loss does not read, the softmax-invariant
+ * relative-position tables, BatchNorm buffers) is zero. */
+size_t lo_teacher_full_backward_bytes(const LoTeacher* h);
+int lo_teacher_full_backward(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, const float* expert_weights,
+                             float coef, float gscale, float* rows, float* flat_grads, void* stream);
 /* reward / baseline / advantage bookkeeping of _process_batch (train_hybrid.py:870-892) on the device; state2 =
  * {baseline, initialised}; out7 = quality_loss, semantic_reward, quality_reward, baseline, advantage, teacher_loss,
  * mean(quality_scores); adv_dev = mean advantage (input of lo_vae_loss). */

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ rmean, float* __restrict__ rvar, int training,
                                                              float* __restrict__ ss, int tps, int vtps,
-                                                             const float* __restrict__ cvec, float nsample) {
+                                                             const float* __restrict__ cvec, float nsample, float* __restrict__ mr) {
+  // training: 1 = batch statistics + running-statistics update; 2 = batch statistics only (the recomputation of a block inside
+  // lo_teacher_full_backward: the forward of the same step has already moved the running statistics); 0 = running statistics.
+  // mr != null: (mean, 1/sqrt(var + eps)) per channel for the BatchNorm backward.
   __shared__ double red[2][16][17];
   const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -126,11 +129,14 @@ __global__ __launch_bounds__(256) void lo_bn_finalize_kernel(const float* __rest
       double v = tq / (double)count - m * m;
       if (v < 0.0) v = 0.0;
       mean = (float)m; var = (float)v;
-      rmean[c] = 0.9f * rmean[c] + 0.1f * mean;
-      rvar[c] = 0.9f * rvar[c] + 0.1f * (float)(v * (double)count / ((double)count - 1.0));
+      if (training == 1) {
+        rmean[c] = 0.9f * rmean[c] + 0.1f * mean;
+        rvar[c] = 0.9f * rvar[c] + 0.1f * (float)(v * (double)count / ((double)count - 1.0));
+      }
     } else {
       mean = rmean[c]; var = rvar[c];
     }
+    if (mr) { mr[c * 2] = mean; mr[c * 2 + 1] = 1.0f / sqrtf(var + BN_EPS); }
     float sc = gamma[c] / sqrtf(var + BN_EPS);
     ss[c * 2] = sc;
     ss[c * 2 + 1] = beta[c] - mean * sc;
@@ -1036,6 +1042,9 @@ struct HeadsBwdArgs {
   int B, E, I, F;
   uint32_t thr; float inv_keep;                     // the forward's dropout (same call seed): gate and quality-head hidden layers
   LoDropSite ds_gate, ds_q[8];
+  // full backward (lo_teacher_full_backward): the gradients that leave the heads towards the trunk, or null
+  float* d_pool_f;                                  // [B][128]  d loss / d mean_hw(features)        (through the gate)
+  float* d_pool_e;                                  // [E][B][F] d loss / d mean_hw(expert_e output) (through quality head e's LayerNorm)
 };
 __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
   __shared__ float x[128], xh[T_FMAX], ln[T_FMAX], a1[256], h1[256], dz[8], dw[8], dq[8][4], dh[256], da[256], scratch[8], wts[8];
@@ -1084,6 +1093,11 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
   if (tid < a.E) row[a.o_g_b2 + tid] = dz[tid];
   __syncthreads();
   for (int idx = tid; idx < a.I * 128; idx += 256) row[a.o_g_w1 + idx] = da[idx >> 7] * x[idx & 127];
+  if (a.d_pool_f && tid < 128) {
+    float t = 0.f;
+    for (int o = 0; o < a.I; ++o) t += a.g_w1[o * 128 + tid] * da[o];
+    a.d_pool_f[n * 128 + tid] = t;
+  }
   __syncthreads();
   // ---- quality heads
   const int H = a.I / 4;
@@ -1121,13 +1135,26 @@ __global__ __launch_bounds__(256) void lo_t_heads_bwd_kernel(HeadsBwdArgs a) {
     if (tid < 4) row[a.o_q[e][5] + tid] = dq[e][tid];
     __syncthreads();
     for (int idx = tid; idx < H * F; idx += 256) row[a.o_q[e][2] + idx] = da[idx / F] * ln[idx % F];
+    if (a.d_pool_e) __syncthreads();      // ln is reused below for d xhat
+    float p1 = 0.f, p2 = 0.f;
     for (int c = tid; c < F; c += 256) {
       float t = 0.f;
       for (int i = 0; i < H; ++i) t += hw.w1[i * F + c] * da[i];
       row[a.o_q[e][0] + c] = t * xh[c];   // d LayerNorm weight
       row[a.o_q[e][1] + c] = t;           // d LayerNorm bias
+      if (a.d_pool_e) { const float dxh = t * hw.ln_w[c]; ln[c] = dxh; p1 += dxh; p2 += dxh * xh[c]; }
     }
     __syncthreads();
+    if (a.d_pool_e) {
+      // LayerNorm backward towards the pooled features: d v = rstd * (d xhat - mean(d xhat) - xhat * mean(d xhat * xhat))
+      p1 = lo_wave_sum(p1); p2 = lo_wave_sum(p2);
+      if ((tid & 63) == 0) { scratch[tid >> 6] = p1; scratch[4 + (tid >> 6)] = p2; }
+      __syncthreads();
+      const float m1 = (((scratch[0] + scratch[1]) + scratch[2]) + scratch[3]) / (float)F;
+      const float m2 = (((scratch[4] + scratch[5]) + scratch[6]) + scratch[7]) / (float)F;
+      for (int c = tid; c < F; c += 256) a.d_pool_e[((size_t)e * a.B + n) * F + c] = rstd * (ln[c] - m1 - xh[c] * m2);
+      __syncthreads();
+    }
   }
 }
 
@@ -1404,7 +1431,8 @@ extern "C" int lo_teacher_pack(LoTeacher* h, const float* P, void* ws, void* str
 }
 
 static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, const std::string& bnp, float* P, void* ws,
-                         int training, hipStream_t st, int tps = 1, int vtps = 1, const float* cvec = nullptr, float* ss_dst = nullptr) {
+                         int training, hipStream_t st, int tps = 1, int vtps = 1, const float* cvec = nullptr, float* ss_dst = nullptr,
+                         float* mr = nullptr) {
   LoProfScope _p("lo_bn_finalize", 0, 0, st);
   if (training && nrow > 256) {
     // two stages: 64 row splits in parallel, then the 64 split sums
@@ -1416,7 +1444,7 @@ static int t_bn_finalize(LoTeacher* h, const float* partial, int nrow, int C, co
   }
   hipLaunchKernelGGL(lo_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nrow, C, (float)((size_t)h->B * T_HW),
                      TP(bnp + ".weight"), TP(bnp + ".bias"), TP(bnp + ".running_mean"), TP(bnp + ".running_var"), training,
-                     ss_dst ? ss_dst : TW(float, h->o_ss), tps, vtps, cvec, (float)h->B);   // ss_dst: (scale, shift) kept elsewhere than the shared slot
+                     ss_dst ? ss_dst : TW(float, h->o_ss), tps, vtps, cvec, (float)h->B, mr);   // ss_dst: (scale, shift) kept elsewhere than the shared slot
   LO_LAUNCH_CHECK("bn_finalize");
   return LO_OK;
 }
@@ -1784,7 +1812,7 @@ extern "C" int lo_teacher_heads_saved(const LoTeacher* h, size_t* byte_offsets3,
 }
 static int t_heads_backward(LoTeacher* h, const float* P, const float* pooled_f, const float* pooled_e, const float* raw_q,
                             const float* expert_weights, const float* dq_up, const float* dw_up, float coef, float drop_p,
-                            uint64_t drop_seed, float* rows, float* grads, hipStream_t st) {
+                            uint64_t drop_seed, float* rows, float* grads, hipStream_t st, float* d_pool_f = nullptr, float* d_pool_e = nullptr) {
   size_t b0, b1;
   LO_TRYT(lo_teacher_grad_range(h, &b0, &b1));
   HeadsBwdArgs a;
@@ -1802,6 +1830,7 @@ static int t_heads_backward(LoTeacher* h, const float* P, const float* pooled_f,
   a.rows = rows; a.row_len = b1 - b0;
   a.scale = -coef / ((float)h->B * 4.f);
   a.dq_up = dq_up; a.dw_up = dw_up;
+  a.d_pool_f = d_pool_f; a.d_pool_e = d_pool_e;
   a.B = h->B; a.E = h->E; a.I = h->I; a.F = h->F;
   a.thr = drop_p > 0.f ? (uint32_t)lrintf(drop_p * 65536.f) : 0u;
   if (drop_p > 0.f && a.thr == 0) a.thr = 1;
@@ -1838,3 +1867,4 @@ extern "C" int lo_hybrid_reward(const float* quality, const float* semantic, int
   LO_LAUNCH_CHECK("hybrid_reward");
   return LO_OK;
 }
+#include "lo_teacher_bwd.inc"

@@ -349,6 +349,33 @@ class LunarMoETeacher(nn.Module):
         return ({"quality_scores": q, "expert_weights": w, "style_embedding": st, "prompt_embedding": pr,
                  "semantic_score": sem, "feature_maps": None}, eng, p, seed)
 
+    def full_backward(self, x: torch.Tensor, expert_weights: torch.Tensor, coef: float, gscale: float = None) -> torch.Tensor:
+        """SURVEY §8 row F2, second half: gradients of ``coef * -mean(quality_scores)`` (train_hybrid.py:891-892, coef =
+        quality_weight / accumulation steps) for EVERY teacher parameter on the loss path -- what ``teacher_loss.backward()``
+        yields when the model's three ``checkpoint`` calls (lunar_evaluator.py:194-197, 266-275, 411-414) are non-reentrant.
+        Must follow the train-mode ``forward(x)`` whose loss it differentiates (same images; the call's dropout stream and head
+        inputs are replayed).  Returns the flat gradient in the layout of ``self._flat`` (``parameter_grad_views`` slices it)."""
+        x = x.detach().contiguous().float()
+        B = x.shape[0]
+        eng = self._engine(B)
+        if getattr(eng, "bws", None) is None:
+            eng.bws = torch.empty(_lib.lib.lo_teacher_full_backward_bytes(eng.handle), dtype=torch.uint8, device=x.device)
+        b, e = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib.lo_teacher_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_teacher_grad_range")
+        rows = torch.empty(B * (e.value - b.value), dtype=torch.float32, device=x.device)
+        grads = torch.empty_like(self._flat)
+        if gscale is None:
+            gscale = 64.0 * B * 16384.0                      # a power of two for power-of-two batches; any positive value is exact enough
+        _lib.check(_lib.lib.lo_teacher_full_backward(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), eng.bws.data_ptr(),
+                                                     expert_weights.contiguous().float().data_ptr(), float(coef), float(gscale), rows.data_ptr(),
+                                                     grads.data_ptr(), _lib.stream_ptr()), "lo_teacher_full_backward")
+        return grads
+
+    def parameter_grad_views(self, flat_grads: torch.Tensor):
+        """name -> view of ``flat_grads`` (layout of ``self._flat``) for every parameter."""
+        base = self._flat.data_ptr()
+        return {k: flat_grads[(p.data_ptr() - base) // 4:(p.data_ptr() - base) // 4 + p.numel()].view(p.shape) for k, p in self.named_parameters()}
+
     def forward(self, x: torch.Tensor, prompt_embedding=None):
         """lunar_evaluator.py:408-462.  ``prompt_embedding`` is accepted and ignored exactly like the reference does
         (it is overwritten at :438 before any use).  With gradients enabled, ``quality_scores`` / ``expert_weights`` carry a
