@@ -334,6 +334,14 @@ int lo_teacher_heads_backward_ex(LoTeacher* h, const float* flat_state, const fl
 size_t lo_teacher_full_backward_bytes(const LoTeacher* h);
 int lo_teacher_full_backward(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, const float* expert_weights,
                              float coef, float gscale, float* rows, float* flat_grads, void* stream);
+/* clip_grad_norm_(teacher.parameters()) + AdamW (train_hybrid.py:914, 922) with every teacher parameter live: the norm over the whole
+ * flat gradient of lo_teacher_full_backward, the update over exactly the tensors that have a .grad in the reference (not the
+ * BatchNorm buffers, not the style / prompt / semantic heads, whose .grad is None there).  m, v: lo_teacher_flat_elems floats each,
+ * scratch: 1028 floats ([1024..1027] = norm, clip coefficient, finite flag, skipped count as for lo_clip_adamw_step).  The fp16 operand
+ * copies are stale afterwards: lo_teacher_pack before the next forward. */
+int lo_teacher_clip_adamw_full(LoTeacher* h, float* flat_state, const float* flat_grads, float* m, float* v, float max_norm, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, void* stream);
+int lo_teacher_full_param_count(const LoTeacher* h, size_t* tensors, size_t* elems);
 /* reward / baseline / advantage bookkeeping of _process_batch (train_hybrid.py:870-892) on the device; state2 =
  * {baseline, initialised}; out7 = quality_loss, semantic_reward, quality_reward, baseline, advantage, teacher_loss,
  * mean(quality_scores); adv_dev = mean advantage (input of lo_vae_loss). */

@@ -351,9 +351,14 @@ class HybridStepper(VAEStepper):
     teacher calls, each with its own call seed; the heads' backward replays the masks of the evaluated call."""
 
     def __init__(self, vae: LunarisCoreVAE, teacher, teacher_lr: float = 1e-4, quality_weight: float = 0.5, reward_scale: float = 0.1,
-                 semantic_weight: float = 0.5, baseline_momentum: float = 0.9, run_dead_teacher_call: bool = True, **kw):
+                 semantic_weight: float = 0.5, baseline_momentum: float = 0.9, run_dead_teacher_call: bool = True,
+                 teacher_full_backward: bool = False, **kw):
         super().__init__(vae, **kw)
         self.teacher = teacher
+        # SURVEY §8 row F2: the teacher trained "as documented" -- every parameter on the path of the teacher loss gets its gradient
+        # (lo_teacher_full_backward: the reference with non-reentrant checkpoints) and its AdamW update; off = the reference as it
+        # executes (gate + quality heads only)
+        self.teacher_full_backward = bool(teacher_full_backward)
         self.teacher_base_lr = teacher_lr
         self.quality_weight, self.reward_scale = quality_weight, reward_scale
         self.semantic_weight, self.baseline_momentum = semantic_weight, baseline_momentum
@@ -371,7 +376,9 @@ class HybridStepper(VAEStepper):
         b, e = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.lib.lo_teacher_grad_range(h, C.byref(b), C.byref(e)), "lo_teacher_grad_range")
         if not self._t_ready:
-            self.t_range = (b.value, e.value)
+            self.t_heads_range = (b.value, e.value)
+            self.t_range = (0, t._flat.numel()) if self.teacher_full_backward else (b.value, e.value)
+            b, e = C.c_size_t(self.t_range[0]), C.c_size_t(self.t_range[1])
             n = e.value - b.value
             self.t_grads = torch.zeros_like(t._flat)
             self.t_m = torch.zeros(n, dtype=torch.float32, device=t._flat.device)
@@ -389,9 +396,10 @@ class HybridStepper(VAEStepper):
                 live = {"state": {i: st for i, st in pending.get("state", {}).items() if b.value <= offs[names[int(i)]] < e.value}}
                 load_adamw_state_dict(live, tp, self.t_m, self.t_v, rel)
                 self._pending_teacher_opt = None
+        hb, he = self.t_heads_range
         rows = getattr(self, "_t_rows", None)
-        if rows is None or rows.numel() != batch * (e.value - b.value):
-            self._t_rows = torch.empty(batch * (e.value - b.value), dtype=torch.float32, device=t._flat.device)
+        if rows is None or rows.numel() != batch * (he - hb):
+            self._t_rows = torch.empty(batch * (he - hb), dtype=torch.float32, device=t._flat.device)
         return h, ws
 
     def step(self, images: torch.Tensor, batch_idx: int = 0, eps: Optional[torch.Tensor] = None, **_):
@@ -428,6 +436,10 @@ class HybridStepper(VAEStepper):
             self.opt_steps += 1
             self._clip_adamw(flat, lr, st, eng)
             self._observe_skipped_updates()
+            if self.teacher_full_backward:
+                self._teacher_full_update(t, recon, tout, t_lr, st)
+                self.last = (recon, mu, logvar)
+                return recon, mu, logvar
             # teacher: gate + quality heads only (train_hybrid.py:891-904, 914, 922)
             b, e = self.t_range
             _lib.check(_lib.lib.lo_teacher_heads_backward(h, t._flat.data_ptr(), ws.data_ptr(), tout["expert_weights"].data_ptr(),
@@ -443,6 +455,24 @@ class HybridStepper(VAEStepper):
             # the gate / head weights are read in fp32 by the head kernels: no re-pack needed
         self.last = (recon, mu, logvar)
         return recon, mu, logvar
+
+    def _teacher_full_update(self, t, recon, tout, t_lr, st):
+        """teacher_loss.backward() + clip + AdamW with every teacher parameter live (train_hybrid.py:891-904, 914, 922 under
+        non-reentrant checkpoints): lo_teacher_full_backward on the evaluated images, then lo_teacher_clip_adamw_full."""
+        eng = t._engine(recon.shape[0])
+        if getattr(eng, "bws", None) is None:
+            eng.bws = torch.empty(_lib.lib.lo_teacher_full_backward_bytes(eng.handle), dtype=torch.uint8, device=recon.device)
+        gscale = 64.0 * recon.shape[0] * 16384.0
+        _lib.check(_lib.lib.lo_teacher_full_backward(eng.handle, recon.data_ptr(), t._flat.data_ptr(), eng.ws.data_ptr(), eng.bws.data_ptr(),
+                                                     tout["expert_weights"].data_ptr(), float(self.quality_weight) / float(self.accum),
+                                                     gscale, self._t_rows.data_ptr(), self.t_grads.data_ptr(), st), "lo_teacher_full_backward")
+        if self.grad_sync is not None:
+            self.grad_sync(self.t_grads)
+        _lib.check(_lib.lib.lo_teacher_clip_adamw_full(eng.handle, t._flat.data_ptr(), self.t_grads.data_ptr(), self.t_m.data_ptr(),
+                                                       self.t_v.data_ptr(), float(self.max_grad_norm), float(t_lr), float(self.betas[0]),
+                                                       float(self.betas[1]), float(self.eps), float(self.weight_decay), self.opt_steps,
+                                                       self.t_scratch.data_ptr(), st), "lo_teacher_clip_adamw_full")
+        t.mark_weights_changed()              # conv / attention operands are packed fp16 copies: re-packed before the next forward
 
     def metrics(self) -> Dict[str, float]:
         """The 12 scalars of train_hybrid.py:929-942 (+ grad norm / lr); one host copy."""

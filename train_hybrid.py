@@ -82,6 +82,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="operand format of the VAE's forward convolutions: fp16 (parity-tested default) or fp8 = OCP e4m3 in the layers with Cin %% 128 == 0 that no fused-tap fp16 kernel owns at this batch size (11 of 16 at batch 2, 6 at batch 64), fp16 backward")
     p.add_argument("--teacher_dropout", type=float, default=0.1,
                    help="dropout_rate of the teacher (the reference constructs it with its default 0.1, train_hybrid.py:400-404); 0 = dropout-free fast path")
+    p.add_argument("--teacher_full_backward", action="store_true",
+                   help="train the teacher 'as documented' (SURVEY §8 F2): gradients and AdamW updates for the experts and the feature extractor too, "
+                        "i.e. the reference with non-reentrant checkpoints (lunar_evaluator.py:194-197, 266-275, 411-414); off = the reference as it "
+                        "executes (only the gate and the quality heads learn)")
     return p
 
 
@@ -150,7 +154,10 @@ def main(argv=None):
         teacher = LunarMoETeacher(num_experts=args.num_experts, feature_dim=args.feature_dim, embedding_dim=args.embedding_dim,
                                   dropout_rate=args.teacher_dropout).to("cuda").train()
         stepper = HybridStepper(vae, teacher, teacher_lr=args.teacher_lr, quality_weight=args.quality_weight, reward_scale=args.reward_scale,
-                                semantic_weight=args.semantic_weight, baseline_momentum=args.baseline_momentum, **common)
+                                semantic_weight=args.semantic_weight, baseline_momentum=args.baseline_momentum,
+                                teacher_full_backward=args.teacher_full_backward, **common)
+        if args.teacher_full_backward:
+            log.info("teacher full backward on: every teacher parameter on the loss path is trained (non-reentrant checkpoint semantics)")
         log.info(f"teacher on: LunarMoETeacher forward as executed by the reference, dropout_rate {args.teacher_dropout} in train mode"
                  + ("" if args.teacher_dropout > 0 else " (dropout-free fast path: constant-field shortcuts)"))
     else:
