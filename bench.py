@@ -143,6 +143,7 @@ def main():
                     help="operand format of the forward convs in the timed leg (fp8 = BASELINE config 5 mode; the headline number is fp16)")
     ap.add_argument("--fp8-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps in the fp8 operand mode, BASELINE config 5 (0 = skip)")
     ap.add_argument("--hybrid-steps", type=int, default=20, help="extra leg (N=1): full hybrid VAE+teacher steps, BASELINE config 3 (0 = skip)")
+    ap.add_argument("--fullbwd-steps", type=int, default=3, help="extra leg (N=1): full hybrid steps with --teacher_full_backward, SURVEY F2 (0 = skip)")
     ap.add_argument("--highend-steps", type=int, default=3, help="extra leg (N=1): full hybrid steps of the README High-End recipe, --feature_dim 512 (0 = skip)")
     ap.add_argument("--config2-steps", type=int, default=100, help="extra leg (N=1): VAE-only steps at batch 32 / latent 256, BASELINE config 2 (0 = skip)")
     ap.add_argument("--dp-exchange", choices=["allreduce", "direct"], default=os.environ.get("LO_DP_EXCHANGE", "direct"),
@@ -443,11 +444,11 @@ def main():
             del st
             torch.cuda.empty_cache()
 
-            def hybrid_leg(p_drop, steps, prof_steps, precision="fp16", feature_dim=128, warm=6):
+            def hybrid_leg(p_drop, steps, prof_steps, precision="fp16", feature_dim=128, warm=6, full_bwd=False):
                 torch.manual_seed(42)
                 teacher = LunarMoETeacher(num_experts=4, feature_dim=feature_dim, embedding_dim=256, dropout_rate=p_drop, mfma_precision=precision).to("cuda").train()
                 vae_m = LunarisCoreVAE(latent_dim=args.latent, mfma_precision=precision).to("cuda")    # same seed: same initial weights in every leg
-                hs = HybridStepper(vae_m, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline)
+                hs = HybridStepper(vae_m, teacher, gradient_accumulation_steps=1, pipeline_optimizer=pipeline, teacher_full_backward=full_bwd)
                 hs.step(pool[0], batch_idx=0)
                 first = hs.metrics()                       # first step from identical weights / sprites / mask stream: comparable across legs
                 for i in range(1, warm):
@@ -471,6 +472,9 @@ def main():
                     rw = collect_profile(_lib.lib)
                     _lib.lib.lo_prof_enable(0)
                     tot = sum(r[0] for r in rw.values())
+                    if full_bwd:
+                        leg["kernel_ms_per_step"] = tot / prof_steps
+                        leg["top_kernels_ms_per_step"] = {k: round(r[0] / prof_steps, 3) for k, r in sorted(rw.items(), key=lambda kv: -kv[1][0])[:12]}
                     # the teacher's full-resolution 3x3 convolutions (one kernel, lo_conv3x3_pp, under per-call-site profiler names)
                     conv = [r for k, r in rw.items() if k.startswith("t_conv1") or k.startswith("t_conv2 (dense") or k.startswith("t_conv2 (generic")]
                     c_ms, c_n, c_fl = sum(r[0] for r in conv), sum(r[1] for r in conv), sum(r[2] for r in conv)
@@ -507,6 +511,13 @@ def main():
             main_leg["without_teacher_dropout"] = {k: fast_leg[k] for k in ("value", "ms_per_step", "teacher_dropout", "teacher_path", "host_enqueue_ms")}
             main_leg["without_teacher_dropout"]["note"] = "LunarMoETeacher(dropout_rate=0): constant-field shortcuts valid; NOT the reference's default step"
             out["config3_full_hybrid"] = main_leg
+            if args.fullbwd_steps > 0:
+                # the same step with the teacher trained "as documented" (--teacher_full_backward): trunk recomputed
+                # block by block and differentiated, clip + AdamW over all 234 live teacher tensors
+                fb = hybrid_leg(0.1, args.fullbwd_steps, 1, warm=2, full_bwd=True)
+                fb["workload"] = ("config3_full_hybrid with --teacher_full_backward: + recomputation and backward of the feature extractor and the 12 ExpertBlocks "
+                                  "(non-reentrant checkpoint semantics of lunar_evaluator.py:194-197, 266-275, 411-414) + AdamW over every live teacher parameter")
+                out["config3_full_hybrid"]["teacher_full_backward"] = fb
             if args.highend_steps > 0:
                 # README.md:102-118 "High-End" recipe: batch 64, latent 512, embedding 256, feature_dim 512 (2 TFLOP per image and teacher
                 # forward: 262 TFLOP per step), teacher dropout 0.1; generic full-resolution teacher path

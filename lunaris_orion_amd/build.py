@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblunaris_hip.so")
 SOURCES = ["lo_util.cpp", "lo_conv.hip", "lo_conv3.hip", "lo_wgrad3.hip", "lo_wgrad2.hip", "lo_norm.hip", "lo_edge.hip", "lo_train.hip", "lo_lowrank.hip", "lo_attn.hip", "lo_teacher.hip", "lo_api.hip"]
-HEADERS = ["lo_common.h", "lo_internal.h", os.path.join("..", "..", "include", "lunaris_hip.h")]
+# lo_teacher_bwd.inc is textually included at the end of lo_teacher.hip (the teacher's full backward; same translation unit)
+HEADERS = ["lo_common.h", "lo_internal.h", "lo_teacher_bwd.inc", os.path.join("..", "..", "include", "lunaris_hip.h")]
 
 
 def _hipcc() -> str:

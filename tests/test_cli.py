@@ -145,7 +145,7 @@ def test_bench_line_contract(tmp_path):
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--min-warmup", "0", "--batch", "8", "--latent", "256",
                         "--hybrid-steps", "1", "--cpu-batch", "2", "--cpu-steps", "1", "--cpu-warmup", "1", "--cpu-hybrid-steps", "0",
-                        "--fp8-steps", "0", "--config2-steps", "0", "--highend-steps", "0"], capture_output=True, text=True, timeout=900)      # the legs this test does not look at: off
+                        "--fp8-steps", "0", "--config2-steps", "0", "--highend-steps", "0", "--fullbwd-steps", "0"], capture_output=True, text=True, timeout=900)      # the legs this test does not look at: off
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1

@@ -568,3 +568,40 @@ def test_statistics_only_call_with_dropout_has_the_side_effects_of_forward():
         states.append({k: v.detach().cpu().clone() for k, v in t.state_dict().items()})
     for k in states[0]:
         assert torch.equal(states[0][k], states[1][k]), k
+
+
+def test_oracle_autograd_reproduces_the_reference_full_backward_fixture():
+    """SURVEY §8 row F2, second half.  tests/golden/teacher_fullgrad_drop_B2.npz holds the gradients of the REFERENCE teacher for its own
+    teacher loss with `torch.utils.checkpoint.checkpoint` made non-reentrant (oracle/make_golden.py run_teacher_fullgrad: the reference's
+    modules, its dropout modules on injected masks).  Autograd through the oracle's plain restatement must give the same numbers:
+    this pins the oracle that `lo_teacher_full_backward` is tested against on the GPU (tests/test_teacher_fullgrad_gpu.py)."""
+    import os
+    import numpy as np
+    from oracle import dropout_ref as D
+    from oracle import vae_ref as R
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "teacher_fullgrad_drop_B2.npz"))
+    B = int(z["meta"][0])
+    assert int(z["meta"][4]) == 1 and int(z["n_with_grad"]) == 234 and int(z["n_params"]) == 252
+    seed, p = 0x5EEDD209C0FFEE11, 0.1
+    x = R.normalise_sprites(R.closed_form_sprites(B))
+    S = T.closed_form_teacher_state()
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "last_spatial" not in k else v) for k, v in S.items()}
+    out, _ = T.teacher_forward(x, P, training=True, masks=D.TeacherMasks(seed, p, B))
+    loss = float(z["quality_weight"]) * -torch.mean(out["quality_scores"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-6
+    names = [k for k, v in P.items() if v.requires_grad]
+    grads = dict(zip(names, torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)))
+    n = 0
+    for k, g in grads.items():
+        tag = f"tgrad/{k}"
+        if tag + "/l2" not in z:
+            # no gradient in the reference either (the heads the loss does not read), or the softmax-invariant relative-position tables
+            assert g is None, k
+            continue
+        n += 1
+        l2 = float(z[tag + "/l2"])
+        assert abs(g.double().norm().item() - l2) <= 2e-3 * l2 + 1e-12, k
+        idx = ((R.closed_form_uniform("sample." + tag, min(2048, g.numel())) + 1.0) * 0.5 * g.numel()).long().clamp_(0, g.numel() - 1)
+        ref = torch.from_numpy(z[tag + "/samples"])
+        assert (g.flatten()[idx] - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-9, k
+    assert n == 234 - 24
