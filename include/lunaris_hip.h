@@ -332,6 +332,11 @@ int lo_teacher_heads_backward_ex(LoTeacher* h, const float* flat_state, const fl
  * every parameter on the loss path is written, everything else (the three heads the loss does not read, the softmax-invariant
  * relative-position tables, BatchNorm buffers) is zero. */
 size_t lo_teacher_full_backward_bytes(const LoTeacher* h);
+/* lo_teacher_forward(training = 1) through the plain expert path with every ExpertBlock's output kept inside bws: the forward to use
+ * in a step that ends in lo_teacher_full_backward(..., the same bws), which then skips its own recomputation of the block inputs. */
+int lo_teacher_forward_keep(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, float dropout_p,
+                            uint64_t drop_seed, float* quality_scores, float* expert_weights, float* style_embedding,
+                            float* prompt_embedding, float* semantic_score, void* stream);
 int lo_teacher_full_backward(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, const float* expert_weights,
                              float coef, float gscale, float* rows, float* flat_grads, void* stream);
 /* clip_grad_norm_(teacher.parameters()) + AdamW (train_hybrid.py:914, 922) with every teacher parameter live: the norm over the whole

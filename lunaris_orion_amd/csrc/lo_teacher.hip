@@ -1224,6 +1224,9 @@ struct LoTeacher {
   // dropout of the last forward (lo_teacher_heads_backward replays the head masks), and which path it took:
   // 0 sparse (constant-field shortcuts), 1 dense (LO_T_DENSE=1), 2 dropout (train mode, dropout_p > 0)
   float last_p; uint64_t last_seed; int last_path;
+  // full-backward mode (lo_teacher_bwd.inc): lo_teacher_forward_keep runs the plain (generic) expert path for every feature_dim and
+  // leaves each block's output where lo_teacher_full_backward expects it, which then skips its own first pass
+  bool keep; f16* keep_xs[8][3]; const void* kept_bws; bool kept;
 };
 
 // name -> index of the state table: hashed (a forward makes ~1000 of these look-ups; the linear scan over 351 names they used to be
@@ -1253,6 +1256,7 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
   h->B = B; h->E = num_experts; h->I = 256; h->emb = embedding_dim; h->layers = 3; h->F = F;
   h->att_zeroed = false; h->att_zeroed_ws = nullptr;
   h->last_p = 0.f; h->last_seed = 0; h->last_path = -1;
+  h->keep = false; h->kept = false; h->kept_bws = nullptr;
   // ---- state table in the reference's state_dict order (lunar_evaluator.py; checked against the oracle in tests)
   auto add = [&](const std::string& k, size_t n, bool f = true) { h->names.push_back(k); h->numel.push_back(n); h->is_float.push_back(f); };
   auto conv = [&](const std::string& p, int co, int ci, int k, int groups = 1) { add(p + ".weight", (size_t)co * (ci / groups) * k * k); add(p + ".bias", co); };
@@ -1325,16 +1329,17 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
       h->o_wqkv[e][l] = take((size_t)3 * F * F * 2);
       h->o_wproj[e][l] = take((size_t)F * F * 2);
     }
+  // the plain expert path: feature_dim 256 / 512 always, feature_dim 128 in keep mode (lo_teacher_forward_keep)
+  LO_TRYT(lo_make_geom(&h->g3a, LO_CONV3_S1, B, 128, 128, 128, F));
+  LO_TRYT(lo_make_geom(&h->g3b, LO_CONV3_S1, B, 128, 128, F, F));
+  LO_TRYT(lo_make_geom(&h->gqF, LO_LINEAR, B, 128, 128, F, 3 * F));
+  LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, F, F));
+  h->o_attc = take((size_t)B * 1024 * F * 2);
   if (F != 128) {
-    LO_TRYT(lo_make_geom(&h->g3a, LO_CONV3_S1, B, 128, 128, 128, F));
-    LO_TRYT(lo_make_geom(&h->g3b, LO_CONV3_S1, B, 128, 128, F, F));
-    LO_TRYT(lo_make_geom(&h->gqF, LO_LINEAR, B, 128, 128, F, 3 * F));
     LO_TRYT(lo_make_geom(&h->gsc, LO_LINEAR, B, 128, 128, 128, F));
-    LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, F, F));
     for (int e = 0; e < num_experts; ++e) h->o_wsc[e] = take((size_t)F * 128 * 2);
     h->o_sc = take(px * F * 2);
     h->o_ss_sc = take((size_t)F * 2 * 4);
-    h->o_attc = take((size_t)B * 1024 * F * 2);
   }
   for (int b = 0; b < 3; ++b) h->o_wpw[b] = take((size_t)64 * 32 * 2);
   h->o_wfus = take((size_t)128 * 192 * 2);
@@ -1500,7 +1505,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
     LO_HIP(hipMemsetAsync(TW(void, h->o_Z), 0, (size_t)B * 1024 * 1088 * 2, st));    // rows >= 543 of every sample stay zero
     LO_HIP(hipMemsetAsync(TW(void, h->o_qin), 0, (size_t)h->qrows * 128 * 2, st));
-    if (h->F != 128) LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * h->F * 2, st));   // rows >= 543 of every sample stay zero
+    LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * h->F * 2, st));   // rows >= 543 of every sample stay zero
     h->att_zeroed = true; h->att_zeroed_ws = ws;
   }
   float* bnp = TW(float, h->o_bnp);
@@ -1554,21 +1559,23 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
                      f8 ? TW(uint8_t, h->o_feat8) : nullptr));
   LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
   // ---- experts (lunar_evaluator.py:260-275, 422-428)
-  if (h->F != 128) {
-    // generic path (feature_dim 256 / 512, README High-End recipe): every tensor at full resolution; the attention keeps the
+  const bool plain = h->F != 128 || h->keep;
+  h->kept = false;
+  if (plain) {
+    // generic path (feature_dim 256 / 512, README High-End recipe; any feature_dim in keep mode): every tensor at full resolution; the attention keeps the
     // reference's "only 543 positions are ever written" behaviour through compact rows (attc / projc) + one expansion pass,
     // which is also where proj_drop is applied
     const int F = h->F;
     h->last_path = drop ? 2 : 1;
-    const int lgc8 = F == 256 ? 5 : 6;
+    const int lgc8 = F == 128 ? 4 : (F == 256 ? 5 : 6);
     for (int e = 0; e < h->E; ++e) {
       const f16* xin = TW(f16, h->o_feat);
       for (int l = 0; l < 3; ++l) {
         std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
         const LoGeom& g1 = l == 0 ? h->g3a : h->g3b;
-        f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
+        f16* xout = h->keep ? h->keep_xs[e][l] : TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
         const float* id_ss = nullptr;
-        if (l == 0) {
+        if (l == 0 && F != 128) {
           // shortcut = BatchNorm(Conv1x1(x)) (in_channels 128 != out_channels F): raw output + its (scale, shift), applied in the tail
           LoConvExtra exs{0, bnp};
           LO_TAGGED("t_shortcut (igemm)", lo_conv_run(h->gsc, xin, TW(f16, h->o_wsc[e]), TP(p + ".shortcut.0.bias"), nullptr, TW(f16, h->o_sc), nullptr, nullptr, 1, st, nullptr, &exs));
@@ -1588,7 +1595,8 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           LoProfScope _p("lo_t_attn (generic)", 0, 0, st);
           const dim3 grid((B * 543 + 3) / 4);
           const LoDropSite dsa = site(LO_DS_BLOCK(e, l, 1));
-          if (F == 256) hipLaunchKernelGGL((lo_t_attn_generic_kernel<32>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
+          if (F == 128) hipLaunchKernelGGL((lo_t_attn_generic_kernel<16>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
+          else if (F == 256) hipLaunchKernelGGL((lo_t_attn_generic_kernel<32>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
           else hipLaunchKernelGGL((lo_t_attn_generic_kernel<64>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
         }
         LO_LAUNCH_CHECK("t_attn_generic");
@@ -1596,7 +1604,10 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         {
           LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * F, st);
           const size_t nchunk = px * (F / 8);
-          if (lgc8 == 5)
+          if (lgc8 == 4)
+            hipLaunchKernelGGL((lo_t_projdrop_kernel<4>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
+                               TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
+          else if (lgc8 == 5)
             hipLaunchKernelGGL((lo_t_projdrop_kernel<5>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
                                TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
           else
@@ -1612,15 +1623,16 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           LO_LAUNCH_CHECK("t_drop2d_ss");
         }
         if (l < 2 || !stats_only)
-          LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), l == 0 ? TW(f16, h->o_sc) : xin, l < 2 ? xout : nullptr, F, F, 0, 1,
+          LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), (l == 0 && F != 128) ? TW(f16, h->o_sc) : xin, (l < 2 || h->keep) ? xout : nullptr, F, F, 0, 1,
                              (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st, nullptr, drop, nullptr, id_ss));
         xin = xout;
       }
       if (!stats_only) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * F, F, ws, st));
     }
+    h->kept = h->keep && !stats_only;
   }
   const int mt3 = lo_conv_bn_rows(h->g3);   // BatchNorm partial rows of the conv1 epilogue (igemm: M tiles; fused-tap kernel: pixel tiles)
-  for (int e = 0; e < (h->F == 128 ? h->E : 0); ++e) {
+  for (int e = 0; e < (plain ? 0 : h->E); ++e) {
     const f16* xin = TW(f16, h->o_feat);
     const uint8_t* xin8 = f8 ? TW(uint8_t, h->o_feat8) : nullptr;
     for (int l = 0; l < 3; ++l) {
@@ -1737,7 +1749,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     if ((drop && !stats_only) || (!drop && !h->fuse_tail)) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
   }
   if (stats_only) return LO_OK;
-  if (h->fuse_tail && !drop) {
+  if (h->fuse_tail && !drop && !plain) {
     // x_3 of every expert is pooled in ONE pass over feat (the full-resolution x_l were never written)
     {
       LoProfScope _p("lo_t_pool (tail on load)", 0, 2.0 * px * 128, st);

@@ -325,8 +325,9 @@ class LunarMoETeacher(nn.Module):
         with torch.no_grad():
             self._nbt += 1
 
-    def _native_forward(self, x: torch.Tensor):
-        """One `lo_teacher_forward`.  Returns (outputs, engine, dropout_p, call seed)."""
+    def _native_forward(self, x: torch.Tensor, keep: bool = False):
+        """One `lo_teacher_forward` (keep: `lo_teacher_forward_keep`, the train-mode forward of a step that ends in `full_backward`: every
+        block's output stays in the backward's scratch).  Returns (outputs, engine, dropout_p, call seed)."""
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 128, 128):
             raise ValueError(f"expected input of shape [B, 3, 128, 128], got {tuple(x.shape)}")
         x = x.detach().contiguous().float()
@@ -340,9 +341,16 @@ class LunarMoETeacher(nn.Module):
         sem = torch.empty(B, 1, dtype=torch.float32, device=dev)
         p = float(self.dropout_rate) if self.training else 0.0
         seed = self._next_drop_seed() if p > 0 else 0
-        _lib.check(_lib.lib.lo_teacher_forward(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), 1 if self.training else 0,
-                                               p, seed, q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
-                                               _lib.stream_ptr()), "lo_teacher_forward")
+        if keep and self.training:
+            if getattr(eng, "bws", None) is None:
+                eng.bws = torch.empty(_lib.lib.lo_teacher_full_backward_bytes(eng.handle), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib.lo_teacher_forward_keep(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), eng.bws.data_ptr(),
+                                                        p, seed, q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
+                                                        _lib.stream_ptr()), "lo_teacher_forward_keep")
+        else:
+            _lib.check(_lib.lib.lo_teacher_forward(eng.handle, x.data_ptr(), self._flat.data_ptr(), eng.ws.data_ptr(), 1 if self.training else 0,
+                                                   p, seed, q.data_ptr(), w.data_ptr(), st.data_ptr(), pr.data_ptr(), sem.data_ptr(),
+                                                   _lib.stream_ptr()), "lo_teacher_forward")
         if self.training:
             with torch.no_grad():
                 self._nbt += 1

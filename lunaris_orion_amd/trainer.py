@@ -410,7 +410,9 @@ class HybridStepper(VAEStepper):
         recon, mu, logvar, eng = vae._native_forward(images, eps, target=images)
         if self.run_dead_teacher_call:
             t.update_statistics_only(images)            # train_hybrid.py:853-855 (side effects only)
-        tout = t._native_forward(recon)[0]              # train_hybrid.py:865 (no autograd node: the head gradients are taken below)
+        # train_hybrid.py:865 (no autograd node: the head gradients are taken below).  Full-backward mode: the plain forward that keeps
+        # every block's output for lo_teacher_full_backward (only on the micro-batch whose gradients are used)
+        tout = t._native_forward(recon, keep=self.teacher_full_backward and (batch_idx + 1) % self.accum == 0)[0]
         self.last_teacher_out = tout
         h, ws = self._teacher_setup(B)
         q_rows, s_rows, n_rows = tout["quality_scores"], tout["semantic_score"], B

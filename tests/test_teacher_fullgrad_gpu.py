@@ -50,11 +50,11 @@ def _oracle_grads(x, drop, device="cpu", **kw):
     return {k: (None if t is None else t.detach().cpu()) for k, t in zip(names, g)}, loss.item()
 
 
-def _native_grads(m, x, drop):
+def _native_grads(m, x, drop, keep=False):
     if drop:
         m.set_dropout_stream(DROP_SEED, exact_next=True)
     with torch.no_grad():
-        out = m(x)
+        out = m._native_forward(x, keep=True)[0] if keep else m(x)       # keep: lo_teacher_forward_keep, no first pass in the backward
     flat = m.full_backward(x, out["expert_weights"], QW)
     torch.cuda.synchronize()
     return {k: v.detach().cpu() for k, v in m.parameter_grad_views(flat).items()}, out
@@ -66,12 +66,19 @@ def _zero_by_construction(k):
     return k.endswith("shortcut.0.bias")
 
 
-@pytest.mark.parametrize("drop", [False, True], ids=["no_dropout", "dropout_0.1"])
-def test_full_backward_matches_the_reference_fixture_and_the_oracle(drop):
+@pytest.mark.parametrize("drop,keep", [(False, False), (True, False), (True, True)], ids=["no_dropout", "dropout_0.1", "dropout_0.1_kept_forward"])
+def test_full_backward_matches_the_reference_fixture_and_the_oracle(drop, keep):
+    """keep: the step's forward is lo_teacher_forward_keep (plain expert path, block outputs left in the backward's scratch: what
+    HybridStepper(teacher_full_backward=True) runs); otherwise the production forward, and the backward recomputes them itself."""
     B = 2
     x = R.normalise_sprites(R.closed_form_sprites(B))
     m = _teacher(drop)
-    got, out = _native_grads(m, x.cuda(), drop)
+    got, out = _native_grads(m, x.cuda(), drop, keep)
+    if keep:
+        # the kept forward is the same function as the production one: outputs against the oracle's at the forward tolerances
+        oo, _ = T.teacher_forward(x, T.closed_form_teacher_state(), training=True, masks=D.TeacherMasks(DROP_SEED, DROP_P, B))
+        assert (out["quality_scores"].cpu() - oo["quality_scores"]).abs().max().item() <= 2e-3
+        assert (out["style_embedding"].cpu() - oo["style_embedding"]).abs().max().item() <= 2e-2
     ora, _ = _oracle_grads(x, drop)
     z = np.load(os.path.join(GOLD, f"teacher_fullgrad_{'drop_' if drop else ''}B2.npz"))
     assert int(z["n_with_grad"]) == 234
