@@ -110,10 +110,11 @@ def test_full_backward_matches_the_reference_fixture_and_the_oracle(drop, keep):
     print("worst relative errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:8])
 
 
-def test_full_backward_feature_dim_256_shortcut_branch_matches_the_oracle():
-    """feature_dim != 128: the first block of every expert has the Conv1x1 + BatchNorm shortcut (lunar_evaluator.py:254-257), 32-wide
-    heads; the oracle's autograd runs on the device (same functions, ATen fp32 kernels)."""
-    B, F, emb = 1, 256, 256
+@pytest.mark.parametrize("F", [256, 512])
+def test_full_backward_wide_teacher_shortcut_branch_matches_the_oracle(F):
+    """feature_dim != 128 (512 = the README High-End recipe): the first block of every expert has the Conv1x1 + BatchNorm shortcut
+    (lunar_evaluator.py:254-257), 32- / 64-wide heads; the oracle's autograd runs on the device (same functions, ATen fp32 kernels)."""
+    B, emb = 1, 256
     x = R.normalise_sprites(R.closed_form_sprites(B))
     m = _teacher(True, F, emb)
     got, _ = _native_grads(m, x.cuda(), True)
