@@ -1,3 +1,10 @@
+#!/usr/bin/env python
+"""Three timed hybrid steps with `--teacher_full_backward` semantics (HybridStepper(teacher_full_backward=True)) at batch 64, teacher dropout
+0.1: wall / host time per step and peak device memory.  The target of `rocprofv3 --kernel-trace --stats -- python3 tools/full_backward_probe.py`
+(per-kernel durations of the teacher's full backward: profiles/r04_teacher_full_backward_kernel_stats.csv).
+
+  python tools/full_backward_probe.py [feature_dim]
+"""
 import sys, torch, time
 sys.path.insert(0, "/root/repo")
 from lunaris_orion_amd.teacher import LunarMoETeacher
