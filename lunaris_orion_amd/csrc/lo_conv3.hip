@@ -759,11 +759,16 @@ struct ConvT4PatchArgs {
   f16* out;             // [B][2H][2W][32]
   float* gn_partial;    // [B][tiles per image][8][2] or null
   LoGeom g;
+  const f16* add_src;   // DG form: residual gradient added to the output (fp32, before the rounding), or null
 };
 
 // NCB = Cin / 64 channel blocks (1 or 2: all blocks of the patch stay resident), COUT = 32 or 64.  One weight buffer holds the two
 // phases of a (parity, channel block): 2 * COUT rows of 512 B (4 taps x 64 channels); the accumulators run over the channel blocks.
-template <int NCB, int COUT>
+// DG: the same kernel as the DATA GRADIENT of a stride-2 3x3 convolution (LO_CONV3_S2_DGRAD: four sub-pixel phases of 1 / 2 / 2 / 4
+// taps reading the same 17 x 17 patch of dy, 9 tap products instead of 16): tap slots past T[phase] of the 512-byte weight rows are
+// filled from the zero page and skipped in the K loop, the residual (skip) gradient is added to the accumulators.  On lo_igemm_nt
+// the four phases are separate tiles with K = 128 ... 512: prologue- and epilogue-bound (46 us for 9.7 GFLOP at batch 64).
+template <int NCB, int COUT, bool DG = false>
 __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArgs a) {
   constexpr int TH = 16, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;      // 324 patch pixels
   constexpr int CIN = 64 * NCB, KT = 4 * CIN;                             // K per phase
@@ -809,7 +814,8 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
       const int pw = r / COUT, co = r - pw * COUT;
       const int p = par * 2 + pw;
       const int c = pos ^ (r & 15), t = c >> 3, c8 = c & 7;
-      const unsigned char* src = wb + ((size_t)g.wofs[p] + (size_t)co * KT + t * CIN + cb * 64 + c8 * 8) * 2;
+      const int ktp = DG ? g.T[p] * CIN : KT;
+      const unsigned char* src = (DG && t >= g.T[p]) ? zpage : wb + ((size_t)g.wofs[p] + (size_t)co * ktp + t * CIN + cb * 64 + c8 * 8) * 2;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s_w + q * 1024), 16, 0, 0);
     }
@@ -845,6 +851,7 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
         const int p = par * 2 + pw;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+          if (DG && t >= g.T[p]) continue;
           const int dy = g.dy[p][t], dx = g.dx[p][t];
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
@@ -881,7 +888,11 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
         const int row = 2 * wave + rr, ox = 2 * fr + pw;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          const f32x4 v = acc[pw][rr][nf] + bv[nf];
+          f32x4 v = acc[pw][rr][nf] + bv[nf];
+          if (DG && a.add_src) {
+            const f16x4 r4 = *reinterpret_cast<const f16x4*>(a.add_src + ((size_t)(n_img * 2 * H + 2 * (y0 + row) + par) * (2 * W) + 2 * x0 + ox) * COUT + nf * 16 + 4 * fq);
+            v += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+          }
           const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
           const int chunk = nf * 2 + (fq >> 1);
           *reinterpret_cast<f16x4*>(s_w + (row * 32 + ox) * (COUT * 2) + ((chunk ^ ((ox >> 1) & (OCH - 1))) * 16) + (fq & 1) * 8) = h;
@@ -937,9 +948,30 @@ bool lo_convt4_patch_applies(const LoGeom& g) {
 }
 int lo_convt4_patch_tiles_per_image(const LoGeom& g) { return lo_convt4_patch_applies(g) ? (g.Hin / 16) * (g.Win / 16) : 0; }
 
+// Data gradient of the stride-2 3x3 convolution 64 -> 128 (lunar_generate.py:102): dy [B][32][32][128] -> dx [B][64][64][64] (+ add_src)
+bool lo_convs2d_patch_applies(const LoGeom& g) {
+  if (g.n_phase != 4 || g.in_stride != 1 || g.out_stride != 2 || g.Cin != 128 || g.Cout != 64) return false;
+  if (g.T[0] != 1 || g.T[1] != 2 || g.T[2] != 2 || g.T[3] != 4) return false;
+  for (int p = 0; p < 4; ++p)
+    for (int t = 0; t < g.T[p]; ++t) if (g.dy[p][t] < 0 || g.dy[p][t] > 1 || g.dx[p][t] < 0 || g.dx[p][t] > 1) return false;
+  return g.Hin % 16 == 0 && g.Win % 16 == 0 && g.Hout == 2 * g.Hin && g.Wout == 2 * g.Win;
+}
+int lo_convs2d_patch_run(const LoGeom& g, const f16* dy, const f16* wp, const f16* add_src, f16* dx, hipStream_t st) {
+  LO_REQUIRE(lo_convs2d_patch_applies(g), "lo_convs2d_patch_run: geometry not supported");
+  ConvT4PatchArgs a{dy, wp, nullptr, dx, nullptr, g, add_src};
+  const int tiles = g.B * (g.Hin / 16) * (g.Win / 16);
+  double flops = 0;
+  for (int p = 0; p < 4; ++p) flops += 2.0 * g.B * g.GH * g.GW * (double)g.Cout * g.T[p] * g.Cin;
+  const double bytes = 2.0 * ((double)g.B * g.Hin * g.Win * g.Cin + (add_src ? 2.0 : 1.0) * (double)g.B * g.Hout * g.Wout * g.Cout + 9.0 * g.Cin * g.Cout);
+  LoProfScope _p(lo_prof_geom_name("lo_convs2d_patch", g), flops, bytes, st);
+  LO_LAUNCH_STOP((lo_convt4_patch_fwd_kernel<2, 64, true>), dim3(tiles), dim3(512), 0, st, a);
+  LO_LAUNCH_CHECK("convs2d_patch");
+  return LO_OK;
+}
+
 int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, f16* out, float* gn_partial, hipStream_t st) {
   LO_REQUIRE(lo_convt4_patch_applies(g), "lo_convt4_patch_run: geometry not supported");
-  ConvT4PatchArgs a{in, wp, bias, out, gn_partial, g};
+  ConvT4PatchArgs a{in, wp, bias, out, gn_partial, g, nullptr};
   const int tiles = g.B * (g.Hin / 16) * (g.Win / 16);
   double flops = 0;
   for (int p = 0; p < 4; ++p) flops += 2.0 * g.B * g.GH * g.GW * (double)g.Cout * g.T[p] * g.Cin;

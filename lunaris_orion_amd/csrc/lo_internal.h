@@ -57,6 +57,8 @@ bool lo_conv3_fuses_gnb(const LoGeom& g);
 bool lo_convt4_patch_applies(const LoGeom& g);   // patch-resident forward of the 64 -> 32 transposed convolution
 int lo_convt4_patch_tiles_per_image(const LoGeom& g);
 int lo_convt4_patch_run(const LoGeom& g, const f16* in, const f16* wp, const float* bias, f16* out, float* gn_partial, hipStream_t st);
+bool lo_convs2d_patch_applies(const LoGeom& g);   // the same kernel as the data gradient of the stride-2 conv 64 -> 128 (all four phases from one dy patch)
+int lo_convs2d_patch_run(const LoGeom& g, const f16* dy, const f16* wp, const f16* add_src, f16* dx, hipStream_t st);
 int lo_conv_gnb_rows(const LoGeom& g);   // P1 rows per sample written by lo_conv_run(g, ..., gb) (fused GroupNorm-backward epilogue)
 int lo_splitk_reduce(const float* slab, const float* bias, float* out32, f16* out16, int M, int N, int nsplit, hipStream_t st);
 int lo_wgrad_nsplit(const LoGeom& g);

@@ -61,6 +61,7 @@ DGRAD_CASES = [
     (KIND_S1D, KIND_S1, 2, 64, 64, 64),
     (KIND_S1D, KIND_S1, 2, 512, 512, 8),
     (KIND_S2D, KIND_S2, 2, 64, 128, 64),
+    (KIND_S2D, KIND_S2, 32, 64, 128, 64),      # batch >= 32: the patch-resident form (all four phases from one dy patch)
     (KIND_S2D, KIND_S2, 2, 256, 512, 16),
     (KIND_T4D, KIND_T4, 2, 512, 256, 8),
     (KIND_T4D, KIND_T4, 2, 64, 32, 64),
