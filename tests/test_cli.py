@@ -140,6 +140,35 @@ def test_cli_hybrid_readme_high_end_flags_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_teacher_full_backward_flag_on_gpu(tmp_path):
+    """--teacher_full_backward: every teacher parameter on the loss path is trained -- the checkpoint carries AdamW
+    state for all of them -- and a run resumed from that checkpoint continues (optimizer state of the full range restored)."""
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_data(str(data), n=12)
+    out = tmp_path / "out"
+    base = [sys.executable, os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--batch_size", "2", "--gradient_accumulation_steps", "1",
+            "--num_epochs", "1", "--log_every", "1", "--teacher_full_backward"]
+    r = subprocess.run(base + ["--output_dir", str(out), "--max_steps", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import torch
+    ck = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
+    st = ck["teacher_optimizer"]["state"]
+    moving = [i for i, s_ in st.items() if float(s_["exp_avg_sq"].abs().sum()) > 0]
+    # 234 tensors have a gradient in the reference under non-reentrant checkpoints; the 24 relative-position tables among them have a
+    # zero gradient (softmax-invariant), so 210 second moments have moved
+    assert len(moving) == 210, len(moving)
+    assert "teacher full backward on" in (out / "training.log").read_text()
+    out2 = tmp_path / "out2"
+    r = subprocess.run(base + ["--output_dir", str(out2), "--max_steps", "1", "--resume_from", str(out / "checkpoints" / "latest.pt")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck2 = torch.load(out2 / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
+    k = next(i for i in moving)
+    assert not torch.equal(ck2["teacher_optimizer"]["state"][k]["exp_avg"], st[k]["exp_avg"])      # the restored moments kept moving
+
+
+@pytest.mark.gpu
 def test_bench_line_contract(tmp_path):
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and (when asked) `cpu_baseline`."""
     import json
