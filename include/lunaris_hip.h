@@ -339,6 +339,14 @@ int lo_teacher_forward_keep(LoTeacher* h, const float* images_nchw, float* flat_
                             float* prompt_embedding, float* semantic_score, void* stream);
 int lo_teacher_full_backward(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, const float* expert_weights,
                              float coef, float gscale, float* rows, float* flat_grads, void* stream);
+/* The same backward for arbitrary upstream gradients d_quality [B][4] / d_weights [B][E] (either may be NULL) with the head inputs
+ * (lo_teacher_heads_saved), dropout_p and call seed of the forward being differentiated passed explicitly: what the module's autograd
+ * node calls (LunarMoETeacher(full_backward=True), so that teacher_loss.backward() of a foreign training loop fills every .grad).
+ * Upstream gradients should be of order 1: a foreign loss scale is divided out first (lo_grad_scale_pick / lo_scale_copy_dev). */
+int lo_teacher_full_backward_ex(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, const float* pooled_f,
+                                const float* pooled_e, const float* raw_q, const float* expert_weights, const float* d_quality,
+                                const float* d_weights, float dropout_p, uint64_t drop_seed, float gscale, float* rows, float* flat_grads,
+                                void* stream);
 /* clip_grad_norm_(teacher.parameters()) + AdamW (train_hybrid.py:914, 922) with every teacher parameter live: the norm over the whole
  * flat gradient of lo_teacher_full_backward, the update over exactly the tensors that have a .grad in the reference (not the
  * BatchNorm buffers, not the style / prompt / semantic heads, whose .grad is None there).  m, v: lo_teacher_flat_elems floats each,

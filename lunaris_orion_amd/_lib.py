@@ -71,6 +71,7 @@ SIGNATURES = {
     "lo_teacher_heads_backward": (i32, [vp, f32p, vp, f32p, flt, f32p, f32p, vp]),
     "lo_teacher_heads_saved": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lo_teacher_full_backward_bytes": (C.c_size_t, [vp]),
+    "lo_teacher_full_backward_ex": (i32, [vp, f32p, f32p, vp, vp, f32p, f32p, f32p, f32p, f32p, f32p, flt, u64, flt, f32p, f32p, vp]),
     "lo_teacher_forward_keep": (i32, [vp, f32p, f32p, vp, vp, flt, u64, f32p, f32p, f32p, f32p, f32p, vp]),
     "lo_teacher_full_backward": (i32, [vp, f32p, f32p, vp, vp, f32p, flt, flt, f32p, f32p, vp]),
     "lo_teacher_clip_adamw_full": (i32, [vp, f32p, f32p, f32p, f32p, flt, flt, flt, flt, flt, flt, i32, f32p, vp]),

@@ -111,7 +111,9 @@ class _TeacherFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *live):
-        out, eng, p, seed = model._native_forward(x)
+        full = model.all_parameters_live and model.training
+        out, eng, p, seed = model._native_forward(x, keep=full)
+        ctx.full, ctx.x = full, (x if full else None)
         offs, elems = (C.c_size_t * 3)(), (C.c_size_t * 3)()
         _lib.check(_lib.lib.lo_teacher_heads_saved(eng.handle, offs, elems), "lo_teacher_heads_saved")
         saved = [eng.ws[offs[i]:offs[i] + 4 * elems[i]].view(torch.float32).clone() for i in range(3)]
@@ -132,7 +134,21 @@ class _TeacherFunction(torch.autograd.Function):
         _lib.check(_lib.lib.lo_teacher_grad_range(eng.handle, C.byref(b), C.byref(e)), "lo_teacher_grad_range")
         rows = torch.empty(w.shape[0] * (e.value - b.value), dtype=torch.float32, device=w.device)
         grads = torch.zeros_like(model._flat)
-        if gq is not None or gw is not None:
+        if ctx.full and (gq is not None or gw is not None):
+            # every parameter on the path (lo_teacher_full_backward_ex).  A foreign loss scale (GradScaler: 65 536) is divided out on the
+            # device first, like at the VAE's boundary, so that the fp16 activation gradients see upstream values of order 1
+            from .vae import _normalise_upstream
+            scr, (gq, gw) = _normalise_upstream([gq, gw])
+            B = w.shape[0]
+            if getattr(eng, "bws", None) is None:
+                eng.bws = torch.empty(_lib.lib.lo_teacher_full_backward_bytes(eng.handle), dtype=torch.uint8, device=w.device)
+            _lib.check(_lib.lib.lo_teacher_full_backward_ex(eng.handle, ctx.x.data_ptr(), model._flat.data_ptr(), eng.ws.data_ptr(), eng.bws.data_ptr(),
+                                                            pooled_f.data_ptr(), pooled_e.data_ptr(), raw_q.data_ptr(), w.data_ptr(), _lib.ptr(gq),
+                                                            _lib.ptr(gw), float(ctx.drop[0]), int(ctx.drop[1]), float(2 ** 20), rows.data_ptr(),
+                                                            grads.data_ptr(), _lib.stream_ptr()), "lo_teacher_full_backward_ex")
+            _lib.check(_lib.lib.lo_grad_unscale_dev(grads.data_ptr(), grads.numel(), scr.data_ptr() + 4, None, _lib.stream_ptr()),
+                       "lo_grad_unscale_dev")
+        elif gq is not None or gw is not None:
             _lib.check(_lib.lib.lo_teacher_heads_backward_ex(eng.handle, model._flat.data_ptr(), pooled_f.data_ptr(), pooled_e.data_ptr(),
                                                              raw_q.data_ptr(), w.data_ptr(), _lib.ptr(gq), _lib.ptr(gw), float(ctx.drop[0]),
                                                              int(ctx.drop[1]), rows.data_ptr(), grads.data_ptr(), _lib.stream_ptr()),
@@ -148,8 +164,12 @@ class _TeacherFunction(torch.autograd.Function):
 
 class LunarMoETeacher(nn.Module):
     def __init__(self, num_experts=4, feature_dim=128, dropout_rate=0.1, rel_pos_size=8, use_checkpointing=True,
-                 expert_layers=3, intermediate_dim=256, embedding_dim=64, mfma_precision: str = "fp16"):
+                 expert_layers=3, intermediate_dim=256, embedding_dim=64, mfma_precision: str = "fp16", full_backward: bool = False):
         super().__init__()
+        # full_backward (an addition of this build): the autograd graph of `quality_scores` / `expert_weights` covers EVERY
+        # parameter on their path -- experts and feature extractor included -- i.e. the reference with `use_reentrant=False` at its three
+        # checkpoint calls (lunar_evaluator.py:194-197, 266-275, 411-414).  Default: the reference as it executes (gate + quality heads only).
+        self.all_parameters_live = bool(full_backward)
         # mfma_precision (an addition of this build): "fp16" (default, parity-tested) or "fp8" = OCP e4m3 operands in the 24
         # full-resolution 3x3 convolutions of the train-mode dropout path (BASELINE config 5); eval mode is fp16 either way
         if mfma_precision not in ("fp16", "fp8"):
@@ -276,7 +296,10 @@ class LunarMoETeacher(nn.Module):
         return eng
 
     def live_parameters(self):
-        """The parameters that receive gradients in the reference step (gate.*, quality_heads.*: SURVEY §3.2), state_dict order."""
+        """The parameters that receive gradients in the reference step (gate.*, quality_heads.*: SURVEY §3.2), state_dict order; with
+        ``LunarMoETeacher(full_backward=True)`` every parameter on the path of quality_scores / expert_weights (all but the style / prompt / semantic heads)."""
+        if self.all_parameters_live:
+            return [p for k, p in self.named_parameters() if k.split(".")[0] not in ("semantic_head", "style_net", "prompt_net")]
         return [p for k, p in self.named_parameters() if k.startswith("gate.") or k.startswith("quality_heads.")]
 
     # ---- dropout stream -----------------------------------------------------------------------------------

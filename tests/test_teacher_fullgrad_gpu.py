@@ -227,3 +227,42 @@ def test_hybrid_stepper_with_teacher_full_backward_runs_the_whole_step():
     assert moved[False]["gate.2.weight"] and not moved[False]["experts.0.0.conv1.0.weight"] and not moved[False]["feature_extractor.conv1.0.weight"]
     for k, mv in moved[True].items():
         assert mv == (k.split(".")[0] not in ("semantic_head", "style_net", "prompt_net")), k
+
+
+def test_module_with_full_backward_fills_every_grad_through_autograd():
+    """LunarMoETeacher(full_backward=True) in a foreign training loop: `teacher_loss.backward()` (train_hybrid.py:891-904) leaves a .grad on
+    every parameter on the path, equal to the reference's (fixture); multiplied by a GradScaler-style 65 536 the gradients come out
+    multiplied by exactly 65 536 (the upstream normalisation is a power of two picked on the device)."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    B = 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    z = np.load(os.path.join(GOLD, "teacher_fullgrad_drop_B2.npz"))
+    grads = {}
+    for scale in (1.0, 65536.0):
+        m = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=64, dropout_rate=DROP_P, full_backward=True)
+        m.load_state_dict(T.closed_form_teacher_state())
+        m = m.to("cuda").train()
+        m.set_dropout_stream(DROP_SEED, exact_next=True)
+        out = m(x)
+        loss = QW * -torch.mean(out["quality_scores"])
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        grads[scale] = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+    n = 0
+    for k, g in grads[1.0].items():
+        if k.split(".")[0] in ("semantic_head", "style_net", "prompt_net"):
+            assert g is None, k
+            continue
+        assert g is not None, k
+        assert torch.equal(grads[65536.0][k], g * 65536.0), k
+        tag = f"tgrad/{k}"
+        if tag + "/samples" not in z:
+            assert g.abs().max().item() == 0.0, k         # relative-position tables
+            continue
+        n += 1
+        g = g.cpu()
+        idx = ((R.closed_form_uniform("sample." + tag, min(2048, g.numel())) + 1.0) * 0.5 * g.numel()).long().clamp_(0, g.numel() - 1)
+        ref = torch.from_numpy(z[tag + "/samples"])
+        ds = (g.flatten()[idx] - ref).norm().item()
+        assert ds <= 4e-2 * max(ref.norm().item(), 1e-3 * float(z["total_norm"]) * (len(idx) / g.numel()) ** 0.5) + 1e-12, (k, ds, ref.norm().item())
+    assert n == 210
