@@ -408,7 +408,7 @@ def main():
             out["config5_fp8_forward"] = {
                 "value": B / dt8, "unit": "sprites/s", "ms_per_step": 1e3 * dt8, "steps": args.fp8_steps,
                 "workload": f"VAE-only step, batch {B}, latent {args.latent}: OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4) in the "
-                            "forward convs with Cin % 128 == 0 that no fused-tap / patch-resident fp16 kernel owns at this batch, fp16 backward",
+                            "forward convs with Cin % 128 == 0 (all but the 128->64 transposed conv, which stays on its patch-resident fp16 kernel), fp16 backward",
                 "fp8_forward_conv_layers": m8._engine(B).fp8_layers, "forward_conv_layers": 16,
                 "loss_parity_vs_f16_first_step": {k: abs(first["fp8"][k] - first["fp16"][k]) for k in ("recon_loss", "kl_loss")},
                 "f16_first_step": {k: first["fp16"][k] for k in ("recon_loss", "kl_loss", "grad_norm")},

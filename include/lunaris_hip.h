@@ -256,8 +256,9 @@ int lo_grad_scale_pick(const float* g0, size_t n0, const float* g1, size_t n1, c
 int lo_scale_copy_dev(const float* src, float* dst, size_t n, const float* scale_dev, void* stream);
 int lo_grad_unscale_dev(float* x, size_t n, const float* scale_dev, const void* fail_word, void* stream);
 /* fp8 operand mode (LO_VAE_FP8_FWD, train_hybrid.py --mfma_precision fp8; BASELINE.json configs[4]): how many of the plan's 16
- * forward conv layers actually run on e4m3 operands.  The count depends on the batch: layers a fused-tap or patch-resident fp16
- * kernel owns at this batch size stay fp16 (11 at batch 2, 6 at batch 64).  0 when the mode is off. */
+ * forward conv layers actually run on e4m3 operands: those with Cin % 128 == 0 and Cout % 64 == 0, except the 128 -> 64 transposed
+ * conv, which stays on its patch-resident fp16 kernel (10 at batch 64; LO_F8_FORCE=0 also leaves the shapes of the fused-tap fp16
+ * kernel in fp16: 6).  0 when the mode is off. */
 int lo_vae_fp8_layers(const LoVae* h, int* layers);
 /* where lo_vae_forward left an intermediate tensor inside the workspace (fp16 NHWC; dims4 = B, H, W, C), for parity tests
  * against the reference's hooked module outputs (lunar_generate.py:94-120, 168-190): which 0 = raw encoder conv output

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
-"""Per-layer answer to "why do only 6 of the 16 forward convolutions of the VAE run on e4m3 operands at batch 64" (VERDICT r3 item 8;
+"""Per-layer answer to "which of the 16 forward convolutions of the VAE should run on e4m3 operands at batch 64" (VERDICT r3 item 8;
 BASELINE.json configs[4]).  For every forward conv / transposed conv of the VAE (lunar_generate.py:95-119, 169-187) at batch 64: the
 fp16 launch the step uses (`lo_conv_forward`: the same launcher, which picks the fused-tap / patch-resident kernel where one applies)
 against the e4m3 implicit GEMM (`lo_conv_forward_f8`, activation quantisation not included), 200 warm-up + 100 timed calls each between
-two HIP events on the library's stream.  The e4m3 path exists for Cin % 128 == 0 and Cout % 64 == 0; where it is slower than the fp16
-kernel that owns the layer, the step keeps fp16.
+two HIP events on the library's stream.  The e4m3 path exists for Cin % 128 == 0 and Cout % 64 == 0; the step's fp8 mode uses it on every such layer but the 128 -> 64
+transposed conv, which the patch-resident fp16 kernel runs faster.
 
   python tools/fp8_layer_table.py > profiles/r04_fp8_per_layer.txt
 """
@@ -12,7 +12,6 @@ import ctypes as C
 import os
 import sys
 
-os.environ["LO_F8_FORCE"] = "1"     # before the library loads: time the e4m3 implicit GEMM on the shapes a fused-tap fp16 kernel owns, too
 
 import torch
 

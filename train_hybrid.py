@@ -79,7 +79,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many micro-batches (0 = no limit)")
     p.add_argument("--generate_samples", type=int, default=0, help="decode this many prior samples to PNG when training ends (lunar_generate.py:278-291)")
     p.add_argument("--mfma_precision", choices=["fp16", "fp8"], default="fp16",
-                   help="operand format of the VAE's forward convolutions: fp16 (parity-tested default) or fp8 = OCP e4m3 in the layers with Cin %% 128 == 0 that no fused-tap fp16 kernel owns at this batch size (11 of 16 at batch 2, 6 at batch 64), fp16 backward")
+                   help="operand format of the VAE's forward convolutions: fp16 (parity-tested default) or fp8 = OCP e4m3 in the layers with Cin %% 128 == 0 (10 of 16 at batch 64; the 128->64 transposed conv stays on its patch-resident fp16 kernel), fp16 backward")
     p.add_argument("--teacher_dropout", type=float, default=0.1,
                    help="dropout_rate of the teacher (the reference constructs it with its default 0.1, train_hybrid.py:400-404); 0 = dropout-free fast path")
     p.add_argument("--teacher_full_backward", action="store_true",
