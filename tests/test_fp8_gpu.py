@@ -213,6 +213,38 @@ def test_fp8_mode_loss_parity_at_batch64_latent512():
     assert abs(first["fp8"]["grad_norm"] - first["fp16"]["grad_norm"]) <= 2e-2 * first["fp16"]["grad_norm"]
 
 
+def test_fp8_mode_loss_parity_of_the_full_hybrid_step_at_batch64_latent512():
+    """The same assertion for the FULL hybrid step (BASELINE configs[2] shape with configs[4]'s operand mode): e4m3
+    operands in the VAE's forward convs and in the teacher's 48 3x3 convs of the step, against the fp16 mode from identical weights,
+    sprites, noise and dropout masks -- the first step's losses, the teacher's outputs and the reward bookkeeping (what bench.py reports
+    as `config5_fp8_forward.full_hybrid.loss_parity_vs_f16_first_step`)."""
+    from lunaris_orion_amd.teacher import LunarMoETeacher
+    from lunaris_orion_amd.trainer import HybridStepper
+    from oracle import teacher_ref as T
+    L, B = 512, 64
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    eps = R.closed_form_eps(B, L, salt=0).cuda()
+    first = {}
+    for prec in ("fp16", "fp8"):
+        m = _vae(L, prec)
+        t = LunarMoETeacher(num_experts=4, feature_dim=128, embedding_dim=64, dropout_rate=0.1, mfma_precision=prec)
+        t.load_state_dict(T.closed_form_teacher_state())
+        t = t.to("cuda").train()
+        t.set_dropout_stream(0x5EED0F8)
+        st = HybridStepper(m, t, lr=1e-4, teacher_lr=1e-4)
+        st.step(x, 0, eps)
+        first[prec] = st.metrics()
+        assert first[prec]["grads_finite"] == 1.0
+        del m, t, st
+        torch.cuda.empty_cache()
+    a, b = first["fp16"], first["fp8"]
+    print("hybrid B=64 / L=512 fp8 vs fp16:", {k: abs(a[k] - b[k]) for k in ("recon_loss", "kl_loss", "quality_scores", "teacher_loss", "baseline", "advantage")})
+    assert abs(a["recon_loss"] - b["recon_loss"]) <= 3e-3 and abs(a["kl_loss"] - b["kl_loss"]) <= 3e-3
+    assert abs(a["quality_scores"] - b["quality_scores"]) <= 5e-3 and abs(a["teacher_loss"] - b["teacher_loss"]) <= 5e-3
+    assert abs(a["baseline"] - b["baseline"]) <= 5e-3 and abs(a["grad_norm"] - b["grad_norm"]) <= 2e-2 * a["grad_norm"]
+    assert any(a[k] != b[k] for k in ("recon_loss", "quality_scores"))          # the mode is on
+
+
 @pytest.mark.parametrize("B,H", [(2, 128), (3, 32)])
 def test_teacher_fused_tap_conv_fp8_matches_fp16_kernel_on_dequantised_operands(B, H):
     """The teacher's 3x3 128->128 convolution kernel (lo_conv3x3_pp) on e4m3 operands against the SAME kernel in fp16 on the
