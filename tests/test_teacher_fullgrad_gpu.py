@@ -38,7 +38,17 @@ def _teacher(drop, F=128, emb=64):
     return m
 
 
+_ORACLE_CACHE = {}
+
+
 def _oracle_grads(x, drop, device="cpu", **kw):
+    key = (tuple(x.shape), bool(drop), device, tuple(sorted(kw.items())))
+    if key not in _ORACLE_CACHE:              # inputs are closed-form: the same (shape, dropout) always means the same numbers
+        _ORACLE_CACHE[key] = _oracle_grads_uncached(x, drop, device, **kw)
+    return _ORACLE_CACHE[key]
+
+
+def _oracle_grads_uncached(x, drop, device="cpu", **kw):
     S = T.closed_form_teacher_state(**kw)
     P = {k: (v.to(device).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "last_spatial" not in k else v.to(device))
          for k, v in S.items()}
