@@ -276,3 +276,17 @@ def test_module_with_full_backward_fills_every_grad_through_autograd():
         ds = (g.flatten()[idx] - ref).norm().item()
         assert ds <= 4e-2 * max(ref.norm().item(), 1e-3 * float(z["total_norm"]) * (len(idx) / g.numel()) ** 0.5) + 1e-12, (k, ds, ref.norm().item())
     assert n == 210
+
+
+def test_full_backward_is_bitwise_reproducible():
+    """Every reduction of the full backward has a fixed order (per-block partial rows + ordered sums, one writer per k / v row in the
+    attention, no float atomics): two fresh engines give bit-identical gradients, with the kept forward and with the recomputed one."""
+    B = 2
+    x = R.normalise_sprites(R.closed_form_sprites(B)).cuda()
+    for keep in (False, True):
+        runs = []
+        for _ in range(2):
+            got, _ = _native_grads(_teacher(True), x, True, keep)
+            runs.append(got)
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], runs[1][k]), (keep, k)
