@@ -331,10 +331,13 @@ int lo_teacher_heads_backward_ex(LoTeacher* h, const float* flat_state, const fl
  * gradients (parameter gradients come out unscaled; 64 * B * 16384 is a good value); bws = lo_teacher_full_backward_bytes(h) bytes
  * of scratch; rows as for lo_teacher_heads_backward; flat_grads = the whole state-table layout (lo_teacher_flat_elems floats):
  * every parameter on the loss path is written, everything else (the three heads the loss does not read, the softmax-invariant
- * relative-position tables, BatchNorm buffers) is zero. */
+ * relative-position tables, BatchNorm buffers) is zero.  After a plain lo_teacher_forward the trunk is recomputed first (one extra
+ * forward: the reference's own cost under checkpointing); after lo_teacher_forward_keep on the same bws nothing is. */
 size_t lo_teacher_full_backward_bytes(const LoTeacher* h);
-/* lo_teacher_forward(training = 1) through the plain expert path with every ExpertBlock's output kept inside bws: the forward to use
- * in a step that ends in lo_teacher_full_backward(..., the same bws), which then skips its own recomputation of the block inputs. */
+/* LunarMoETeacher.forward in train mode (outputs and side effects of lo_teacher_forward(training = 1)) in plain form, with every tensor
+ * the backward reads -- feature extractor and all 12 ExpertBlocks -- left inside bws: the forward to use in a step that ends in
+ * lo_teacher_full_backward(..., the same bws), which then recomputes nothing (26 GB of kept tensors at batch 64 / feature_dim 128; above
+ * 160 GB the plan keeps the block outputs only and the backward recomputes one block at a time). */
 int lo_teacher_forward_keep(LoTeacher* h, const float* images_nchw, float* flat_state, void* ws, void* bws, float dropout_p,
                             uint64_t drop_seed, float* quality_scores, float* expert_weights, float* style_embedding,
                             float* prompt_embedding, float* semantic_score, void* stream);

@@ -1224,9 +1224,9 @@ struct LoTeacher {
   // dropout of the last forward (lo_teacher_heads_backward replays the head masks), and which path it took:
   // 0 sparse (constant-field shortcuts), 1 dense (LO_T_DENSE=1), 2 dropout (train mode, dropout_p > 0)
   float last_p; uint64_t last_seed; int last_path;
-  // full-backward mode (lo_teacher_bwd.inc): lo_teacher_forward_keep runs the plain (generic) expert path for every feature_dim and
-  // leaves each block's output where lo_teacher_full_backward expects it, which then skips its own first pass
-  bool keep; f16* keep_xs[8][3]; const void* kept_bws; bool kept;
+  // full-backward mode (lo_teacher_bwd.inc): lo_teacher_forward_keep is a forward of its own (plain form, every tensor of every block
+  // kept inside the backward's scratch `kept_bws`); lo_teacher_full_backward on the same scratch then recomputes nothing
+  const void* kept_bws; bool kept;
 };
 
 // name -> index of the state table: hashed (a forward makes ~1000 of these look-ups; the linear scan over 351 names they used to be
@@ -1256,7 +1256,7 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
   h->B = B; h->E = num_experts; h->I = 256; h->emb = embedding_dim; h->layers = 3; h->F = F;
   h->att_zeroed = false; h->att_zeroed_ws = nullptr;
   h->last_p = 0.f; h->last_seed = 0; h->last_path = -1;
-  h->keep = false; h->kept = false; h->kept_bws = nullptr;
+  h->kept = false; h->kept_bws = nullptr;
   // ---- state table in the reference's state_dict order (lunar_evaluator.py; checked against the oracle in tests)
   auto add = [&](const std::string& k, size_t n, bool f = true) { h->names.push_back(k); h->numel.push_back(n); h->is_float.push_back(f); };
   auto conv = [&](const std::string& p, int co, int ci, int k, int groups = 1) { add(p + ".weight", (size_t)co * (ci / groups) * k * k); add(p + ".bias", co); };
@@ -1329,17 +1329,16 @@ extern "C" int lo_teacher_create_ex(int B, int num_experts, int feature_dim, int
       h->o_wqkv[e][l] = take((size_t)3 * F * F * 2);
       h->o_wproj[e][l] = take((size_t)F * F * 2);
     }
-  // the plain expert path: feature_dim 256 / 512 always, feature_dim 128 in keep mode (lo_teacher_forward_keep)
-  LO_TRYT(lo_make_geom(&h->g3a, LO_CONV3_S1, B, 128, 128, 128, F));
-  LO_TRYT(lo_make_geom(&h->g3b, LO_CONV3_S1, B, 128, 128, F, F));
-  LO_TRYT(lo_make_geom(&h->gqF, LO_LINEAR, B, 128, 128, F, 3 * F));
-  LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, F, F));
-  h->o_attc = take((size_t)B * 1024 * F * 2);
   if (F != 128) {
+    LO_TRYT(lo_make_geom(&h->g3a, LO_CONV3_S1, B, 128, 128, 128, F));
+    LO_TRYT(lo_make_geom(&h->g3b, LO_CONV3_S1, B, 128, 128, F, F));
+    LO_TRYT(lo_make_geom(&h->gqF, LO_LINEAR, B, 128, 128, F, 3 * F));
     LO_TRYT(lo_make_geom(&h->gsc, LO_LINEAR, B, 128, 128, 128, F));
+    LO_TRYT(lo_make_geom(&h->gpc, LO_LINEAR, B, 8, 128, F, F));
     for (int e = 0; e < num_experts; ++e) h->o_wsc[e] = take((size_t)F * 128 * 2);
     h->o_sc = take(px * F * 2);
     h->o_ss_sc = take((size_t)F * 2 * 4);
+    h->o_attc = take((size_t)B * 1024 * F * 2);
   }
   for (int b = 0; b < 3; ++b) h->o_wpw[b] = take((size_t)64 * 32 * 2);
   h->o_wfus = take((size_t)128 * 192 * 2);
@@ -1470,6 +1469,33 @@ static int t_pool(LoTeacher* h, float* pooled, int C, void* ws, hipStream_t st) 
   return LO_OK;
 }
 
+// gate, quality heads, weighted scores, style / prompt / semantic heads from the pooled features the trunk left in the workspace
+// (o_pool_f, o_pool_e): lunar_evaluator.py:417, 425, 431-449
+static int t_run_heads(LoTeacher* h, float* P, void* ws, float* quality, float* weights, float* style, float* prompt, float* semantic,
+                       uint32_t thr, float inv_keep, uint64_t drop_seed, hipStream_t st) {
+  const int B = h->B;
+  auto site = [&](uint32_t s) { return lo_drop_site_keys(drop_seed, s); };
+  HeadsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pooled_f = TW(float, h->o_pool_f); a.pooled_e = TW(float, h->o_pool_e);
+  a.g_w1 = TP("gate.2.weight"); a.g_b1 = TP("gate.2.bias"); a.g_w2 = TP("gate.5.weight"); a.g_b2 = TP("gate.5.bias");
+  auto headw = [&](const std::string& p) { return HeadW{TP(p + ".2.weight"), TP(p + ".2.bias"), TP(p + ".3.weight"), TP(p + ".3.bias"), TP(p + ".6.weight"), TP(p + ".6.bias")}; };
+  for (int e = 0; e < h->E; ++e) a.q[e] = headw("quality_heads." + std::to_string(e));
+  a.sem = headw("semantic_head"); a.style = headw("style_net"); a.prompt = headw("prompt_net");
+  a.quality = quality; a.weights = weights; a.style_out = style; a.prompt_out = prompt; a.sem_out = semantic;
+  a.raw_q = TW(float, h->o_rawq);
+  a.B = B; a.E = h->E; a.I = h->I; a.emb = h->emb; a.F = h->F;
+  a.thr = thr; a.inv_keep = inv_keep;
+  a.ds_gate = site(LO_DS_GATE); a.ds_sem = site(LO_DS_SEM); a.ds_style = site(LO_DS_STYLE); a.ds_prompt = site(LO_DS_PROMPT);
+  for (int e = 0; e < h->E; ++e) a.ds_q[e] = site(LO_DS_QUALITY(e));
+  {
+    LoProfScope _p("lo_t_heads", 0, 0, st);
+    hipLaunchKernelGGL(lo_t_heads_kernel, dim3(B), dim3(256), 0, st, a);
+  }
+  LO_LAUNCH_CHECK("t_heads");
+  return LO_OK;
+}
+
 // x: fp32 NCHW images.  P: flat state (parameters AND BatchNorm running statistics; the latter are updated in place when
 // training != 0).  outputs: quality_scores [B,4], expert_weights [B,E], style/prompt embeddings [B,emb], semantic [B,1].
 // dropout_p / drop_seed: train mode applies the reference's six dropout sites with probability dropout_p from the counter RNG
@@ -1505,7 +1531,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     LO_HIP(hipMemsetAsync(TW(void, h->o_att), 0, px * 128 * 2, st));   // positions >= 543 are never written again
     LO_HIP(hipMemsetAsync(TW(void, h->o_Z), 0, (size_t)B * 1024 * 1088 * 2, st));    // rows >= 543 of every sample stay zero
     LO_HIP(hipMemsetAsync(TW(void, h->o_qin), 0, (size_t)h->qrows * 128 * 2, st));
-    LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * h->F * 2, st));   // rows >= 543 of every sample stay zero
+    if (h->F != 128) LO_HIP(hipMemsetAsync(TW(void, h->o_attc), 0, (size_t)B * 1024 * h->F * 2, st));   // rows >= 543 of every sample stay zero
     h->att_zeroed = true; h->att_zeroed_ws = ws;
   }
   float* bnp = TW(float, h->o_bnp);
@@ -1559,23 +1585,22 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
                      f8 ? TW(uint8_t, h->o_feat8) : nullptr));
   LO_TRYT(t_pool(h, TW(float, h->o_pool_f), 128, ws, st));
   // ---- experts (lunar_evaluator.py:260-275, 422-428)
-  const bool plain = h->F != 128 || h->keep;
-  h->kept = false;
-  if (plain) {
-    // generic path (feature_dim 256 / 512, README High-End recipe; any feature_dim in keep mode): every tensor at full resolution; the attention keeps the
+  h->kept = false;                      // whatever lo_teacher_forward_keep left in a backward scratch no longer belongs to the last forward
+  if (h->F != 128) {
+    // generic path (feature_dim 256 / 512, README High-End recipe): every tensor at full resolution; the attention keeps the
     // reference's "only 543 positions are ever written" behaviour through compact rows (attc / projc) + one expansion pass,
     // which is also where proj_drop is applied
     const int F = h->F;
     h->last_path = drop ? 2 : 1;
-    const int lgc8 = F == 128 ? 4 : (F == 256 ? 5 : 6);
+    const int lgc8 = F == 256 ? 5 : 6;
     for (int e = 0; e < h->E; ++e) {
       const f16* xin = TW(f16, h->o_feat);
       for (int l = 0; l < 3; ++l) {
         std::string p = "experts." + std::to_string(e) + "." + std::to_string(l);
         const LoGeom& g1 = l == 0 ? h->g3a : h->g3b;
-        f16* xout = h->keep ? h->keep_xs[e][l] : TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
+        f16* xout = TW(f16, (l & 1) ? h->o_x1 : h->o_x0);
         const float* id_ss = nullptr;
-        if (l == 0 && F != 128) {
+        if (l == 0) {
           // shortcut = BatchNorm(Conv1x1(x)) (in_channels 128 != out_channels F): raw output + its (scale, shift), applied in the tail
           LoConvExtra exs{0, bnp};
           LO_TAGGED("t_shortcut (igemm)", lo_conv_run(h->gsc, xin, TW(f16, h->o_wsc[e]), TP(p + ".shortcut.0.bias"), nullptr, TW(f16, h->o_sc), nullptr, nullptr, 1, st, nullptr, &exs));
@@ -1595,8 +1620,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           LoProfScope _p("lo_t_attn (generic)", 0, 0, st);
           const dim3 grid((B * 543 + 3) / 4);
           const LoDropSite dsa = site(LO_DS_BLOCK(e, l, 1));
-          if (F == 128) hipLaunchKernelGGL((lo_t_attn_generic_kernel<16>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
-          else if (F == 256) hipLaunchKernelGGL((lo_t_attn_generic_kernel<32>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
+          if (F == 256) hipLaunchKernelGGL((lo_t_attn_generic_kernel<32>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
           else hipLaunchKernelGGL((lo_t_attn_generic_kernel<64>), grid, dim3(256), 0, st, TW(f16, h->o_qkv), TW(f16, h->o_attc), B, dsa, thr, inv_keep);
         }
         LO_LAUNCH_CHECK("t_attn_generic");
@@ -1604,10 +1628,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
         {
           LoProfScope _p("lo_t_projdrop", 0, 2.0 * px * F, st);
           const size_t nchunk = px * (F / 8);
-          if (lgc8 == 4)
-            hipLaunchKernelGGL((lo_t_projdrop_kernel<4>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
-                               TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
-          else if (lgc8 == 5)
+          if (lgc8 == 5)
             hipLaunchKernelGGL((lo_t_projdrop_kernel<5>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, st, TW(f16, h->o_projc), TP(p + ".attention.proj.bias"),
                                TW(f16, h->o_proj), (uint8_t*)nullptr, nchunk, site(LO_DS_BLOCK(e, l, 2)), thr, inv_keep);
           else
@@ -1623,16 +1644,15 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
           LO_LAUNCH_CHECK("t_drop2d_ss");
         }
         if (l < 2 || !stats_only)
-          LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), (l == 0 && F != 128) ? TW(f16, h->o_sc) : xin, (l < 2 || h->keep) ? xout : nullptr, F, F, 0, 1,
+          LO_TRYT(t_bn_apply(h, TW(f16, h->o_rawB), TP(p + ".layer_scale"), l == 0 ? TW(f16, h->o_sc) : xin, l < 2 ? xout : nullptr, F, F, 0, 1,
                              (l == 2 && !stats_only) ? TW(float, h->o_poolp) : nullptr, ws, st, nullptr, drop, nullptr, id_ss));
         xin = xout;
       }
       if (!stats_only) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * F, F, ws, st));
     }
-    h->kept = h->keep && !stats_only;
   }
   const int mt3 = lo_conv_bn_rows(h->g3);   // BatchNorm partial rows of the conv1 epilogue (igemm: M tiles; fused-tap kernel: pixel tiles)
-  for (int e = 0; e < (plain ? 0 : h->E); ++e) {
+  for (int e = 0; e < (h->F == 128 ? h->E : 0); ++e) {
     const f16* xin = TW(f16, h->o_feat);
     const uint8_t* xin8 = f8 ? TW(uint8_t, h->o_feat8) : nullptr;
     for (int l = 0; l < 3; ++l) {
@@ -1749,7 +1769,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     if ((drop && !stats_only) || (!drop && !h->fuse_tail)) LO_TRYT(t_pool(h, TW(float, h->o_pool_e) + (size_t)e * B * 128, 128, ws, st));
   }
   if (stats_only) return LO_OK;
-  if (h->fuse_tail && !drop && !plain) {
+  if (h->fuse_tail && !drop) {
     // x_3 of every expert is pooled in ONE pass over feat (the full-resolution x_l were never written)
     {
       LoProfScope _p("lo_t_pool (tail on load)", 0, 2.0 * px * 128, st);
@@ -1767,25 +1787,7 @@ extern "C" int lo_teacher_forward(LoTeacher* h, const float* x, float* P, void* 
     LO_LAUNCH_CHECK("pool_finalize");
   }
   // ---- heads (lunar_evaluator.py:417, 425, 431-449)
-  HeadsArgs a;
-  memset(&a, 0, sizeof(a));
-  a.pooled_f = TW(float, h->o_pool_f); a.pooled_e = TW(float, h->o_pool_e);
-  a.g_w1 = TP("gate.2.weight"); a.g_b1 = TP("gate.2.bias"); a.g_w2 = TP("gate.5.weight"); a.g_b2 = TP("gate.5.bias");
-  auto headw = [&](const std::string& p) { return HeadW{TP(p + ".2.weight"), TP(p + ".2.bias"), TP(p + ".3.weight"), TP(p + ".3.bias"), TP(p + ".6.weight"), TP(p + ".6.bias")}; };
-  for (int e = 0; e < h->E; ++e) a.q[e] = headw("quality_heads." + std::to_string(e));
-  a.sem = headw("semantic_head"); a.style = headw("style_net"); a.prompt = headw("prompt_net");
-  a.quality = quality; a.weights = weights; a.style_out = style; a.prompt_out = prompt; a.sem_out = semantic;
-  a.raw_q = TW(float, h->o_rawq);
-  a.B = B; a.E = h->E; a.I = h->I; a.emb = h->emb; a.F = h->F;
-  a.thr = thr; a.inv_keep = inv_keep;
-  a.ds_gate = site(LO_DS_GATE); a.ds_sem = site(LO_DS_SEM); a.ds_style = site(LO_DS_STYLE); a.ds_prompt = site(LO_DS_PROMPT);
-  for (int e = 0; e < h->E; ++e) a.ds_q[e] = site(LO_DS_QUALITY(e));
-  {
-    LoProfScope _p("lo_t_heads", 0, 0, st);
-    hipLaunchKernelGGL(lo_t_heads_kernel, dim3(B), dim3(256), 0, st, a);
-  }
-  LO_LAUNCH_CHECK("t_heads");
-  return LO_OK;
+  return t_run_heads(h, P, ws, quality, weights, style, prompt, semantic, thr, inv_keep, drop_seed, st);
 }
 
 // the keep decisions of one dropout site as bytes (what lo_teacher_forward applies for this call seed): checked bit for bit
