@@ -217,7 +217,7 @@ def test_bench_two_rank_control_flow_on_one_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["vae_only", "hybrid"])
+@pytest.mark.parametrize("mode", ["vae_only", "hybrid", "hybrid_full_backward"])
 def test_cli_two_ranks_on_one_gpu(tmp_path, mode):
     """train_hybrid.py under `torch.distributed.run` with two ranks (rehearsal: both on the test box's one GPU, gloo carrying the
     collectives): disjoint shards per rank, the phased backward with the three overlapped exchanges, the rank-consistent
@@ -229,9 +229,10 @@ def test_cli_two_ranks_on_one_gpu(tmp_path, mode):
     out = tmp_path / "out"
     env = dict(os.environ, LO_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29543" if mode == "vae_only" else "29545", os.path.join(ROOT, "train_hybrid.py"), "--data_dir", str(data), "--output_dir", str(out),
+                        "--master-port", {"vae_only": "29543", "hybrid": "29545", "hybrid_full_backward": "29547"}[mode], os.path.join(ROOT, "train_hybrid.py"),
+                        "--data_dir", str(data), "--output_dir", str(out),
                         "--batch_size", "4", "--gradient_accumulation_steps", "1", "--num_epochs", "2", "--log_every", "1",
-                        "--latent_dim", "256"] + (["--vae_only"] if mode == "vae_only" else []),
+                        "--latent_dim", "256"] + {"vae_only": ["--vae_only"], "hybrid": [], "hybrid_full_backward": ["--teacher_full_backward"]}[mode],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     log = (out / "training.log").read_text()
@@ -240,3 +241,8 @@ def test_cli_two_ranks_on_one_gpu(tmp_path, mode):
     import torch
     ck = torch.load(out / "checkpoints" / "latest.pt", map_location="cpu", weights_only=False)
     assert ck["global_step"] == 2 * ((int(0.9 * 40) // 2) // 4)
+    if mode == "hybrid_full_backward":
+        # --teacher_full_backward under data parallel: the whole flat teacher gradient is averaged across the ranks and every live
+        # tensor is updated (second moments of the expert / feature-extractor weights have moved)
+        st = ck["teacher_optimizer"]["state"]
+        assert sum(1 for s_ in st.values() if float(s_["exp_avg_sq"].abs().sum()) > 0) == 210
