@@ -766,7 +766,7 @@ struct ConvT4PatchArgs {
 // phases of a (parity, channel block): 2 * COUT rows of 512 B (4 taps x 64 channels); the accumulators run over the channel blocks.
 // DG: the same kernel as the DATA GRADIENT of a stride-2 3x3 convolution (LO_CONV3_S2_DGRAD: four sub-pixel phases of 1 / 2 / 2 / 4
 // taps reading the same 17 x 17 patch of dy, 9 tap products instead of 16): tap slots past T[phase] of the 512-byte weight rows are
-// filled from the zero page and skipped in the K loop, the residual (skip) gradient is added to the accumulators.  On lo_igemm_nt
+// filled from the zero page and skipped in the K loop, the residual (skip) gradient is added in the coalesced store loop.  On lo_igemm_nt
 // the four phases are separate tiles with K = 128 ... 512: prologue- and epilogue-bound (46 us for 9.7 GFLOP at batch 64).
 template <int NCB, int COUT, bool DG = false>
 __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArgs a) {
@@ -888,11 +888,7 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
         const int row = 2 * wave + rr, ox = 2 * fr + pw;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          f32x4 v = acc[pw][rr][nf] + bv[nf];
-          if (DG && a.add_src) {
-            const f16x4 r4 = *reinterpret_cast<const f16x4*>(a.add_src + ((size_t)(n_img * 2 * H + 2 * (y0 + row) + par) * (2 * W) + 2 * x0 + ox) * COUT + nf * 16 + 4 * fq);
-            v += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
-          }
+          const f32x4 v = acc[pw][rr][nf] + bv[nf];
           const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
           const int chunk = nf * 2 + (fq >> 1);
           *reinterpret_cast<f16x4*>(s_w + (row * 32 + ox) * (COUT * 2) + ((chunk ^ ((ox >> 1) & (OCH - 1))) * 16) + (fq & 1) * 8) = h;
@@ -904,9 +900,18 @@ __global__ __launch_bounds__(512) void lo_convt4_patch_fwd_kernel(ConvT4PatchArg
 #pragma unroll
     for (int i = 0; i < OCH; ++i) {
       const int c = tid + 512 * i, chunk = c % OCH, k = c / OCH, ox = k & 31, row = k >> 5;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(s_w + (row * 32 + ox) * (COUT * 2) + ((chunk ^ ((ox >> 1) & (OCH - 1))) * 16));
+      u32x4 v = *reinterpret_cast<const u32x4*>(s_w + (row * 32 + ox) * (COUT * 2) + ((chunk ^ ((ox >> 1) & (OCH - 1))) * 16));
       const int oy = 2 * (y0 + row) + par;
-      *reinterpret_cast<u32x4*>(a.out + ((size_t)(n_img * 2 * H + oy) * (2 * W) + 2 * x0 + ox) * COUT + chunk * 8) = v;
+      const size_t oo = ((size_t)(n_img * 2 * H + oy) * (2 * W) + 2 * x0 + ox) * COUT + chunk * 8;
+      if (DG && a.add_src) {
+        // the residual (skip) gradient joins here, on the coalesced side: fp16(fp16(acc) + r), the same two roundings as lo_igemm_nt's epilogue
+        const f16x8 r = *reinterpret_cast<const f16x8*>(a.add_src + oo);
+        f16x8 hv = *reinterpret_cast<f16x8*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = (f16)((float)hv[j] + (float)r[j]);
+        v = *reinterpret_cast<u32x4*>(&hv);
+      }
+      *reinterpret_cast<u32x4*>(a.out + oo) = v;
     }
     if (par == 0) {
       __syncthreads();                       // the staged block has been read
